@@ -1,0 +1,585 @@
+// chol.hip -- blocked right-looking Cholesky with friedrich's pivot rules, GEMM-recast triangular solves,
+// the bordered row-append update, and the C ABI around the device-resident factor.
+//
+// Reference behaviour being replaced (all single-threaded nalgebra loops there):
+//   make_cholesky_cov_matrix        src/algebra/mod.rs:59-92      (Gram + noise^2 + Cholesky::new[_with_substitute])
+//   add_rows_cholesky_cov_matrix    src/algebra/mod.rs:97-126     (one Cholesky::insert_column per new row)
+//   Cholesky::solve_mut / solve     src/gaussian_process/mod.rs:235, 298, 379
+//   Cholesky::l().solve_lower_triangular                          mod.rs:203, 260-263, 342-345
+//   Cholesky::inverse               src/gaussian_process/optimizer.rs:32, 169
+//   DMatrix::cholesky().unpack()    src/gaussian_process/multivariate_normal.rs:57
+//
+// Structure.  Three block sizes:
+//   64   K4 potf2: one workgroup factors + inverts a diagonal block in LDS (potf2.hip)
+//   128  "inverse block": L's diagonal is covered by 128 x 128 blocks whose explicit inverses are kept next to
+//        the factor (fr_chol::dinv).  Every triangular solve -- inside the factorisation and in the predict
+//        family -- is a chain of FP64-MFMA GEMMs against these inverses; with N (or M) <= 128 the GEMM has a
+//        single tile column (row), so it can safely run in place.
+//   nb   (default 256) outer block: the trailing update A22 -= P P^T is one lower-triangular SYRK launch with
+//        K = nb, the dominant FP64-MFMA kernel (n^3/3 of the flops).
+#include "fr_internal.hpp"
+#include "kprog_device.hpp"
+
+namespace fr {
+
+constexpr int64_t IB = 128;            // inverse block
+constexpr int64_t INV_ELEMS = IB * IB;
+
+static inline int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
+static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
+
+static int gemm(fr_ctx* ctx, int cls, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, bool a_kmajor,
+                const double* B, int64_t ldb, bool b_kmajor, double alpha, double beta, double* D, int64_t ldd,
+                bool lower = false)
+{
+    GemmDesc g;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.A = A;
+    g.lda = lda;
+    g.a_kmajor = a_kmajor;
+    g.B = B;
+    g.ldb = ldb;
+    g.b_kmajor = b_kmajor;
+    g.Cin = D;
+    g.ldcin = ldd;
+    g.D = D;
+    g.ldd = ldd;
+    g.alpha = alpha;
+    g.beta = beta;
+    g.lower = lower;
+    g.prof_cls = cls;
+    return launch_gemm(ctx, g);
+}
+
+// inv21 = -inv22 * L21 * inv11 for a 128-block split at n1 (inverse of a 2x2 block lower-triangular matrix)
+static int combine_inverse(fr_ctx* ctx, const double* L21, int64_t ldl, double* inv, int64_t n1, int64_t n2, double* T)
+{
+    // T (n2 x n1) = L21 * inv11
+    FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n2, n1, n1, L21, ldl, false, inv, IB, true, 1.0, 0.0, T, 64));
+    // inv21 = -inv22 * T
+    return gemm(ctx, FR_PROF_GEMM_PANEL, n2, n1, n2, inv + n1 + n1 * IB, IB, false, T, 64, true, -1.0, 0.0, inv + n1, IB);
+}
+
+// Factor the sb x sb (sb <= 128) diagonal block at A and produce its inverse in `inv` (ld 128).
+static int factor_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, int64_t col, int mode, double sub, double* inv,
+                           int64_t* info, double* T)
+{
+    const int64_t n1 = imin(kDiagBlock, sb), n2 = sb - n1;
+    FR_TRY(launch_fill(ctx, inv, IB, IB, IB, 0.0));
+    FR_TRY(launch_potf2(ctx, A, ld, n1, col, mode, sub, inv, IB, info));
+    if (n2 > 0) {
+        double* A21 = A + n1;
+        double* A22 = A + n1 + n1 * ld;
+        // A21 <- A21 * inv11^T   (op(B)[k][n] = inv11[n][k]: n-major)
+        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n2, n1, n1, A21, ld, false, inv, IB, false, 1.0, 0.0, A21, ld));
+        // A22 -= A21 * A21^T
+        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n2, n2, n1, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
+        FR_TRY(launch_potf2(ctx, A22, ld, n2, col + n1, mode, sub, inv + n1 + n1 * IB, IB, info));
+        FR_TRY(combine_inverse(ctx, A21, ld, inv, n1, n2, T));
+    }
+    return FR_OK;
+}
+
+// Rebuild the inverse of an already factored 128-block (serde upload, add_rows re-alignment).
+static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, double* inv, double* T)
+{
+    const int64_t n1 = imin(kDiagBlock, sb), n2 = sb - n1;
+    FR_TRY(launch_fill(ctx, inv, IB, IB, IB, 0.0));
+    FR_TRY(launch_potf2(ctx, A, ld, n1, 0, 3, 0.0, inv, IB, nullptr));
+    if (n2 > 0) {
+        FR_TRY(launch_potf2(ctx, A + n1 + n1 * ld, ld, n2, 0, 3, 0.0, inv + n1 + n1 * IB, IB, nullptr));
+        FR_TRY(combine_inverse(ctx, A + n1, ld, inv, n1, n2, T));
+    }
+    return FR_OK;
+}
+
+// In-place blocked Cholesky of the n x n lower triangle at A.  dinv receives the inverses of the diagonal
+// 128-blocks (block i of this sub-matrix at dinv + i*INV_ELEMS).
+static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
+                         int64_t* info, int64_t nb)
+{
+    if (n <= 0) return FR_OK;
+    WsGuard tg(ctx);
+    double* T = tg.get(sizeof(double) * 64 * 64);
+    if (!T) return FR_OUT_OF_MEMORY;
+    for (int64_t k = 0; k < n; k += nb) {
+        const int64_t kb = imin(nb, n - k);
+        for (int64_t s = 0; s < kb; s += IB) {
+            const int64_t j = k + s, sb = imin(IB, kb - s);
+            double* inv = dinv + (j / IB) * INV_ELEMS;
+            FR_TRY(factor_block128(ctx, A + j + j * ld, ld, sb, col0 + j, mode, sub, inv, info, T));
+            const int64_t below = n - (j + sb);
+            if (below > 0) {
+                // K5: panel TRSM  B <- B * L_jj^-T  as a GEMM against the explicit inverse
+                double* B = A + (j + sb) + j * ld;
+                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, sb, sb, B, ld, false, inv, IB, false, 1.0, 0.0, B, ld));
+                const int64_t right = kb - (s + sb);
+                if (right > 0)  // remaining columns of this outer block (left-looking inside the block)
+                    FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, right, sb, B, ld, false, B, ld, false, -1.0, 1.0,
+                                A + (j + sb) + (j + sb) * ld, ld));
+            }
+        }
+        const int64_t rest = n - (k + kb);
+        if (rest > 0) {
+            // K6: trailing update, lower triangle only
+            const double* P = A + (k + kb) + k * ld;
+            FR_TRY(gemm(ctx, FR_PROF_SYRK, rest, rest, kb, P, ld, false, P, ld, false, -1.0, 1.0,
+                        A + (k + kb) + (k + kb) * ld, ld, true));
+        }
+    }
+    return FR_OK;
+}
+
+static inline int64_t split128(int64_t n)
+{
+    const int64_t nbk = (n + IB - 1) / IB;
+    return (nbk / 2) * IB;
+}
+
+// B (n x m) <- L^-1 B
+static int trsm_fwd_rec(fr_ctx* ctx, const double* L, int64_t ld, const double* dinv, int64_t n, double* B, int64_t m,
+                        int64_t ldb, int cls)
+{
+    if (n <= IB) return gemm(ctx, cls, n, m, n, dinv, IB, false, B, ldb, true, 1.0, 0.0, B, ldb);
+    const int64_t n1 = split128(n);
+    FR_TRY(trsm_fwd_rec(ctx, L, ld, dinv, n1, B, m, ldb, cls));
+    FR_TRY(gemm(ctx, cls, n - n1, m, n1, L + n1, ld, false, B, ldb, true, -1.0, 1.0, B + n1, ldb));
+    return trsm_fwd_rec(ctx, L + n1 + n1 * ld, ld, dinv + (n1 / IB) * INV_ELEMS, n - n1, B + n1, m, ldb, cls);
+}
+
+// B (n x m) <- L^-T B
+static int trsm_bwd_rec(fr_ctx* ctx, const double* L, int64_t ld, const double* dinv, int64_t n, double* B, int64_t m,
+                        int64_t ldb, int cls)
+{
+    if (n <= IB) return gemm(ctx, cls, n, m, n, dinv, IB, true, B, ldb, true, 1.0, 0.0, B, ldb);
+    const int64_t n1 = split128(n);
+    FR_TRY(trsm_bwd_rec(ctx, L + n1 + n1 * ld, ld, dinv + (n1 / IB) * INV_ELEMS, n - n1, B + n1, m, ldb, cls));
+    // B1 -= L21^T * B2    (op(A)[m][k] = L21[k][m]: k-major)
+    FR_TRY(gemm(ctx, cls, n1, m, n - n1, L + n1, ld, true, B + n1, ldb, true, -1.0, 1.0, B, ldb));
+    return trsm_bwd_rec(ctx, L, ld, dinv, n1, B, m, ldb, cls);
+}
+
+// X (k x n) <- X L^-T
+static int trsm_right_rec(fr_ctx* ctx, const double* L, int64_t ld, const double* dinv, int64_t n, double* X, int64_t k,
+                          int64_t ldx, int cls)
+{
+    if (n <= IB) return gemm(ctx, cls, k, n, n, X, ldx, false, dinv, IB, false, 1.0, 0.0, X, ldx);
+    const int64_t n1 = split128(n);
+    FR_TRY(trsm_right_rec(ctx, L, ld, dinv, n1, X, k, ldx, cls));
+    // X2 -= X1 * L21^T
+    FR_TRY(gemm(ctx, cls, k, n - n1, n1, X, ldx, false, L + n1, ld, false, -1.0, 1.0, X + n1 * ldx, ldx));
+    return trsm_right_rec(ctx, L + n1 + n1 * ld, ld, dinv + (n1 / IB) * INV_ELEMS, n - n1, X + n1 * ldx, k, ldx, cls);
+}
+
+int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
+{
+    if (n <= 0 || m <= 0) return FR_OK;
+    return trsm_fwd_rec(ctx, c->A, c->ld_a, c->dinv, n, B, m, ldb, cls);
+}
+
+int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
+{
+    if (n <= 0 || m <= 0) return FR_OK;
+    return trsm_bwd_rec(ctx, c->A, c->ld_a, c->dinv, n, B, m, ldb, cls);
+}
+
+static void chol_release(fr_chol* c)
+{
+    if (c->A) (void)hipFree(c->A);
+    if (c->X) (void)hipFree(c->X);
+    if (c->dinv) (void)hipFree(c->dinv);
+    if (c->info) (void)hipFree(c->info);
+    c->A = c->X = c->dinv = nullptr;
+    c->info = nullptr;
+}
+
+static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t d)
+{
+    c->capacity = imax(capacity, 1);
+    c->ld_a = round_up(c->capacity, kAlign);
+    c->ld_x = c->ld_a;
+    c->d = d;
+    const int64_t nblk = (c->capacity + IB - 1) / IB;
+    c->info_cap = 3 + c->capacity;
+    hipError_t e = hipMalloc((void**)&c->A, sizeof(double) * (size_t)c->ld_a * (size_t)c->capacity);
+    if (e == hipSuccess && d > 0) e = hipMalloc((void**)&c->X, sizeof(double) * (size_t)c->ld_x * (size_t)d);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->dinv, sizeof(double) * (size_t)nblk * INV_ELEMS);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->info, sizeof(int64_t) * (size_t)c->info_cap);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        chol_release(c);
+        return set_err(ctx, FR_OUT_OF_MEMORY, "cannot allocate a %lld x %lld factor: %s", (long long)capacity,
+                       (long long)capacity, hipGetErrorString(e));
+    }
+    return FR_OK;
+}
+
+int chol_alloc(fr_ctx* ctx, int64_t n, int64_t capacity, int64_t d, fr_chol** out)
+{
+    fr_chol* c = new fr_chol();
+    c->ctx = ctx;
+    c->n = n;
+    c->nb = ctx->nb;
+    int st = chol_alloc_buffers(ctx, c, imax(capacity, n), d);
+    if (st != FR_OK) {
+        delete c;
+        return st;
+    }
+    *out = c;
+    return FR_OK;
+}
+
+int chol_fetch_info(fr_chol* c)
+{
+    fr_ctx* ctx = c->ctx;
+    int64_t head[3] = {0, 0, 0};
+    FR_HIP(ctx, hipMemcpyAsync(head, c->info, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    c->fail_col = head[0] - 1;
+    c->n_subst = head[1];
+    c->subst.resize((size_t)c->n_subst);
+    if (c->n_subst > 0) {
+        FR_HIP(ctx, hipMemcpyAsync(c->subst.data(), c->info + 3, sizeof(int64_t) * (size_t)c->n_subst,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FR_OK;
+}
+
+int potrf_device(fr_ctx* ctx, fr_chol* c, int64_t j0, int64_t n, int mode, double sub)
+{
+    return potrf_blocked(ctx, c->A + j0 + j0 * c->ld_a, c->ld_a, n, j0, mode, sub, c->dinv + (j0 / IB) * INV_ELEMS, c->info,
+                         c->nb);
+}
+
+// Factor an arbitrary device matrix in place with scratch inverse blocks / info (sample_at's m x m factor).
+int potrf_matrix_ws(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int mode, double sub, int64_t* fail_col)
+{
+    *fail_col = -1;
+    if (n <= 0) return FR_OK;
+    WsGuard dg(ctx), ig(ctx);
+    const int64_t nblk = (n + IB - 1) / IB;
+    double* dinv_tmp = dg.get(sizeof(double) * (size_t)nblk * INV_ELEMS);
+    int64_t* info = (int64_t*)ig.get(sizeof(int64_t) * (size_t)(3 + n));
+    if (!dinv_tmp || !info) return FR_OUT_OF_MEMORY;
+    FR_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int64_t) * 3, ctx->stream));
+    FR_TRY(potrf_blocked(ctx, A, ld, n, 0, mode, sub, dinv_tmp, info, ctx->nb));
+    int64_t head = 0;
+    FR_HIP(ctx, hipMemcpyAsync(&head, info, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *fail_col = head - 1;
+    return FR_OK;
+}
+
+// Gram (lower + noise^2) from the resident inputs, then the factorisation; fills the host info mirror.
+static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise, int has_eps, double eps)
+{
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
+    FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a));
+    FR_TRY(potrf_device(ctx, c, 0, c->n, has_eps ? 1 : 0, eps));
+    FR_TRY(chol_fetch_info(c));
+    if (c->fail_col >= 0)
+        return set_err(ctx, FR_NOT_POSITIVE_DEFINITE,
+                       has_eps ? "Cholesky decomposition failed even though we used `cholesky_epsilon` value of %g (column %lld)"
+                               : "Cholesky decomposition failed, consider setting `cholesky_epsilon` via "
+                                 "`GaussianProcessBuilder` (eps %g unused; column %lld)",
+                       eps, (long long)c->fail_col);
+    return FR_OK;
+}
+
+static int upload_rows(fr_ctx* ctx, const double* src, int64_t ldsrc, double* dst, int64_t lddst, int64_t rows,
+                       int64_t cols)
+{
+    if (rows <= 0 || cols <= 0) return FR_OK;
+    const bool dev = is_device_ptr(src);
+    FR_HIP(ctx, hipMemcpy2DAsync(dst, sizeof(double) * lddst, src, sizeof(double) * ldsrc, sizeof(double) * rows, cols,
+                                 dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (!dev) FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FR_OK;
+}
+
+// EMatrix::add_rows growth policy (extendable_matrix.rs:33-43): max(required, 3*capacity/2)
+static int chol_grow(fr_chol* c, int64_t required)
+{
+    fr_ctx* ctx = c->ctx;
+    if (required <= c->capacity) return FR_OK;
+    const int64_t new_cap = imax(required, (3 * c->capacity) / 2);
+    fr_chol nc;
+    nc.ctx = ctx;
+    FR_TRY(chol_alloc_buffers(ctx, &nc, new_cap, c->d));
+    int st = FR_OK;
+    hipError_t e = hipSuccess;
+    if (c->n > 0) {
+        e = hipMemcpy2DAsync(nc.A, sizeof(double) * nc.ld_a, c->A, sizeof(double) * c->ld_a, sizeof(double) * c->n, c->n,
+                             hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess && c->d > 0)
+            e = hipMemcpy2DAsync(nc.X, sizeof(double) * nc.ld_x, c->X, sizeof(double) * c->ld_x, sizeof(double) * c->n,
+                                 c->d, hipMemcpyDeviceToDevice, ctx->stream);
+        const int64_t nblk = (c->n + IB - 1) / IB;
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(nc.dinv, c->dinv, sizeof(double) * (size_t)nblk * INV_ELEMS, hipMemcpyDeviceToDevice,
+                               ctx->stream);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(nc.info, c->info, sizeof(int64_t) * (size_t)imin(c->info_cap, nc.info_cap),
+                           hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        st = set_err(ctx, FR_HIP_ERROR, "growing the factor failed: %s", hipGetErrorString(e));
+        chol_release(&nc);
+        return st;
+    }
+    chol_release(c);
+    c->A = nc.A;
+    c->X = nc.X;
+    c->dinv = nc.dinv;
+    c->info = nc.info;
+    c->capacity = nc.capacity;
+    c->ld_a = nc.ld_a;
+    c->ld_x = nc.ld_x;
+    c->info_cap = nc.info_cap;
+    nc.A = nc.X = nc.dinv = nullptr;
+    nc.info = nullptr;
+    return FR_OK;
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" {
+
+int fr_chol_from_inputs(fr_ctx* ctx, const fr_kprog* kernel, const double* X, int64_t n, int64_t ldx, int64_t d,
+                        double noise, int has_eps, double eps, int64_t capacity_hint, fr_chol** out)
+{
+    if (!ctx || !out) return FR_INVALID_ARGUMENT;
+    *out = nullptr;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    FR_TRY(kprog_check(ctx, kernel));
+    if (n < 0 || d < 0 || ldx < imax(n, 1)) return set_err(ctx, FR_SHAPE, "bad training input shape");
+    if (n > 0 && d > 0 && !X) return set_err(ctx, FR_INVALID_ARGUMENT, "null training inputs");
+    fr_chol* c = nullptr;
+    FR_TRY(chol_alloc(ctx, n, imax(capacity_hint, n), d, &c));
+    int st = upload_rows(ctx, X, ldx, c->X, c->ld_x, n, d);
+    if (st == FR_OK) st = assemble_and_factor(c, kernel, noise, has_eps, eps);
+    if (st != FR_OK && st != FR_NOT_POSITIVE_DEFINITE) {
+        fr_chol_free(c);
+        return st;
+    }
+    *out = c;
+    return st;
+}
+
+int fr_chol_refactor(fr_chol* c, const fr_kprog* kernel, double noise, int has_eps, double eps)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    FR_TRY(kprog_check(ctx, kernel));
+    if (c->d == 0 && c->n > 0 && !c->X) return set_err(ctx, FR_INVALID_ARGUMENT, "factor holds no training inputs");
+    c->nb = ctx->nb;
+    return assemble_and_factor(c, kernel, noise, has_eps, eps);
+}
+
+int fr_chol_from_matrix(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int has_eps, double eps, fr_chol** out)
+{
+    if (!ctx || !out) return FR_INVALID_ARGUMENT;
+    *out = nullptr;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    if (n < 0 || lda < imax(n, 1)) return set_err(ctx, FR_SHAPE, "bad matrix shape");
+    fr_chol* c = nullptr;
+    FR_TRY(chol_alloc(ctx, n, n, 0, &c));
+    int st = upload_rows(ctx, A, lda, c->A, c->ld_a, n, n);
+    if (st == FR_OK) {
+        hipError_t e = hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream);
+        if (e != hipSuccess) st = set_err(ctx, FR_HIP_ERROR, "memset failed");
+    }
+    if (st == FR_OK) st = potrf_device(ctx, c, 0, n, has_eps ? 1 : 0, eps);
+    if (st == FR_OK) st = chol_fetch_info(c);
+    if (st == FR_OK && c->fail_col >= 0)
+        st = set_err(ctx, FR_NOT_POSITIVE_DEFINITE, "Cholesky decomposition failed at column %lld", (long long)c->fail_col);
+    if (st != FR_OK && st != FR_NOT_POSITIVE_DEFINITE) {
+        fr_chol_free(c);
+        return st;
+    }
+    *out = c;
+    return st;
+}
+
+int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int64_t n_all, int64_t ldx, int64_t d,
+                     int64_t nb_new, double noise)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    FR_TRY(kprog_check(ctx, kernel));
+    const int64_t n_old = n_all - nb_new;  // algebra/mod.rs:102
+    if (nb_new < 0 || n_old != c->n) return set_err(ctx, FR_SHAPE, "add_rows: factor holds %lld rows, inputs imply %lld",
+                                                     (long long)c->n, (long long)n_old);
+    if (d != c->d) return set_err(ctx, FR_SHAPE, "add_rows: feature count %lld != %lld", (long long)d, (long long)c->d);
+    if (ldx < imax(n_all, 1)) return set_err(ctx, FR_SHAPE, "add_rows: bad leading dimension");
+    if (nb_new == 0) return FR_OK;
+    FR_TRY(chol_grow(c, n_all));
+    c->nb = ctx->nb;
+    // new rows of the EMatrix mirror
+    FR_TRY(upload_rows(ctx, Xall + n_old, ldx, c->X + n_old, c->ld_x, nb_new, d));
+    const int64_t ld = c->ld_a;
+    double* A21 = c->A + n_old;               // nb_new x n_old
+    double* A22 = c->A + n_old + n_old * ld;  // nb_new x nb_new
+    // K21 = k(new, old), K22 = lower(k(new, new)) + noise^2 I       (algebra/mod.rs:115-121)
+    FR_TRY(launch_gram_cross(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, c->X, n_old, c->ld_x, d, A21, ld));
+    FR_TRY(launch_gram_sym(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, d, noise * noise, A22, ld));
+    // L21 = K21 L11^-T ; K22 -= L21 L21^T ; L22 = chol(K22) with insert_column's plain sqrt (mode 2)
+    if (n_old > 0) {
+        FR_TRY(trsm_right_rec(ctx, c->A, ld, c->dinv, n_old, A21, nb_new, ld, FR_PROF_GEMM_PANEL));
+        FR_TRY(gemm(ctx, FR_PROF_SYRK, nb_new, nb_new, n_old, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
+    }
+    {
+        WsGuard tmp(ctx);
+        const int64_t nblk = (nb_new + IB - 1) / IB;
+        double* dinv_tmp = tmp.get(sizeof(double) * (size_t)nblk * INV_ELEMS);
+        if (!dinv_tmp) return FR_OUT_OF_MEMORY;
+        FR_TRY(potrf_blocked(ctx, A22, ld, nb_new, n_old, 2, 0.0, dinv_tmp, c->info, c->nb));
+    }
+    c->n = n_all;
+    // re-align the inverse blocks with the global 128-grid over the rows that changed
+    {
+        WsGuard tg(ctx);
+        double* T = tg.get(sizeof(double) * 64 * 64);
+        if (!T) return FR_OUT_OF_MEMORY;
+        for (int64_t b = n_old / IB; b * IB < n_all; ++b) {
+            const int64_t j = b * IB, sb = imin(IB, n_all - j);
+            FR_TRY(invert_block128(ctx, c->A + j + j * ld, ld, sb, c->dinv + b * INV_ELEMS, T));
+        }
+    }
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FR_OK;
+}
+
+int fr_chol_info(const fr_chol* c, int64_t* n, int64_t* capacity, int64_t* d, int64_t* n_subst, int64_t* fail_col)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    if (n) *n = c->n;
+    if (capacity) *capacity = c->capacity;
+    if (d) *d = c->d;
+    if (n_subst) *n_subst = c->n_subst;
+    if (fail_col) *fail_col = c->fail_col;
+    return FR_OK;
+}
+
+int fr_chol_substitutions(const fr_chol* c, int64_t* idx, int64_t max_idx)
+{
+    if (!c || (!idx && max_idx > 0)) return FR_INVALID_ARGUMENT;
+    for (int64_t i = 0; i < c->n_subst && i < max_idx; ++i) idx[i] = c->subst[(size_t)i];
+    return FR_OK;
+}
+
+int fr_chol_solve(fr_chol* c, double* B, int64_t m, int64_t ldb)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    Staged b(ctx);
+    FR_TRY(b.inout(B, c->n, m, ldb));
+    FR_TRY(trsm_lower_fwd(ctx, c, c->n, b.dev, m, b.ld, FR_PROF_GEMM_SOLVE));
+    FR_TRY(trsm_lower_bwd(ctx, c, c->n, b.dev, m, b.ld, FR_PROF_GEMM_SOLVE));
+    return b.commit();
+}
+
+static int check_zero_diag(fr_chol* c, const char* what)
+{
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipMemsetAsync(c->info + 2, 0, sizeof(int64_t), ctx->stream));
+    FR_TRY(launch_diag_check_zero(ctx, c->A, c->n, c->ld_a, c->info + 2));
+    int64_t flag = 0;
+    FR_HIP(ctx, hipMemcpyAsync(&flag, c->info + 2, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) return set_err(ctx, FR_SINGULAR_SOLVE, "%s : solve failed", what);
+    return FR_OK;
+}
+
+int fr_chol_solve_lower(fr_chol* c, double* B, int64_t m, int64_t ldb)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    FR_TRY(check_zero_diag(c, "solve_lower_triangular"));
+    Staged b(ctx);
+    FR_TRY(b.inout(B, c->n, m, ldb));
+    FR_TRY(trsm_lower_fwd(ctx, c, c->n, b.dev, m, b.ld, FR_PROF_GEMM_SOLVE));
+    return b.commit();
+}
+
+int fr_chol_inverse(fr_chol* c, double* out, int64_t ldo)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    Staged o(ctx);
+    FR_TRY(o.out(out, c->n, c->n, ldo));
+    FR_TRY(launch_set_identity(ctx, o.dev, c->n, o.ld));
+    FR_TRY(trsm_lower_fwd(ctx, c, c->n, o.dev, c->n, o.ld, FR_PROF_GEMM_SOLVE));
+    FR_TRY(trsm_lower_bwd(ctx, c, c->n, o.dev, c->n, o.ld, FR_PROF_GEMM_SOLVE));
+    return o.commit();
+}
+
+int fr_chol_download_l(fr_chol* c, double* out, int64_t ldo, int upper_fill)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    Staged o(ctx);
+    FR_TRY(o.out(out, c->n, c->n, ldo));
+    FR_TRY(launch_copy(ctx, c->A, c->ld_a, o.dev, o.ld, c->n, c->n));
+    FR_TRY(launch_tri_fill(ctx, o.dev, c->n, o.ld, upper_fill ? std::nan("") : 0.0));
+    return o.commit();
+}
+
+int fr_chol_upload_l(fr_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* X, int64_t ldx, int64_t d,
+                     int64_t capacity_hint, fr_chol** out)
+{
+    if (!ctx || !out) return FR_INVALID_ARGUMENT;
+    *out = nullptr;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    if (n < 0 || d < 0 || ldl < imax(n, 1) || (d > 0 && ldx < imax(n, 1))) return set_err(ctx, FR_SHAPE, "bad shape");
+    fr_chol* c = nullptr;
+    FR_TRY(chol_alloc(ctx, n, imax(capacity_hint, n), d, &c));
+    int st = upload_rows(ctx, L, ldl, c->A, c->ld_a, n, n);
+    if (st == FR_OK && d > 0) st = upload_rows(ctx, X, ldx, c->X, c->ld_x, n, d);
+    if (st == FR_OK) {
+        hipError_t e = hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream);
+        if (e != hipSuccess) st = set_err(ctx, FR_HIP_ERROR, "memset failed");
+    }
+    if (st == FR_OK) {
+        WsGuard tg(ctx);
+        double* T = tg.get(sizeof(double) * 64 * 64);
+        if (!T) st = FR_OUT_OF_MEMORY;
+        for (int64_t b = 0; st == FR_OK && b * IB < n; ++b) {
+            const int64_t j = b * IB, sb = imin(IB, n - j);
+            st = invert_block128(ctx, c->A + j + j * c->ld_a, c->ld_a, sb, c->dinv + b * INV_ELEMS, T);
+        }
+        if (st == FR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = FR_HIP_ERROR;
+    }
+    if (st != FR_OK) {
+        fr_chol_free(c);
+        return st;
+    }
+    *out = c;
+    return FR_OK;
+}
+
+void fr_chol_free(fr_chol* c)
+{
+    if (!c) return;
+    if (c->ctx) {
+        (void)hipSetDevice(c->ctx->device);
+        (void)hipStreamSynchronize(c->ctx->stream);
+    }
+    chol_release(c);
+    delete c;
+}
+
+}  // extern "C"

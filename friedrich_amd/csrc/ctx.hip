@@ -1,0 +1,344 @@
+// ctx.hip -- context, error reporting, workspace pool, host<->device staging, event-based profiling.
+#include <cstdarg>
+
+#include "fr_internal.hpp"
+
+namespace fr {
+
+int set_err(fr_ctx* ctx, int status, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return status;
+}
+
+bool is_device_ptr(const void* p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'd host memory: not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+void* ws_get(fr_ctx* ctx, size_t bytes)
+{
+    if (bytes == 0) bytes = 8;
+    // best fit among free buffers
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); ++i) {
+        DevBuf& b = ctx->pool[i];
+        if (!b.in_use && b.cap >= bytes && (best < 0 || b.cap < ctx->pool[best].cap)) best = i;
+    }
+    if (best >= 0 && ctx->pool[best].cap <= bytes * 2 + (1u << 20)) {
+        ctx->pool[best].in_use = true;
+        return ctx->pool[best].p;
+    }
+    // drop the largest unused buffers if memory is tight; otherwise allocate fresh
+    void* p = nullptr;
+    size_t cap = (bytes + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (auto& b : ctx->pool)
+            if (!b.in_use && b.p) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipFree(b.p);
+                b.p = nullptr;
+                b.cap = 0;
+            }
+        e = hipMalloc(&p, cap);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_err(ctx, FR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    DevBuf nb;
+    nb.p = p;
+    nb.cap = cap;
+    nb.in_use = true;
+    // reuse an empty slot
+    for (auto& b : ctx->pool)
+        if (!b.p) {
+            b = nb;
+            return p;
+        }
+    ctx->pool.push_back(nb);
+    return p;
+}
+
+void ws_put(fr_ctx* ctx, void* p)
+{
+    for (auto& b : ctx->pool)
+        if (b.p == p) {
+            b.in_use = false;
+            return;
+        }
+}
+
+static bool usable_in_place(const double* p, int64_t rows, int64_t ld)
+{
+    return is_device_ptr(p) && ld >= (rows > 0 ? rows : 1);
+}
+
+int Staged::in(const double* src, int64_t r, int64_t c, int64_t ldsrc)
+{
+    rows = r;
+    cols = c;
+    if (r < 0 || c < 0 || ldsrc < (r > 0 ? r : 1)) return set_err(ctx, FR_SHAPE, "bad matrix shape %lld x %lld ld %lld",
+                                                                   (long long)r, (long long)c, (long long)ldsrc);
+    if (r == 0 || c == 0) {
+        dev = nullptr;
+        ld = 1;
+        return FR_OK;
+    }
+    if (!src) return set_err(ctx, FR_INVALID_ARGUMENT, "null matrix pointer");
+    if (usable_in_place(src, r, ldsrc)) {
+        dev = const_cast<double*>(src);
+        ld = ldsrc;
+        owns = false;
+        return FR_OK;
+    }
+    ld = round_up(r, kAlign);
+    dev = (double*)ws_get(ctx, sizeof(double) * (size_t)ld * (size_t)c);
+    if (!dev) return FR_OUT_OF_MEMORY;
+    owns = true;
+    const bool src_dev = is_device_ptr(src);
+    FR_HIP(ctx, hipMemcpy2DAsync(dev, sizeof(double) * ld, src, sizeof(double) * ldsrc, sizeof(double) * r, c,
+                                 src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    // pageable host memory: make sure the runtime is done with the caller's buffer before we return to it
+    if (!src_dev) FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FR_OK;
+}
+
+int Staged::out(double* dst, int64_t r, int64_t c, int64_t lddst)
+{
+    rows = r;
+    cols = c;
+    if (r < 0 || c < 0 || lddst < (r > 0 ? r : 1)) return set_err(ctx, FR_SHAPE, "bad matrix shape %lld x %lld ld %lld",
+                                                                   (long long)r, (long long)c, (long long)lddst);
+    if (r == 0 || c == 0) {
+        dev = nullptr;
+        ld = 1;
+        return FR_OK;
+    }
+    if (!dst) return set_err(ctx, FR_INVALID_ARGUMENT, "null output pointer");
+    if (usable_in_place(dst, r, lddst)) {
+        dev = dst;
+        ld = lddst;
+        owns = false;
+        return FR_OK;
+    }
+    ld = round_up(r, kAlign);
+    dev = (double*)ws_get(ctx, sizeof(double) * (size_t)ld * (size_t)c);
+    if (!dev) return FR_OUT_OF_MEMORY;
+    owns = true;
+    host = dst;
+    host_ld = lddst;
+    return FR_OK;
+}
+
+int Staged::inout(double* p, int64_t r, int64_t c, int64_t ldp)
+{
+    FR_TRY(in(p, r, c, ldp));
+    if (owns) {
+        host = p;
+        host_ld = ldp;
+    }
+    return FR_OK;
+}
+
+int Staged::commit()
+{
+    if (!owns || !host || rows == 0 || cols == 0) return FR_OK;
+    FR_HIP(ctx, hipMemcpy2DAsync(host, sizeof(double) * host_ld, dev, sizeof(double) * ld, sizeof(double) * rows, cols,
+                                 is_device_ptr(host) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FR_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------
+static hipEvent_t get_event(fr_ctx* ctx)
+{
+    if (!ctx->free_events.empty()) {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(fr_ctx* c, int cls_, double flops, double bytes) : ctx(c), cls(cls_)
+{
+    if (!ctx->prof) return;
+    ctx->prof_launches[cls] += 1;
+    ctx->prof_flops[cls] += flops;
+    ctx->prof_bytes[cls] += bytes;
+    a = get_event(ctx);
+    b = get_event(ctx);
+    if (a) (void)hipEventRecord(a, ctx->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!ctx->prof || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ProfRec r;
+    r.a = a;
+    r.b = b;
+    r.cls = cls;
+    ctx->recs.push_back(r);
+}
+
+static void prof_collect(fr_ctx* ctx)
+{
+    if (ctx->recs.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) ctx->prof_ms[r.cls] += ms;
+        ctx->free_events.push_back(r.a);
+        ctx->free_events.push_back(r.b);
+    }
+    ctx->recs.clear();
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" {
+
+int fr_abi_version(void) { return FR_ABI_VERSION; }
+
+int fr_ctx_create(fr_ctx** out, int device)
+{
+    if (!out) return FR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return FR_NO_DEVICE;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return FR_NO_DEVICE;
+    }
+    if (device >= count) return FR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FR_HIP_ERROR;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FR_HIP_ERROR;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "friedrich_amd: device %d is %s, this library is built for gfx950 only\n", device,
+                prop.gcnArchName);
+        return FR_NO_DEVICE;
+    }
+    fr_ctx* ctx = new fr_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return FR_HIP_ERROR;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return FR_OK;
+}
+
+void fr_ctx_destroy(fr_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    extern void fr_comm_destroy_internal(fr_ctx*);
+    fr_comm_destroy_internal(ctx);
+    for (auto& r : ctx->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    for (auto& b : ctx->pool)
+        if (b.p) (void)hipFree(b.p);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return FR_INVALID_ARGUMENT;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return FR_OK;
+}
+
+int fr_ctx_synchronize(fr_ctx* ctx)
+{
+    if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FR_OK;
+}
+
+const char* fr_last_error(const fr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return FR_INVALID_ARGUMENT;
+    if (!strcmp(name, "nb")) {
+        if (value < kDiagBlock || value % kDiagBlock != 0 || value > 1024)
+            return set_err(ctx, FR_INVALID_ARGUMENT, "nb must be a multiple of %d in [%d, 1024]", kDiagBlock, kDiagBlock);
+        // power-of-two multiples only: the diagonal-block recursion halves down to kDiagBlock
+        int64_t v = value / kDiagBlock;
+        if (v & (v - 1)) return set_err(ctx, FR_INVALID_ARGUMENT, "nb / %d must be a power of two", kDiagBlock);
+        ctx->nb = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "gemm_tile")) {
+        ctx->gemm_tile = value;
+        return FR_OK;
+    }
+    return set_err(ctx, FR_INVALID_ARGUMENT, "unknown option %s", name);
+}
+
+int fr_ctx_profile_enable(fr_ctx* ctx, int enable)
+{
+    if (!ctx) return FR_INVALID_ARGUMENT;
+    prof_collect(ctx);
+    ctx->prof = enable != 0;
+    return FR_OK;
+}
+
+int fr_ctx_profile_reset(fr_ctx* ctx)
+{
+    if (!ctx) return FR_INVALID_ARGUMENT;
+    prof_collect(ctx);
+    for (int i = 0; i < FR_PROF_COUNT; ++i) {
+        ctx->prof_ms[i] = 0;
+        ctx->prof_launches[i] = 0;
+        ctx->prof_flops[i] = 0;
+        ctx->prof_bytes[i] = 0;
+    }
+    return FR_OK;
+}
+
+int fr_ctx_profile_get(fr_ctx* ctx, int cls, double* ms, int64_t* launches, double* flops, double* bytes)
+{
+    if (!ctx || cls < 0 || cls >= FR_PROF_COUNT) return FR_INVALID_ARGUMENT;
+    prof_collect(ctx);
+    if (ms) *ms = ctx->prof_ms[cls];
+    if (launches) *launches = ctx->prof_launches[cls];
+    if (flops) *flops = ctx->prof_flops[cls];
+    if (bytes) *bytes = ctx->prof_bytes[cls];
+    return FR_OK;
+}
+
+}  // extern "C"

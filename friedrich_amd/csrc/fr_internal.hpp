@@ -1,0 +1,225 @@
+// fr_internal.hpp -- shared internals of libfriedrich_amd (gfx950 only; no CPU fallback).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "friedrich_amd.h"
+
+namespace fr {
+
+constexpr int64_t kAlign = 64;  // row padding (elements) of every internal column-major buffer
+constexpr int kDiagBlock = 64;  // K4 base block: one workgroup factors + inverts a 64x64 diagonal block
+
+inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool in_use = false;
+};
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int cls;
+};
+
+}  // namespace fr
+
+struct fr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    // grow-only workspace pool (stream-ordered reuse inside one context)
+    std::vector<fr::DevBuf> pool;
+    // options
+    int64_t nb = 256;       // outer Cholesky block / dinv block
+    int64_t gemm_tile = 0;  // reserved
+    // profiling
+    bool prof = false;
+    std::vector<fr::ProfRec> recs;
+    std::vector<hipEvent_t> free_events;
+    double prof_ms[FR_PROF_COUNT] = {0};
+    int64_t prof_launches[FR_PROF_COUNT] = {0};
+    double prof_flops[FR_PROF_COUNT] = {0};
+    double prof_bytes[FR_PROF_COUNT] = {0};
+    // RCCL
+    void* comm = nullptr;  // ncclComm_t
+    int rank = 0;
+    int world = 1;
+};
+
+// Device-resident factor.  A is capacity x capacity (ld = ld_a) column-major; its lower triangle holds L.
+// dinv holds the explicit inverses of the nb x nb diagonal blocks of L (block b at dinv + b*nb*nb, ld nb),
+// produced by K4/K5 during the factorisation and consumed by every triangular solve.
+struct fr_chol {
+    fr_ctx* ctx = nullptr;
+    int64_t n = 0;         // logical size
+    int64_t capacity = 0;  // row/col capacity of A (and row capacity of X)
+    int64_t ld_a = 0;
+    int64_t d = 0;  // feature count (0 for fr_chol_from_matrix)
+    int64_t ld_x = 0;
+    int64_t nb = 256;
+    double* A = nullptr;
+    double* X = nullptr;     // capacity x d training inputs (EMatrix mirror)
+    double* dinv = nullptr;  // ceil(capacity/nb) blocks of nb x nb
+    int64_t* info = nullptr;  // device: [0] = 1 + first failing column (0: none), [1] = n_subst,
+                              //         [2] = 1 if a zero diagonal was seen, [3..] substituted columns
+    int64_t info_cap = 0;
+    // host mirror of info after the last factorisation
+    int64_t fail_col = -1;
+    int64_t n_subst = 0;
+    std::vector<int64_t> subst;
+};
+
+namespace fr {
+
+// ---- error handling -------------------------------------------------------------------------------
+int set_err(fr_ctx* ctx, int status, const char* fmt, ...);
+
+#define FR_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fr::set_err((ctx), FR_HIP_ERROR, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                               __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define FR_TRY(call)                 \
+    do {                             \
+        int st__ = (call);           \
+        if (st__ != FR_OK) return st__; \
+    } while (0)
+
+// ---- memory ---------------------------------------------------------------------------------------
+bool is_device_ptr(const void* p);
+// workspace: returns nullptr on failure (error recorded in ctx)
+void* ws_get(fr_ctx* ctx, size_t bytes);
+void ws_put(fr_ctx* ctx, void* p);
+
+struct WsGuard {
+    fr_ctx* ctx;
+    void* p = nullptr;
+    WsGuard(fr_ctx* c) : ctx(c) {}
+    WsGuard(const WsGuard&) = delete;
+    ~WsGuard()
+    {
+        if (p) ws_put(ctx, p);
+    }
+    double* get(size_t bytes)
+    {
+        if (p) ws_put(ctx, p);
+        p = ws_get(ctx, bytes);
+        return (double*)p;
+    }
+};
+
+// A rows x cols column-major matrix made available on the device.  Host data are copied into an internal
+// workspace; device data are used in place (zero copy).
+struct Staged {
+    fr_ctx* ctx;
+    double* dev = nullptr;
+    int64_t ld = 0;
+    // copy-back bookkeeping
+    double* host = nullptr;
+    int64_t host_ld = 0;
+    int64_t rows = 0, cols = 0;
+    bool owns = false;
+    Staged(fr_ctx* c) : ctx(c) {}
+    Staged(const Staged&) = delete;
+    ~Staged()
+    {
+        if (owns && dev) ws_put(ctx, dev);
+    }
+    // input: copy host->device if needed
+    int in(const double* src, int64_t rows, int64_t cols, int64_t ld);
+    // output: allocate a device image if dst is a host pointer (contents undefined)
+    int out(double* dst, int64_t rows, int64_t cols, int64_t ld);
+    // in/out
+    int inout(double* p, int64_t rows, int64_t cols, int64_t ld);
+    // copy the device image back to the host destination (no-op for device destinations); synchronises
+    int commit();
+};
+
+// ---- profiling ------------------------------------------------------------------------------------
+struct ProfScope {
+    fr_ctx* ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    int cls;
+    ProfScope(fr_ctx* c, int cls_, double flops, double bytes);
+    ~ProfScope();
+};
+
+// ---- kernels (launchers; all enqueue on ctx->stream) ------------------------------------------------
+// K1: Gram assembly
+int launch_gram_cross(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_t n1, int64_t lda, const double* B,
+                      int64_t n2, int64_t ldb, int64_t d, double* out, int64_t ldo);
+// lower triangle (full 128x128 diagonal tiles) + noise^2 on the diagonal, rows/cols [r0, n) x [c0, n)
+int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,
+                    double noise2, double* out, int64_t ldo);
+// out[i] = k(x_i, x_i) (+ add)
+int launch_gram_diag(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,
+                     double add, double* out);
+int launch_pairwise_distance_sum(fr_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t d, double* out_dev);
+int kprog_check(fr_ctx* ctx, const fr_kprog* p);
+
+// K5/K6: FP64 MFMA GEMM.  D = alpha * op(A) op(B) + beta * Cin  (D may alias Cin)
+//   a_kmajor = false: element (m,k) of op(A) is A[m + k*lda]  ("N")      true: A[k + m*lda]  ("T")
+//   b_kmajor = true : element (k,n) of op(B) is B[k + n*ldb]  ("N")      false: B[n + k*ldb] ("T")
+//   lower = true: only tiles intersecting the lower triangle of the M x M result are computed (SYRK use)
+struct GemmDesc {
+    int64_t M, N, K;
+    const double* A;
+    int64_t lda;
+    bool a_kmajor;
+    const double* B;
+    int64_t ldb;
+    bool b_kmajor;
+    const double* Cin;
+    int64_t ldcin;
+    double* D;
+    int64_t ldd;
+    double alpha, beta;
+    bool lower;
+    int prof_cls;
+};
+int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
+
+// K4: factor one diagonal block (nbk <= 64) in LDS, emit its inverse.
+//   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows)
+int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub,
+                 double* inv, int64_t ldinv, int64_t* info);
+
+// small helpers (elementwise / reductions)
+int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v);
+int launch_copy(fr_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);
+int launch_set_identity(fr_ctx* ctx, double* p, int64_t n, int64_t ld);
+int launch_tri_fill(fr_ctx* ctx, double* p, int64_t n, int64_t ld, double v);            // strict upper := v
+int launch_symmetrize(fr_ctx* ctx, double* p, int64_t n, int64_t ld);                    // upper := lower^T
+int launch_col_norm2(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ldv, double* out);
+int launch_col_dot(fr_ctx* ctx, const double* U, int64_t ldu, const double* V, int64_t ldv, int64_t n, int64_t m,
+                   double* out);
+// out[j] = alpha * dot(V[:,j], y) + beta * out[j]
+int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ldv, const double* y, double alpha,
+                  double beta, double* out);
+int launch_axpby_vec(fr_ctx* ctx, int64_t n, double a, const double* x, double b, double* y);  // y = a*x + b*y
+int launch_diag_check_zero(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t* flag);
+int launch_sum_log_abs(fr_ctx* ctx, const double* v, int64_t n, double* out);
+
+// ---- blocked algorithms (chol.hip) ------------------------------------------------------------------
+// in-place Cholesky of the lower triangle of the n x n block at A (rows/cols offset col0 for bookkeeping)
+int potrf_device(fr_ctx* ctx, fr_chol* c, int64_t j0, int64_t n, int mode, double sub);
+// B (n x m, device) <- L^-1 B   /   B <- L^-T B
+int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int prof_cls);
+int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int prof_cls);
+int chol_alloc(fr_ctx* ctx, int64_t n, int64_t capacity, int64_t d, fr_chol** out);
+int chol_fetch_info(fr_chol* c);
+
+}  // namespace fr

@@ -1,0 +1,242 @@
+// gemm_f64.hip -- K5/K6: the FP64 matrix-core GEMM behind the blocked Cholesky (trailing SYRK update,
+// TRSM recast as GEMM with inverted diagonal blocks), the triangular solves of predict / predict_variance /
+// sample_at (Cholesky::solve_mut, solve_lower_triangular: mod.rs:235,260-263,298,342-345,379) and the
+// gemm_tr contractions (mod.rs:348,383).  The reference runs these as nalgebra's unblocked axpy/dot loops.
+//
+//   D = alpha * op(A) * op(B) + beta * Cin          (all column-major f64, D may alias Cin)
+//
+// Design (gfx950): one workgroup = 4 wave64 in a 2x2 arrangement computes a 128x128 tile, each wave a
+// 64x64 sub-tile as 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  K is consumed in steps of 16
+// through double-buffered LDS; the next step's global loads are issued before the current step's MFMAs
+// and written to the other LDS buffer after them (one barrier per step).  FP64 MFMA is slow enough
+// (16x16x4 every 64 cycles per SIMD) that 8-byte global loads suffice, which removes every alignment
+// requirement on sub-matrix base pointers (row offsets are arbitrary after add_samples).
+//
+// LDS layouts are chosen per operand so that global reads stay coalesced and the MFMA fragment reads
+// (ds_read_b64, two 32-lane groups, 32 eight-byte slots) are conflict-free:
+//   "m-major" operand (element (m,k) at P[m + k*ld]):  tile[k][m], row stride 144  (144 mod 32 == 16)
+//   "k-major" operand (element (m,k) at P[k + m*ld]):  tile[m][k], row stride 18   (18*m mod 32 distinct, even)
+//
+// The MFMA is issued with the roles swapped (B-fragment as the A operand) so that the 16 lanes (lane & 15)
+// of an accumulator register run along m, the contiguous axis of column-major D: every store / Cin load
+// instruction moves four 128-byte segments.
+#include "fr_internal.hpp"
+
+namespace fr {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int S_MMAJ = 144;  // [BK][144]
+constexpr int S_KMAJ = 18;   // [128][18]
+constexpr int TILE_ELEMS = 2304;  // 16*144 == 128*18
+
+struct GemmArgs {
+    int64_t M, N, K;
+    const double* A;
+    int64_t lda;
+    const double* B;
+    int64_t ldb;
+    const double* Cin;
+    int64_t ldcin;
+    double* D;
+    int64_t ldd;
+    double alpha, beta;
+    int lower;
+    int64_t tiles_m, tiles_n;
+};
+
+// element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile
+template <bool KMAJ>
+__device__ __forceinline__ int lds_idx(int x, int k)
+{
+    return KMAJ ? x * S_KMAJ + k : k * S_MMAJ + x;
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void load_tile(const double* __restrict__ P, int64_t ld, int64_t x0, int64_t X, int64_t k0,
+                                          int64_t K, int t, double (&reg)[8])
+{
+    if (!KMAJ) {
+        const int x = t & 127;
+        const bool xok = (x0 + x) < X;
+        const double* p = P + (x0 + x) + k0 * ld;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = (t >> 7) + 2 * i;
+            reg[i] = (xok && (k0 + k) < K) ? p[(int64_t)k * ld] : 0.0;
+        }
+    } else {
+        const int k = t & 15;
+        const bool kok = (k0 + k) < K;
+        const double* p = P + (k0 + k) + x0 * ld;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = (t >> 4) + 16 * i;
+            reg[i] = (kok && (x0 + x) < X) ? p[(int64_t)x * ld] : 0.0;
+        }
+    }
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void store_tile(double* __restrict__ S, int t, const double (&reg)[8])
+{
+    if (!KMAJ) {
+        const int x = t & 127;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) S[((t >> 7) + 2 * i) * S_MMAJ + x] = reg[i];
+    } else {
+        const int k = t & 15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) S[((t >> 4) + 16 * i) * S_KMAJ + k] = reg[i];
+    }
+}
+
+template <bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
+{
+    __shared__ double lds[4 * TILE_ELEMS];  // [stage][A|B][TILE_ELEMS]
+
+    // XCD-aware tile assignment: block b runs on XCD b % 8; give each XCD a contiguous run of tiles so
+    // neighbouring tiles (shared operand panels) hit the same private L2.
+    const int64_t nblk = gridDim.x;
+    const int64_t b = blockIdx.x;
+    const int64_t q = nblk >> 3, r8 = nblk & 7, xcd = b & 7;
+    const int64_t tlin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+
+    int64_t tm, tn;
+    if (g.lower) {
+        int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
+        while (row * (row + 1) / 2 > tlin) --row;
+        while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
+        tm = row;
+        tn = tlin - row * (row + 1) / 2;
+    } else {
+        tm = tlin % g.tiles_m;
+        tn = tlin / g.tiles_m;
+    }
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    d4_t acc[4][4];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    const int64_t nk = (g.K + BK - 1) / BK;
+    double ra[8], rb[8];
+    if (nk > 0) {
+        load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, 0, g.K, t, ra);
+        // op(B) element (k, n): B_KMAJ -> B[k + n*ldb] (k contiguous), else B[n + k*ldb]
+        load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, 0, g.K, t, rb);
+        store_tile<A_KMAJ>(lds, t, ra);
+        store_tile<B_KMAJ>(lds + TILE_ELEMS, t, rb);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) {
+            load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, t, ra);
+            load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, t, rb);
+        }
+        const double* As = lds + cur * 2 * TILE_ELEMS;
+        const double* Bs = As + TILE_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            const int kq = ks * 4 + lq;
+            double af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = As[lds_idx<A_KMAJ>(wm * 64 + i * 16 + l15, kq)];
+                bf[i] = Bs[lds_idx<B_KMAJ>(wn * 64 + i * 16 + l15, kq)];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+        if (more) {
+            double* An = lds + (cur ^ 1) * 2 * TILE_ELEMS;
+            store_tile<A_KMAJ>(An, t, ra);
+            store_tile<B_KMAJ>(An + TILE_ELEMS, t, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: accumulator register r of tile (nt, mt) holds D[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
+    const bool use_c = g.beta != 0.0;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t n = n0 + wn * 64 + nt * 16 + lq + 4 * r;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int64_t m = m0 + wm * 64 + mt * 16 + l15;
+                if (m >= g.M) continue;
+                double v = g.alpha * acc[nt][mt][r];
+                if (use_c) v += g.beta * g.Cin[m + n * g.ldcin];
+                g.D[m + n * g.ldd] = v;
+            }
+        }
+    }
+}
+
+int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
+{
+    if (d.M <= 0 || d.N <= 0) return FR_OK;
+    GemmArgs g;
+    g.M = d.M;
+    g.N = d.N;
+    g.K = d.K < 0 ? 0 : d.K;
+    g.A = d.A;
+    g.lda = d.lda;
+    g.B = d.B;
+    g.ldb = d.ldb;
+    g.Cin = d.Cin ? d.Cin : d.D;
+    g.ldcin = d.Cin ? d.ldcin : d.ldd;
+    g.D = d.D;
+    g.ldd = d.ldd;
+    g.alpha = d.alpha;
+    g.beta = d.beta;
+    g.lower = d.lower ? 1 : 0;
+    g.tiles_m = (d.M + BM - 1) / BM;
+    g.tiles_n = (d.N + BN - 1) / BN;
+    int64_t ntiles;
+    double flops;
+    if (d.lower) {
+        if (d.M != d.N) return set_err(ctx, FR_INVALID_ARGUMENT, "lower-mode GEMM needs a square result");
+        ntiles = g.tiles_m * (g.tiles_m + 1) / 2;
+        flops = (double)d.M * (double)(d.M + 1) * (double)g.K;  // 2 * M(M+1)/2 * K
+    } else {
+        ntiles = g.tiles_m * g.tiles_n;
+        flops = 2.0 * (double)d.M * (double)d.N * (double)g.K;
+    }
+    if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
+    const double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
+    ProfScope ps(ctx, d.prof_cls, flops, bytes);
+    dim3 grid((unsigned)ntiles), block(256);
+    if (!d.a_kmajor && !d.b_kmajor)
+        hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, ctx->stream, g);
+    else if (!d.a_kmajor && d.b_kmajor)
+        hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, ctx->stream, g);
+    else if (d.a_kmajor && d.b_kmajor)
+        hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, ctx->stream, g);
+    else
+        hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, ctx->stream, g);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+}  // namespace fr

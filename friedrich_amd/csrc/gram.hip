@@ -1,0 +1,372 @@
+// gram.hip -- K1 Gram (covariance) assembly and K3 mean-pairwise-distance reduction.
+//
+// Replaces the per-pair loops of src/algebra/mod.rs:41-54 (make_covariance_matrix), :70-79 (lower triangle
+// + noise^2 inside make_cholesky_cov_matrix), :115-121 (the new columns of add_rows_cholesky_cov_matrix) and
+// src/parameters/kernel.rs:94-113 (fit_bandwidth_mean).
+//
+// Roofline: HBM-bound (8 B written per pair; the n x d inputs are read once per tile row/column through
+// LDS).  One workgroup (4 wave64) produces a 128 x 64 tile: training rows are the fast (contiguous) axis of
+// both the column-major inputs and the column-major output, so every global access is a 512 B wave
+// transaction.  Feature columns are staged through LDS in chunks of 16; a lane keeps 2 rows x 16 columns of
+// running ||x-y||^2 / x.y in registers, the 16 column values are LDS broadcasts.
+#include "fr_internal.hpp"
+#include "kprog_device.hpp"
+
+namespace fr {
+
+constexpr int GT_M = 128;  // tile rows   (rows of A / output rows)
+constexpr int GT_N = 64;   // tile cols   (rows of B / output cols)
+constexpr int GT_DC = 16;  // feature chunk staged in LDS
+
+struct GramArgs {
+    fr_kprog prog;
+    const double* A;
+    int64_t n1, lda;
+    const double* B;
+    int64_t n2, ldb;
+    int64_t d;
+    double* out;
+    int64_t ldo;
+    int sym;  // 1: A == B, only tiles touching the lower triangle (by 128-blocks), + noise2 on the diagonal
+    double noise2;
+    int64_t tiles_n;  // cross mode: tiles along n2
+};
+
+__device__ __forceinline__ void sym_tile(int64_t t, int64_t& bi, int64_t& tj)
+{
+    // row block bi owns column tiles [0, 2(bi+1)); prefix count = bi(bi+1)
+    int64_t b = (int64_t)((sqrt(4.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (b * (b + 1) > t) --b;
+    while ((b + 1) * (b + 2) <= t) ++b;
+    bi = b;
+    tj = t - b * (b + 1);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gram_kernel(const GramArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ double XA[GT_DC][GT_M];
+    __shared__ double XB[GT_DC][GT_N];
+
+    int64_t ti, tj;
+    if (a.sym) {
+        sym_tile((int64_t)blockIdx.x, ti, tj);
+    } else {
+        ti = (int64_t)blockIdx.x / a.tiles_n;
+        tj = (int64_t)blockIdx.x % a.tiles_n;
+    }
+    const int64_t i0 = ti * GT_M, j0 = tj * GT_N;
+    const int t = threadIdx.x;
+    const int r = t & 63;
+    const int g = t >> 6;
+
+    double s[2][16], u[2][16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        s[0][b] = s[1][b] = 0.0;
+        u[0][b] = u[1][b] = 0.0;
+    }
+
+    for (int64_t c0 = 0; c0 < a.d; c0 += GT_DC) {
+        const int dc = (int)((a.d - c0) < GT_DC ? (a.d - c0) : GT_DC);
+        // stage the feature chunk: consecutive lanes read consecutive rows of one feature column
+#pragma unroll
+        for (int p = 0; p < GT_DC / 2; ++p) {
+            const int row = t & 127, c = (t >> 7) + 2 * p;
+            const int64_t gi = i0 + row;
+            XA[c][row] = (c < dc && gi < a.n1) ? a.A[gi + (c0 + c) * a.lda] : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < GT_DC / 4; ++p) {
+            const int row = t & 63, c = (t >> 6) + 4 * p;
+            const int64_t gj = j0 + row;
+            XB[c][row] = (c < dc && gj < a.n2) ? a.B[gj + (c0 + c) * a.ldb] : 0.0;
+        }
+        __syncthreads();
+        for (int c = 0; c < dc; ++c) {
+            const double xa0 = XA[c][r], xa1 = XA[c][r + 64];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const double xb = XB[c][g * 16 + b];
+                if (MODE & NEED_S) {
+                    // (x1 - x2).norm_squared(): difference, square, sequential sum (kernel.rs:558)
+                    const double d0 = xa0 - xb, d1 = xa1 - xb;
+                    s[0][b] = s[0][b] + d0 * d0;
+                    s[1][b] = s[1][b] + d1 * d1;
+                }
+                if (MODE & NEED_U) {
+                    // x1.dot(x2): sequential over the feature columns (kernel.rs:381)
+                    u[0][b] = u[0][b] + xa0 * xb;
+                    u[1][b] = u[1][b] + xa1 * xb;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t gi = i0 + r + 64 * h;
+        if (gi >= a.n1) continue;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const int64_t gj = j0 + g * 16 + b;
+            if (gj >= a.n2) continue;
+            double k = kprog_eval(a.prog, s[h][b], u[h][b]);
+            if (a.sym && gi == gj) k = k + a.noise2;  // algebra/mod.rs:78
+            a.out[gi + gj * a.ldo] = k;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_diag_kernel(const fr_kprog prog, const double* X, int64_t n, int64_t ldx,
+                                                        int64_t d, double add, double* out)
+{
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0, u = 0.0;
+    for (int64_t c = 0; c < d; ++c) {
+        const double x = X[i + c * ldx];
+        const double diff = x - x;
+        s = s + diff * diff;
+        u = u + x * x;
+    }
+    out[i] = kprog_eval(prog, s, u) + add;
+}
+
+// K3: sum over strictly-lower pairs of ||x_i - x_j||; per-block partials, then one reducing block
+__device__ __forceinline__ double block_reduce_sum(double v, double* red /* >= 4 doubles of LDS */)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double tot = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) tot += red[i];
+    __syncthreads();
+    return tot;
+}
+
+__global__ __launch_bounds__(256) void pairdist_kernel(const double* X, int64_t n, int64_t ldx, int64_t d,
+                                                       double* partials)
+{
+#pragma clang fp contract(off)
+    __shared__ double XA[GT_DC][GT_M];
+    __shared__ double XB[GT_DC][GT_N];
+    __shared__ double red[4];
+    int64_t ti, tj;
+    sym_tile((int64_t)blockIdx.x, ti, tj);
+    const int64_t i0 = ti * GT_M, j0 = tj * GT_N;
+    const int t = threadIdx.x, r = t & 63, g = t >> 6;
+    double s[2][16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) s[0][b] = s[1][b] = 0.0;
+    for (int64_t c0 = 0; c0 < d; c0 += GT_DC) {
+        const int dc = (int)((d - c0) < GT_DC ? (d - c0) : GT_DC);
+#pragma unroll
+        for (int p = 0; p < GT_DC / 2; ++p) {
+            const int row = t & 127, c = (t >> 7) + 2 * p;
+            const int64_t gi = i0 + row;
+            XA[c][row] = (c < dc && gi < n) ? X[gi + (c0 + c) * ldx] : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < GT_DC / 4; ++p) {
+            const int row = t & 63, c = (t >> 6) + 4 * p;
+            const int64_t gj = j0 + row;
+            XB[c][row] = (c < dc && gj < n) ? X[gj + (c0 + c) * ldx] : 0.0;
+        }
+        __syncthreads();
+        for (int c = 0; c < dc; ++c) {
+            const double xa0 = XA[c][r], xa1 = XA[c][r + 64];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const double xb = XB[c][g * 16 + b];
+                const double d0 = xa0 - xb, d1 = xa1 - xb;
+                s[0][b] = s[0][b] + d0 * d0;
+                s[1][b] = s[1][b] + d1 * d1;
+            }
+        }
+        __syncthreads();
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t gi = i0 + r + 64 * h;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const int64_t gj = j0 + g * 16 + b;
+            if (gi < n && gj < gi) acc += sqrt(s[h][b]);
+        }
+    }
+    const double tot = block_reduce_sum(acc, red);
+    if (t == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* partials, int64_t n, double scale,
+                                                              double* out)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+    const double tot = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = tot * scale;
+}
+
+int kprog_check(fr_ctx* ctx, const fr_kprog* p)
+{
+    if (!p) return set_err(ctx, FR_INVALID_ARGUMENT, "null kernel program");
+    if (p->nops < 1 || p->nops > FR_KPROG_MAX_OPS) return set_err(ctx, FR_UNSUPPORTED_KERNEL, "kernel program length %d", p->nops);
+    int depth = 0;
+    for (int i = 0; i < p->nops; ++i) {
+        const int k = p->ops[i].kind;
+        if (kind_is_leaf(k)) {
+            if (p->ops[i].nparams != leaf_nvalues(k))
+                return set_err(ctx, FR_UNSUPPORTED_KERNEL, "kernel op %d: kind %d expects %d parameters, got %d", i, k,
+                               leaf_nvalues(k), p->ops[i].nparams);
+            if (++depth > 8) return set_err(ctx, FR_UNSUPPORTED_KERNEL, "kernel program too deep");
+        } else if (k == FR_K_SUM || k == FR_K_PROD) {
+            if (depth < 2) return set_err(ctx, FR_UNSUPPORTED_KERNEL, "malformed kernel program (op %d)", i);
+            --depth;
+        } else {
+            return set_err(ctx, FR_UNSUPPORTED_KERNEL, "unknown kernel kind %d", k);
+        }
+    }
+    if (depth != 1) return set_err(ctx, FR_UNSUPPORTED_KERNEL, "malformed kernel program (final depth %d)", depth);
+    return FR_OK;
+}
+
+static int launch_gram(fr_ctx* ctx, const GramArgs& a, int64_t nblocks, int needs, double pairs)
+{
+    if (nblocks <= 0) return FR_OK;
+    if (nblocks > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "Gram grid too large");
+    ProfScope ps(ctx, FR_PROF_GRAM, pairs * (3.0 * (double)a.d + 20.0), pairs * 8.0);
+    dim3 grid((unsigned)nblocks), block(256);
+    if (needs == NEED_S)
+        hipLaunchKernelGGL(gram_kernel<NEED_S>, grid, block, 0, ctx->stream, a);
+    else if (needs == NEED_U)
+        hipLaunchKernelGGL(gram_kernel<NEED_U>, grid, block, 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(gram_kernel<NEED_S | NEED_U>, grid, block, 0, ctx->stream, a);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_gram_cross(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_t n1, int64_t lda, const double* B,
+                      int64_t n2, int64_t ldb, int64_t d, double* out, int64_t ldo)
+{
+    if (n1 == 0 || n2 == 0) return FR_OK;
+    GramArgs a;
+    a.prog = prog;
+    a.A = A;
+    a.n1 = n1;
+    a.lda = lda;
+    a.B = B;
+    a.n2 = n2;
+    a.ldb = ldb;
+    a.d = d;
+    a.out = out;
+    a.ldo = ldo;
+    a.sym = 0;
+    a.noise2 = 0.0;
+    a.tiles_n = (n2 + GT_N - 1) / GT_N;
+    const int64_t tiles_m = (n1 + GT_M - 1) / GT_M;
+    return launch_gram(ctx, a, tiles_m * a.tiles_n, kprog_needs(prog), (double)n1 * (double)n2);
+}
+
+int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,
+                    double noise2, double* out, int64_t ldo)
+{
+    if (n == 0) return FR_OK;
+    GramArgs a;
+    a.prog = prog;
+    a.A = X;
+    a.n1 = n;
+    a.lda = ldx;
+    a.B = X;
+    a.n2 = n;
+    a.ldb = ldx;
+    a.d = d;
+    a.out = out;
+    a.ldo = ldo;
+    a.sym = 1;
+    a.noise2 = noise2;
+    a.tiles_n = 0;
+    const int64_t nbk = (n + GT_M - 1) / GT_M;
+    return launch_gram(ctx, a, nbk * (nbk + 1), kprog_needs(prog), 0.5 * (double)n * (double)(n + 1));
+}
+
+int launch_gram_diag(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d, double add,
+                     double* out)
+{
+    if (n == 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_GRAM, 0.0, (double)n * 8.0);
+    hipLaunchKernelGGL(gram_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, prog, X, n, ldx,
+                       d, add, out);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_pairwise_distance_sum(fr_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t d, double* out_dev)
+{
+    const int64_t nbk = (n + GT_M - 1) / GT_M;
+    const int64_t nblocks = nbk * (nbk + 1);
+    WsGuard part(ctx);
+    double* partials = part.get(sizeof(double) * (size_t)nblocks);
+    if (!partials) return FR_OUT_OF_MEMORY;
+    const double npairs = (double)((n * n - n) / 2);  // kernel.rs:108-109
+    {
+        ProfScope ps(ctx, FR_PROF_GRAM, npairs * (3.0 * (double)d + 10.0), (double)n * (double)d * 8.0);
+        hipLaunchKernelGGL(pairdist_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, X, n, ldx, d, partials);
+        FR_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)partials, nblocks,
+                           1.0 / npairs, out_dev);
+        FR_HIP(ctx, hipGetLastError());
+    }
+    return FR_OK;
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" {
+
+int fr_gram(fr_ctx* ctx, const fr_kprog* kernel, const double* A, int64_t n1, int64_t lda, const double* B, int64_t n2,
+            int64_t ldb, int64_t d, double* out, int64_t ldo)
+{
+    if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    FR_TRY(kprog_check(ctx, kernel));
+    if (d < 0) return set_err(ctx, FR_SHAPE, "negative feature count");
+    Staged a(ctx), b(ctx), o(ctx);
+    FR_TRY(a.in(A, n1, d, lda));
+    FR_TRY(b.in(B, n2, d, ldb));
+    FR_TRY(o.out(out, n1, n2, ldo));
+    FR_TRY(launch_gram_cross(ctx, *kernel, a.dev, n1, a.ld, b.dev, n2, b.ld, d, o.dev, o.ld));
+    return o.commit();
+}
+
+int fr_mean_pairwise_distance(fr_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t d, double* out)
+{
+    if (!ctx || !out) return FR_INVALID_ARGUMENT;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    if (n < 2) {  // 0/0 in the reference (kernel.rs:112)
+        *out = std::nan("");
+        return FR_OK;
+    }
+    Staged x(ctx);
+    FR_TRY(x.in(X, n, d, ldx));
+    WsGuard res(ctx);
+    double* r = res.get(sizeof(double));
+    if (!r) return FR_OUT_OF_MEMORY;
+    FR_TRY(launch_pairwise_distance_sum(ctx, x.dev, n, x.ld, d, r));
+    FR_HIP(ctx, hipMemcpyAsync(out, r, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FR_OK;
+}
+
+}  // extern "C"

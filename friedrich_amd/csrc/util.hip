@@ -1,0 +1,213 @@
+// util.hip -- K7: small HBM-bound helpers (fills, copies, per-column reductions) used by the epilogues of
+// predict / predict_variance / predict_mean_variance / likelihood (src/gaussian_process/mod.rs:203-219,
+// 241, 266-270, 313-319) and by the factor download paths.
+#include "fr_internal.hpp"
+
+namespace fr {
+
+__global__ void fill_kernel(double* p, int64_t rows, int64_t cols, int64_t ld, double v)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (r < rows && c < cols) p[r + c * ld] = v;
+}
+
+__global__ void copy_kernel(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t c = blockIdx.y; c < cols; c += gridDim.y)
+        if (r < rows) dst[r + c * ldd] = src[r + c * lds];
+}
+
+__global__ void identity_kernel(double* p, int64_t n, int64_t ld)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t c = blockIdx.y; c < n; c += gridDim.y)
+        if (r < n) p[r + c * ld] = (r == c) ? 1.0 : 0.0;
+}
+
+__global__ void tri_fill_kernel(double* p, int64_t n, int64_t ld, double v)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t c = blockIdx.y; c < n; c += gridDim.y)
+        if (r < n && r < c) p[r + c * ld] = v;
+}
+
+// upper := lower^T through a 64x64 LDS tile (coalesced on both sides)
+__global__ __launch_bounds__(256) void symmetrize_kernel(double* p, int64_t n, int64_t ld)
+{
+    __shared__ double tile[64][65];
+    const int64_t bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4) {
+        const int64_t r = bi * 64 + tx, cc = bj * 64 + c;
+        tile[c][tx] = (r < n && cc < n) ? p[r + cc * ld] : 0.0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        // write element (row = bj*64 + tx, col = bi*64 + c) = lower(bi*64 + c, bj*64 + tx)
+        const int64_t r = bj * 64 + tx, cc = bi * 64 + c;
+        if (r < n && cc < n && r < cc) p[r + cc * ld] = tile[tx][c];
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double tot = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
+    __syncthreads();
+    return tot;
+}
+
+// out[j] = sum_i U[i,j] * V[i,j]   (U == V: column norm^2, mod.rs:268)
+__global__ __launch_bounds__(256) void col_dot_kernel(const double* U, int64_t ldu, const double* V, int64_t ldv,
+                                                      int64_t n, double* out)
+{
+    __shared__ double red[4];
+    const int64_t j = blockIdx.x;
+    const double* u = U + j * ldu;
+    const double* v = V + j * ldv;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += u[i] * v[i];
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) out[j] = tot;
+}
+
+// out[j] = alpha * V[:,j] . y + beta * out[j]   (gemm_tr on a vector, mod.rs:241, 306, 388)
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* V, int64_t n, int64_t ldv, const double* y,
+                                                     double alpha, double beta, double* out)
+{
+    __shared__ double red[4];
+    const int64_t j = blockIdx.x;
+    const double* v = V + j * ldv;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += v[i] * y[i];
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) out[j] = alpha * tot + (beta != 0.0 ? beta * out[j] : 0.0);
+}
+
+__global__ void axpby_kernel(int64_t n, double a, const double* x, double b, double* y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a * x[i] + (b != 0.0 ? b * y[i] : 0.0);
+}
+
+__global__ void diag_zero_kernel(const double* A, int64_t n, int64_t lda, int64_t* flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && A[i + i * lda] == 0.0) flag[0] = 1;
+}
+
+__global__ __launch_bounds__(256) void sum_log_abs_kernel(const double* v, int64_t n, double* out)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += log(fabs(v[i]));
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
+static inline unsigned ydim(int64_t cols) { return (unsigned)(cols < 65535 ? (cols > 0 ? cols : 1) : 65535); }
+
+int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v)
+{
+    if (rows <= 0 || cols <= 0) return FR_OK;
+    for (int64_t c0 = 0; c0 < cols; c0 += 65535) {
+        const int64_t cc = (cols - c0) < 65535 ? (cols - c0) : 65535;
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)cc), dim3(256), 0, ctx->stream,
+                           p + c0 * ld, rows, cc, ld, v);
+    }
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_copy(fr_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols)
+{
+    if (rows <= 0 || cols <= 0) return FR_OK;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((rows + 255) / 256), ydim(cols)), dim3(256), 0, ctx->stream, src,
+                       lds, dst, ldd, rows, cols);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_set_identity(fr_ctx* ctx, double* p, int64_t n, int64_t ld)
+{
+    if (n <= 0) return FR_OK;
+    hipLaunchKernelGGL(identity_kernel, dim3((unsigned)((n + 255) / 256), ydim(n)), dim3(256), 0, ctx->stream, p, n, ld);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_tri_fill(fr_ctx* ctx, double* p, int64_t n, int64_t ld, double v)
+{
+    if (n <= 0) return FR_OK;
+    hipLaunchKernelGGL(tri_fill_kernel, dim3((unsigned)((n + 255) / 256), ydim(n)), dim3(256), 0, ctx->stream, p, n, ld,
+                       v);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_symmetrize(fr_ctx* ctx, double* p, int64_t n, int64_t ld)
+{
+    if (n <= 0) return FR_OK;
+    const int64_t nbk = (n + 63) / 64;
+    if (nbk > 65535) return set_err(ctx, FR_INVALID_ARGUMENT, "matrix too large to symmetrize");
+    hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)nbk, (unsigned)nbk), dim3(256), 0, ctx->stream, p, n, ld);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_col_dot(fr_ctx* ctx, const double* U, int64_t ldu, const double* V, int64_t ldv, int64_t n, int64_t m,
+                   double* out)
+{
+    if (m <= 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)n * m, 8.0 * (double)n * m * (U == V ? 1.0 : 2.0));
+    hipLaunchKernelGGL(col_dot_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, U, ldu, V, ldv, n, out);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_col_norm2(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ldv, double* out)
+{
+    return launch_col_dot(ctx, V, ldv, V, ldv, n, m, out);
+}
+
+int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ldv, const double* y, double alpha,
+                  double beta, double* out)
+{
+    if (m <= 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)n * m, 8.0 * (double)n * m);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, V, n, ldv, y, alpha, beta, out);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_axpby_vec(fr_ctx* ctx, int64_t n, double a, const double* x, double b, double* y)
+{
+    if (n <= 0) return FR_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, a, x, b, y);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_diag_check_zero(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t* flag)
+{
+    if (n <= 0) return FR_OK;
+    hipLaunchKernelGGL(diag_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, n, lda, flag);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_sum_log_abs(fr_ctx* ctx, const double* v, int64_t n, double* out)
+{
+    hipLaunchKernelGGL(sum_log_abs_kernel, dim3(1), dim3(256), 0, ctx->stream, v, n, out);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+}  // namespace fr

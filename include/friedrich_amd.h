@@ -1,0 +1,211 @@
+/*
+ * friedrich_amd.h -- C ABI of the MI355X-native dense-linear-algebra core for friedrich.
+ *
+ * This is the drop-in boundary for friedrich's crate-private `algebra` module and for the
+ * `nalgebra::Cholesky<f64, Dynamic>` methods `GaussianProcess` calls on its private
+ * `covmat_cholesky` field (reference: src/lib.rs:39, src/gaussian_process/mod.rs:78).  The reference
+ * has no FFI of its own; every entry point below cites the reference item (file:line, relative to the
+ * friedrich 0.5.1 source tree) it replaces.  INTEGRATION.md shows the Rust `extern "C"` block and the
+ * replacement bodies a maintainer would add.
+ *
+ * Conventions
+ *  - All matrices are f64, column-major with an explicit leading dimension (nalgebra `DMatrix` layout;
+ *    `EMatrix::as_matrix()` has ld = capacity != nrows, src/algebra/extendable_matrix.rs:52-55).
+ *  - Every `const double*` / `double*` data argument may be a HOST pointer or a DEVICE (HIP) pointer; the
+ *    library classifies it with hipPointerGetAttributes and stages host data itself.
+ *  - Every function returns an fr_status; FR_OK == 0.  fr_last_error(ctx) gives the message.  The reference
+ *    panics where this ABI returns FR_NOT_POSITIVE_DEFINITE / FR_SINGULAR_SOLVE / FR_SHAPE; the host shim
+ *    turns the status back into the reference's panic text.
+ *  - Work is enqueued on the context's HIP stream; functions that return host results synchronise that
+ *    stream before returning, functions that only touch device memory do not.
+ *  - A fr_chol may be read concurrently (predict family) from several host threads only through distinct
+ *    contexts created with fr_ctx_create on the same device; mutation (add_rows, refactor) is exclusive.
+ */
+#ifndef FRIEDRICH_AMD_H
+#define FRIEDRICH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR_ABI_VERSION 1
+
+typedef enum {
+    FR_OK = 0,
+    FR_NOT_POSITIVE_DEFINITE = 1, /* a pivot was <= 0 / NaN and no usable substitute: algebra/mod.rs:85,90;
+                                     multivariate_normal.rs:57.  fr_chol_info() gives the column. */
+    FR_SINGULAR_SOLVE = 2,        /* exact zero on the factor's diagonal: mod.rs:203,263,345 */
+    FR_UNSUPPORTED_KERNEL = 3,    /* kernel program not expressible on device -> caller keeps the nalgebra path */
+    FR_SHAPE = 4,                 /* shape assertion of the reference violated: mod.rs:153,177,178,231,253,293,334,374 */
+    FR_INVALID_ARGUMENT = 5,
+    FR_OUT_OF_MEMORY = 6,
+    FR_HIP_ERROR = 7,
+    FR_RCCL_ERROR = 8,
+    FR_NO_DEVICE = 9
+} fr_status;
+
+/* ---- kernel program: POD description of a friedrich `Kernel` (src/parameters/kernel.rs) -------------
+ * Reverse-polish list: leaves push k(x,y), FR_K_SUM / FR_K_PROD pop two and push k1+k2 / k1*k2
+ * (KernelSum kernel.rs:132-211, KernelProd :221-307).  params[] follow get_parameters() order. */
+typedef enum {
+    FR_K_LINEAR = 0,            /* kernel.rs:342-402   [c]                */
+    FR_K_POLYNOMIAL = 1,        /* :411-485            [alpha, c, d]      */
+    FR_K_SQUAREDEXP = 2,        /* :496-601 (Gaussian) [ls, ampl]         */
+    FR_K_EXPONENTIAL = 3,       /* :612-706            [ls, ampl]         */
+    FR_K_MATERN1 = 4,           /* :717-813            [ls, ampl]         */
+    FR_K_MATERN2 = 5,           /* :824-925            [ls, ampl]         */
+    FR_K_HYPERTAN = 6,          /* :934-1001           [alpha, c]         */
+    FR_K_MULTIQUADRIC = 7,      /* :1010-1070          [c]                */
+    FR_K_RATIONALQUADRATIC = 8, /* :1079-1157          [alpha, ls]        */
+    FR_K_SUM = 100,
+    FR_K_PROD = 101
+} fr_kernel_kind;
+
+#define FR_KPROG_MAX_OPS 15
+
+typedef struct {
+    int32_t kind;    /* fr_kernel_kind */
+    int32_t nparams; /* number of values in params[] (0 for SUM/PROD) */
+    double params[3];
+} fr_kernel_op;
+
+typedef struct {
+    int32_t nops;
+    int32_t reserved;
+    fr_kernel_op ops[FR_KPROG_MAX_OPS];
+} fr_kprog;
+
+typedef struct fr_ctx fr_ctx;   /* device, HIP stream, workspaces, RCCL communicator */
+typedef struct fr_chol fr_chol; /* device-resident Cholesky factor (+ the training inputs it was built from) */
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int fr_abi_version(void);
+/* device < 0: current HIP device.  Fails with FR_NO_DEVICE when no gfx950 GPU is visible -- there is no
+ * CPU fallback behind this ABI. */
+int fr_ctx_create(fr_ctx** out, int device);
+void fr_ctx_destroy(fr_ctx* ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
+int fr_ctx_synchronize(fr_ctx* ctx);
+const char* fr_last_error(const fr_ctx* ctx);
+/* Tunables: "nb" (outer Cholesky block, multiple of 64), "gemm_tile" (0 = 128x128, 1 = 256x128). */
+int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
+
+/* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline leg). */
+typedef enum {
+    FR_PROF_GRAM = 0,      /* K1 Gram assembly kernels */
+    FR_PROF_POTF2 = 1,     /* K4 diagonal-block factor + inverse */
+    FR_PROF_GEMM_PANEL = 2,/* K5 panel / solve GEMMs (TRSM recast as GEMM) */
+    FR_PROF_SYRK = 3,      /* K6 trailing-update SYRK (the dominant FP64-MFMA kernel) */
+    FR_PROF_GEMM_SOLVE = 4,/* K5/K6 GEMMs issued by the triangular solves */
+    FR_PROF_REDUCE = 5,    /* K7 epilogue reductions */
+    FR_PROF_COMM = 6,      /* RCCL collectives */
+    FR_PROF_COUNT = 7
+} fr_prof_class;
+int fr_ctx_profile_enable(fr_ctx* ctx, int enable);
+int fr_ctx_profile_reset(fr_ctx* ctx);
+/* total milliseconds, launch count, and algorithmic flops / bytes accumulated for one class */
+int fr_ctx_profile_get(fr_ctx* ctx, int prof_class, double* ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) ---------------------------------------------- */
+#define FR_COMM_ID_BYTES 128
+int fr_comm_unique_id(void* out_id /* FR_COMM_ID_BYTES */);
+int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_id);
+int fr_ctx_comm_info(const fr_ctx* ctx, int* rank, int* world_size);
+
+/* ---- src/algebra/mod.rs --------------------------------------------------------------------------- */
+/* make_covariance_matrix (algebra/mod.rs:41-54): out[r,c] = k(A.row(r), B.row(c)), out is n1 x n2. */
+int fr_gram(fr_ctx* ctx, const fr_kprog* kernel, const double* A, int64_t n1, int64_t lda, const double* B,
+            int64_t n2, int64_t ldb, int64_t d, double* out, int64_t ldo);
+
+/* make_cholesky_cov_matrix (algebra/mod.rs:59-92) + Cholesky::new / new_with_substitute (nalgebra;
+ * called at :83,:90): K = lower(k(x_i,x_j)) + noise^2 I, factored on the device.  `noise` is the
+ * standard deviation (squared at :78).  has_eps/eps = cholesky_epsilon: Option<f64>.
+ * capacity_hint >= n reserves room for fr_chol_add_rows (EMatrix-style growth otherwise).
+ * On FR_NOT_POSITIVE_DEFINITE *out is still returned (free it) and fr_chol_info gives the column. */
+int fr_chol_from_inputs(fr_ctx* ctx, const fr_kprog* kernel, const double* X, int64_t n, int64_t ldx, int64_t d,
+                        double noise, int has_eps, double eps, int64_t capacity_hint, fr_chol** out);
+/* Same factorisation on the inputs already resident in the handle (the optimizer's re-fit,
+ * optimizer.rs:133-136, :267-270; fit_parameters mod.rs:426-429). */
+int fr_chol_refactor(fr_chol* chol, const fr_kprog* kernel, double noise, int has_eps, double eps);
+/* DMatrix::cholesky() / Cholesky::new_with_substitute on an explicit symmetric matrix (only the lower
+ * triangle is read): multivariate_normal.rs:57. */
+int fr_chol_from_matrix(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int has_eps, double eps,
+                        fr_chol** out);
+/* add_rows_cholesky_cov_matrix (algebra/mod.rs:97-126) + Cholesky::insert_column: append the last nb_new
+ * rows of Xall (n_all x d) to the factor as one blocked bordered update.  No epsilon, no failure check
+ * (plain sqrt => NaN), exactly like the reference. */
+int fr_chol_add_rows(fr_chol* chol, const fr_kprog* kernel, const double* Xall, int64_t n_all, int64_t ldx,
+                     int64_t d, int64_t nb_new, double noise);
+/* make_gradient_covariance_matrices (algebra/mod.rs:129-155) is never materialised; see fr_grad_terms. */
+
+/* ---- nalgebra::Cholesky methods used on covmat_cholesky -------------------------------------------- */
+/* n, capacity (row capacity of the device buffers), d, number of substituted pivots, failing column (-1) */
+int fr_chol_info(const fr_chol* chol, int64_t* n, int64_t* capacity, int64_t* d, int64_t* n_subst,
+                 int64_t* fail_col);
+/* ordered list of columns where cholesky_epsilon replaced the pivot ("pivot indices" of BASELINE.json) */
+int fr_chol_substitutions(const fr_chol* chol, int64_t* idx, int64_t max_idx);
+/* Cholesky::solve_mut (mod.rs:235; solve = clone + solve_mut :298,:379): B <- K^-1 B, B is n x m, in place */
+int fr_chol_solve(fr_chol* chol, double* B, int64_t m, int64_t ldb);
+/* Cholesky::l().solve_lower_triangular (mod.rs:203, 260-263, 342-345): B <- L^-1 B in place.
+ * FR_SINGULAR_SOLVE when the factor has an exact zero on its diagonal. */
+int fr_chol_solve_lower(fr_chol* chol, double* B, int64_t m, int64_t ldb);
+/* Cholesky::inverse (optimizer.rs:32,169): out <- K^-1 (n x n, both triangles) */
+int fr_chol_inverse(fr_chol* chol, double* out, int64_t ldo);
+/* Cholesky::l() / unpack() (upper_fill = 0: zeros) or the raw serde image of the factor
+ * (upper_fill = 1: NaN above the diagonal, algebra/mod.rs:67) */
+int fr_chol_download_l(fr_chol* chol, double* out, int64_t ldo, int upper_fill);
+/* Rebuild a device factor from a deserialised one (serde round trip, mod.rs:58): L n x n lower, X n x d. */
+int fr_chol_upload_l(fr_ctx* ctx, const double* L, int64_t n, int64_t ldl, const double* X, int64_t ldx,
+                     int64_t d, int64_t capacity_hint, fr_chol** out);
+void fr_chol_free(fr_chol* chol);
+
+/* ---- src/gaussian_process/mod.rs ------------------------------------------------------------------- */
+/* y = residual training outputs (training_outputs.as_vector(), n values); prior_q = prior.prior(&inputs)
+ * (m values, may be NULL for a zero prior); Xq is m x d. */
+/* likelihood (mod.rs:196-220) */
+int fr_likelihood(fr_chol* chol, const fr_kprog* kernel, const double* y, double noise, double* out);
+/* predict (mod.rs:226-244) */
+int fr_predict_mean(fr_chol* chol, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m,
+                    int64_t ldq, const double* prior_q, double* out_mean);
+/* predict_variance (mod.rs:248-273) */
+int fr_predict_variance(fr_chol* chol, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq,
+                        double* out_var);
+/* predict_mean_variance (mod.rs:290-326) */
+int fr_predict_mean_variance(fr_chol* chol, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m,
+                             int64_t ldq, const double* prior_q, double* out_mean, double* out_var);
+/* predict_covariance (mod.rs:329-350): out_cov is m x m */
+int fr_predict_covariance(fr_chol* chol, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq,
+                          double* out_cov, int64_t ldc);
+/* sample_at (mod.rs:371-392) + MultivariateNormal::new (multivariate_normal.rs:54-59): posterior mean,
+ * covariance (may be NULL) and cholesky(cov).unpack().  FR_NOT_POSITIVE_DEFINITE mirrors the expect() at
+ * multivariate_normal.rs:57. */
+int fr_posterior(fr_chol* chol, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m, int64_t ldq,
+                 const double* prior_q, double* out_mean, double* out_cov, int64_t ldc, double* out_cov_l,
+                 int64_t ldl);
+
+/* DMatrix::gemm / gemm_tr (mod.rs:348, 383; A.4): C <- alpha * op(A) * op(B) + beta * C on the FP64 matrix cores.
+ * trans_a / trans_b: 0 = as stored, 1 = transposed.  op(A) is M x K, op(B) is K x N, C is M x N.  C must not
+ * alias A or B. */
+int fr_gemm(fr_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+            int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+
+/* ---- src/parameters/kernel.rs heuristics ----------------------------------------------------------- */
+/* fit_bandwidth_mean (kernel.rs:94-113): mean Euclidean distance over the n(n-1)/2 row pairs */
+int fr_mean_pairwise_distance(fr_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t d, double* out);
+
+/* ---- src/gaussian_process/optimizer.rs ------------------------------------------------------------- */
+/* The per-iteration reductions of gradient_marginal_likelihood (:24-60, scaled = 0) and
+ * scaled_gradient_marginal_likelihood (:159-203, scaled = 1) without materialising K^-1 G_q products on
+ * the host: out_grad has nb_parameters (+1 when !scaled: the noise gradient, :54-57) entries,
+ * *out_scale = y^T K^-1 y / n (:174, scaled only). */
+int fr_grad_terms(fr_chol* chol, const fr_kprog* kernel, const double* y, double noise, int scaled,
+                  double* out_grad, double* out_scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRIEDRICH_AMD_H */

@@ -1,0 +1,311 @@
+"""GPU parity tests: every call goes through the C ABI (libfriedrich_amd.so) and is compared with the CPU
+oracle (oracle/) on the same seeded inputs.  Tolerance: BASELINE.json's north_star allows 1e-8 relative
+error for f64 results; the tests hold the HIP path to TOL = 1e-9 (typically observed: 1e-13..1e-11), and the
+substitution ("pivot") index lists to exact equality on margin fixtures."""
+import numpy as np
+import pytest
+
+from conftest import ALL_KERNELS, PD_KERNELS, rand_inputs, rel_err
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9        # north_star: <= 1e-8 relative
+TOL_GRAM = 1e-13  # per-pair kernel values: only libm differences (exp/pow/tanh/hypot)
+
+
+# ---- K5/K6 GEMM ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 150, 77), (129, 1, 300), (1, 257, 5), (300, 260, 16), (17, 19, 0)])
+def test_gemm_matches_numpy(ctx, ta, tb, M, N, K):
+    rng = np.random.default_rng(M * 1000 + N * 10 + K + ta * 2 + tb)
+    A = np.asfortranarray(rng.standard_normal((K, M) if ta else (M, K)))
+    B = np.asfortranarray(rng.standard_normal((N, K) if tb else (K, N)))
+    C0 = np.asfortranarray(rng.standard_normal((M, N)))
+    C = C0.copy(order="F")
+    ctx.gemm(A, B, C, trans_a=bool(ta), trans_b=bool(tb), alpha=-0.75, beta=1.25)
+    ref = -0.75 * ((A.T if ta else A) @ (B.T if tb else B)) + 1.25 * C0
+    assert rel_err(C, ref) < 1e-13
+    # beta == 0 must not read C (NaN-filled output buffer)
+    C = np.full((M, N), np.nan, order="F")
+    ctx.gemm(A, B, C, trans_a=bool(ta), trans_b=bool(tb), alpha=1.0, beta=0.0)
+    assert rel_err(C, (A.T if ta else A) @ (B.T if tb else B)) < 1e-13
+
+
+# ---- K1 Gram ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ALL_KERNELS, ids=lambda k: k[0] + str(len(k)))
+@pytest.mark.parametrize("n1,n2,d", [(150, 70, 5), (1, 1, 1), (129, 65, 16), (64, 200, 19)])
+def test_gram_matches_oracle(ctx, kernel, n1, n2, d):
+    A, B = rand_inputs(n1, d, 1), rand_inputs(n2, d, 2)
+    got = ctx.gram(kernel, A, B)
+    want = O.make_covariance_matrix(kernel, A, B)
+    assert rel_err(got, want) < TOL_GRAM
+
+
+def test_gram_strided_inputs(ctx):
+    # EMatrix::as_matrix(): leading dimension = capacity != nrows (extendable_matrix.rs:52-55)
+    big = rand_inputs(300, 4, 3)
+    view = big[:170]  # ld = 300
+    k = ("matern2", 0.7, 1.2)
+    import ctypes
+    from friedrich_amd import _capi as C
+    out = np.empty((170, 170), order="F")
+    p = C.kprog(k)
+    st = ctx.lib.fr_gram(ctx.h, ctypes.byref(p), big.ctypes.data, 170, 300, big.ctypes.data, 170, 300, 4,
+                         out.ctypes.data, 170)
+    assert st == 0
+    assert rel_err(out, O.make_covariance_matrix(k, view, view)) < TOL_GRAM
+
+
+def test_mean_pairwise_distance(ctx):
+    for n, d in [(2, 1), (257, 3), (1000, 16)]:
+        X = rand_inputs(n, d, n)
+        assert abs(ctx.mean_pairwise_distance(X) / O.fit_bandwidth_mean(X) - 1.0) < 1e-12
+
+
+# ---- K4/K5/K6 Cholesky -----------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 4, 63, 64, 65, 127, 128, 129, 200, 256, 300, 513, 1000])
+@pytest.mark.parametrize("kernel", [PD_KERNELS[0], PD_KERNELS[1]], ids=["se", "matern2"])
+def test_cholesky_matches_oracle(ctx, n, kernel):
+    X = rand_inputs(n, 3, n)
+    noise = 0.1
+    st, L_o, idx_o = O.make_cholesky_cov_matrix(kernel, X, noise)
+    assert st == 0 and len(idx_o) == 0
+    chol = ctx.cholesky_from_inputs(kernel, X, noise)
+    info = chol.info()
+    assert info["n"] == n and info["n_subst"] == 0 and info["fail_col"] == -1
+    L = chol.l()
+    assert rel_err(L, np.tril(L_o)) < TOL
+    assert np.all(np.triu(L, 1) == 0.0)
+    Ln = chol.l(nan_upper=True)
+    assert np.all(np.isnan(Ln[np.triu_indices(n, 1)]))  # serde image keeps NaN above the diagonal (algebra/mod.rs:67)
+    chol.free()
+
+
+@pytest.mark.parametrize("kernel", PD_KERNELS, ids=lambda k: k[0] + str(len(k)))
+def test_cholesky_kernels_and_block_sizes(ctx, kernel):
+    n = 700
+    X = rand_inputs(n, 6, 11)
+    st, L_o, _ = O.make_cholesky_cov_matrix(kernel, X, 0.05)
+    assert st == 0
+    for nb in (64, 128, 256, 512):
+        ctx.set_option("nb", nb)
+        chol = ctx.cholesky_from_inputs(kernel, X, 0.05)
+        assert rel_err(chol.l(), np.tril(L_o)) < TOL
+        chol.free()
+    ctx.set_option("nb", 256)
+
+
+def test_readme_dataset(ctx):
+    # the reference's only dataset (src/main.rs:16-17)
+    X = np.array([[0.8], [1.2], [3.8], [4.2]])
+    k = ("squared_exp", 1.0, 1.0)
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    chol = ctx.cholesky_from_inputs(k, X, 0.1)
+    assert rel_err(chol.l(), np.tril(L_o)) < 1e-14
+    chol.free()
+
+
+def test_substitution_indices_margin_fixture(ctx):
+    # tanh "kernel" Gram matrices are robustly indefinite: every failing pivot is far from zero, so the
+    # left-looking (reference) and blocked right-looking (HIP) factorisations must substitute the SAME columns
+    n = 256
+    X = rand_inputs(n, 2, 5) * 3.0
+    k = ("hyper_tan", 1.0, 0.0)
+    eps = 1e-6
+    st, L_o, idx_o = O.make_cholesky_cov_matrix(k, X, 0.0, eps)
+    assert st == 0 and len(idx_o) > 10
+    chol = ctx.cholesky_from_inputs(k, X, 0.0, eps=eps)
+    idx = chol.substitutions()
+    assert idx.tolist() == idx_o.tolist()
+    chol.free()
+
+
+def test_substitution_from_matrix_negative_block(ctx):
+    rng = np.random.default_rng(0)
+    n = 200
+    Q = rng.standard_normal((n, n))
+    A = Q @ Q.T + n * np.eye(n)
+    A[188:, 188:] -= 3.0 * n * np.eye(12)  # pivots 188.. strongly negative
+    st, L_o, idx_o = O.cholesky(A, sub=200.0)
+    assert st == 0 and len(idx_o) > 0
+    chol = ctx.cholesky_from_matrix(A, eps=200.0)
+    assert chol.substitutions().tolist() == idx_o.tolist()
+    assert rel_err(chol.l(), np.tril(L_o)) < TOL
+    chol.free()
+
+
+def test_failure_status_and_column(ctx):
+    from friedrich_amd.device import FriedrichError
+    rng = np.random.default_rng(1)
+    n = 300
+    Q = rng.standard_normal((n, n))
+    A = Q @ Q.T + n * np.eye(n)
+    A[222, 222] = -5.0
+    st_o, _, _ = O.cholesky(A)
+    assert st_o == 1 + 222
+    chol = ctx.cholesky_from_matrix(A, allow_failure=True)
+    assert chol.info()["fail_col"] == 222
+    chol.free()
+    with pytest.raises(FriedrichError) as e:
+        ctx.cholesky_from_matrix(A)
+    assert e.value.status == 1
+    # epsilon <= 0 cannot rescue the factorisation (algebra/mod.rs:85)
+    chol = ctx.cholesky_from_matrix(A, eps=0.0, allow_failure=True)
+    assert chol.info()["fail_col"] == 222
+    chol.free()
+
+
+# ---- solves ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m", [(5, 1), (130, 3), (300, 200), (513, 129), (1000, 64)])
+def test_solves_match_oracle(ctx, n, m):
+    k = ("matern2", 0.7, 1.2)
+    X = rand_inputs(n, 4, n + m)
+    B = np.asfortranarray(np.random.default_rng(m).standard_normal((n, m)))
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    chol = ctx.cholesky_from_inputs(k, X, 0.1)
+    assert rel_err(chol.solve_lower(B), O.solve_lower(L_o, B)[1]) < TOL
+    assert rel_err(chol.solve(B), O.chol_solve(L_o, B)) < TOL
+    if n <= 513:
+        assert rel_err(chol.inverse(), O.chol_inverse(L_o)) < TOL
+    chol.free()
+
+
+def test_upload_download_roundtrip(ctx):
+    k = ("squared_exp", 0.8, 1.3)
+    n = 333
+    X = rand_inputs(n, 3, 9)
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    chol = ctx.cholesky_upload(L_o, X)  # NaN upper triangle, as serde would deliver it
+    B = np.asfortranarray(np.random.default_rng(3).standard_normal((n, 7)))
+    assert rel_err(chol.solve(B), O.chol_solve(L_o, B)) < TOL
+    assert rel_err(chol.l(), np.tril(L_o)) == 0.0
+    chol.free()
+
+
+# ---- predict family --------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", [PD_KERNELS[0], PD_KERNELS[1], PD_KERNELS[4]], ids=["se", "matern2", "sum"])
+@pytest.mark.parametrize("n,m,d", [(4, 1, 1), (200, 33, 2), (515, 130, 8)])
+def test_predict_family_matches_oracle(ctx, kernel, n, m, d):
+    X = rand_inputs(n, d, 100 + n)
+    Xq = rand_inputs(m, d, 200 + m)
+    y = np.sin(X.sum(axis=1)) + 0.3
+    prior = O.ConstantPrior(0.25)
+    gp = O.OracleGP(prior, kernel, 0.07, None, X, y)
+    chol = ctx.cholesky_from_inputs(kernel, X, 0.07)
+    yres = gp.y
+    pq = prior.prior(Xq)
+    assert rel_err(chol.predict_mean(kernel, yres, Xq, pq), gp.predict(Xq)) < TOL
+    var = chol.predict_variance(kernel, Xq)
+    assert np.max(np.abs(var - gp.predict_variance(Xq))) < TOL * np.max(np.abs(gp.predict_variance(Xq)) + 1.0)
+    mean2, var2 = chol.predict_mean_variance(kernel, yres, Xq, pq)
+    mo, vo = gp.predict_mean_variance(Xq)
+    assert rel_err(mean2, mo) < TOL
+    assert np.max(np.abs(var2 - vo)) < TOL * (np.max(np.abs(vo)) + 1.0)
+    assert rel_err(chol.predict_covariance(kernel, Xq), gp.predict_covariance(Xq)) < 1e-8
+    assert abs(chol.likelihood(kernel, yres, 0.07) / gp.likelihood() - 1.0) < TOL
+    chol.free()
+
+
+def test_posterior_matches_oracle(ctx):
+    k = ("squared_exp", 0.6, 1.1)
+    n, m, d = 400, 40, 2
+    X, Xq = rand_inputs(n, d, 1), rand_inputs(m, d, 2)
+    y = np.cos(X.sum(axis=1))
+    gp = O.OracleGP(O.ZeroPrior(), k, 0.1, None, X, y)
+    chol = ctx.cholesky_from_inputs(k, X, 0.1)
+    mean, cov, cov_l = chol.posterior(k, y, Xq)
+    mo, co, lo = gp.sample_at(Xq)
+    assert rel_err(mean, mo) < TOL
+    assert rel_err(cov, co) < 1e-8
+    assert rel_err(cov_l, lo) < 1e-6  # the m x m posterior is itself ill-conditioned (cond ~ 1e6)
+    assert np.all(np.triu(cov_l, 1) == 0.0)
+    z = np.linspace(-1, 1, m)
+    assert rel_err(O.OracleGP.mvn_sample(mean, cov_l, z), O.OracleGP.mvn_sample(mo, lo, z)) < 1e-6
+    chol.free()
+
+
+# ---- add_samples -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("n0,chunks", [(4, [4]), (100, [1, 27, 128]), (130, [200, 64]), (256, [256])])
+def test_add_rows_matches_oracle_and_refit(ctx, n0, chunks):
+    k = ("matern2", 0.8, 1.0)
+    d = 3
+    total = n0 + sum(chunks)
+    Xall = rand_inputs(total, d, 77)
+    noise = 0.1
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, Xall[:n0], noise)
+    chol = ctx.cholesky_from_inputs(k, Xall[:n0], noise)  # capacity == n0: exercises EMatrix-style growth
+    n = n0
+    for c in chunks:
+        L_o = O.add_rows_cholesky_cov_matrix(k, L_o, Xall[:n + c], c, noise)
+        chol.add_rows(k, np.asfortranarray(Xall[:n + c]), c, noise)
+        n += c
+        assert chol.n == n
+        assert rel_err(chol.l(), np.tril(L_o)) < TOL
+    # equals a from-scratch factor of the grown set, and the solves still work (inverse blocks re-aligned)
+    st, L_full, _ = O.make_cholesky_cov_matrix(k, Xall, noise)
+    assert rel_err(chol.l(), np.tril(L_full)) < TOL
+    B = np.asfortranarray(np.random.default_rng(5).standard_normal((total, 9)))
+    assert rel_err(chol.solve(B), O.chol_solve(L_full, B)) < TOL
+    chol.free()
+
+
+def test_add_rows_has_no_epsilon_and_no_failure_check(ctx):
+    # add_samples never applies cholesky_epsilon (mod.rs:185-189): a duplicated noiseless row yields a zero /
+    # NaN pivot silently, exactly like Cholesky::insert_column's plain sqrt
+    k = ("squared_exp", 1.0, 1.0)
+    X = np.array([[0.0], [1.0], [2.0]])
+    chol = ctx.cholesky_from_inputs(k, X, 0.0, eps=1e-6)
+    Xall = np.asfortranarray(np.vstack([X, [[1.0]], [[3.0]]]))
+    L_o = O.add_rows_cholesky_cov_matrix(k, O.make_cholesky_cov_matrix(k, X, 0.0, 1e-6)[1], Xall, 2, 0.0)
+    chol.add_rows(k, Xall, 2, 0.0)
+    L = chol.l()
+    lo = np.tril(L_o)
+    assert np.array_equal(np.isfinite(L), np.isfinite(lo))
+    fin = np.isfinite(lo)
+    assert rel_err(L[fin], lo[fin]) < 1e-6
+    chol.free()
+
+
+# ---- device-resident inputs (zero copy) --------------------------------------------------------------
+def test_device_pointers(ctx):
+    import torch
+    k = ("squared_exp", 0.9, 1.0)
+    n, m, d = 384, 50, 4
+    X, Xq = rand_inputs(n, d, 21), rand_inputs(m, d, 22)
+    y = np.sin(X.sum(axis=1))
+    dev = torch.device("cuda:0")
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev).t()      # column-major n x d on the GPU
+    Xqd = torch.from_numpy(np.ascontiguousarray(Xq.T)).to(dev).t()
+    yd = torch.from_numpy(y).to(dev)
+    outd = torch.empty(m, dtype=torch.float64, device=dev)
+    chol = ctx.cholesky_from_inputs(k, Xd, 0.1)
+    chol.predict_mean(k, yd, Xqd, None, out=outd)
+    ctx.synchronize()
+    gp = O.OracleGP(O.ZeroPrior(), k, 0.1, None, X, y)
+    assert rel_err(outd.cpu().numpy(), gp.predict(Xq)) < TOL
+    chol.free()
+
+
+# ---- size-independent properties at benchmark scale ---------------------------------------------------
+def test_large_factor_properties(ctx):
+    # N = 4096, d = 8 (BASELINE config 2): L L^T reproduces K, and solve() inverts K, without the O(n^3) oracle
+    from friedrich_amd import synth
+    n, d, m = 4096, 8, 256
+    X, y, Xq = synth.make_problem(n, d, cfg=2, m=m)
+    ls = ctx.mean_pairwise_distance(X)
+    hp = synth.default_hyperparameters(X, y, ls)
+    k = ("squared_exp", hp["ls"], hp["ampl"])
+    chol = ctx.cholesky_from_inputs(k, X, hp["noise"])
+    assert chol.info()["n_subst"] == 0
+    L = chol.l()
+    K = ctx.gram(k, X, X) + hp["noise"] ** 2 * np.eye(n)
+    LLt = ctx.gemm(L, L, trans_b=True)
+    assert rel_err(LLt, K) < 1e-12
+    B = np.asfortranarray(np.random.default_rng(0).standard_normal((n, 8)))
+    Z = chol.solve(B)
+    assert rel_err(K @ Z, B) < 1e-9
+    # predict_variance is non-negative and below the prior variance
+    var = chol.predict_variance(k, Xq)
+    assert np.all(var > -1e-10) and np.all(var <= hp["ampl"] + 1e-12)
+    chol.free()
