@@ -105,6 +105,41 @@ SIGNATURES = {
 }
 
 _lib = None
+hip_runtime = None  # "torch" or "system" once loaded
+
+
+def _preload_hip_runtime():
+    """libfriedrich_amd.so carries no DT_NEEDED on libamdhip64: bind it to the ONE HIP runtime of this process.
+    torch wheels bundle their own libamdhip64/libhsa-runtime64/librccl; a second runtime in the same process
+    cannot open the GPU, so when torch is installed its copy is used (FRIEDRICH_AMD_HIP_RUNTIME=system|torch
+    overrides)."""
+    global hip_runtime
+    mode = os.environ.get("FRIEDRICH_AMD_HIP_RUNTIME", "auto")
+    if mode in ("auto", "torch"):
+        try:
+            import torch  # noqa: F401  (loads its bundled ROCm libraries)
+
+            tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+            p = os.path.join(tl, "libamdhip64.so")
+            if os.path.exists(p):
+                ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+                rccl = os.path.join(tl, "librccl.so")
+                if os.path.exists(rccl):
+                    os.environ.setdefault("FRIEDRICH_AMD_RCCL_PATH", rccl)
+                hip_runtime = "torch"
+                return
+        except ImportError:
+            if mode == "torch":
+                raise
+    for cand in ("/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7",
+                 "libamdhip64.so"):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            hip_runtime = "system"
+            return
+        except OSError:
+            continue
+    raise RuntimeError("no HIP runtime (libamdhip64) found")
 
 
 def load():
@@ -116,6 +151,7 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build the HIP library first (python -m friedrich_amd.build). "
             "There is no CPU fallback behind this package.")
+    _preload_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == the ABI lost a symbol

@@ -17,6 +17,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libfriedrich_amd.so")
 SOURCES = ["ctx.hip", "gram.hip", "gemm_f64.hip", "potf2.hip", "util.hip", "chol.hip", "gp.hip", "comm.hip", "dist.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CLANGXX = os.environ.get("FR_CLANGXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I/opt/rocm/include"]
 
@@ -55,7 +56,10 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _newer(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+        # Linked WITHOUT a DT_NEEDED on libamdhip64: the HIP runtime is whichever one the host process already
+        # has (torch bundles its own copy; two HSA runtimes in one process cannot both open the GPU).
+        # Python: friedrich_amd._capi.load() preloads it; C/C++/Rust hosts link -lamdhip64 themselves.
+        run([CLANGXX, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

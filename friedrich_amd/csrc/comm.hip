@@ -1,6 +1,7 @@
 // comm.hip -- RCCL plumbing (one process per GPU; collectives over xGMI).  librccl is loaded lazily with
 // dlopen so single-GPU users never pay for it; there is no other transport.
 #include <dlfcn.h>
+#include <cstdlib>
 #include <rccl/rccl.h>
 
 #include "fr_internal.hpp"
@@ -23,7 +24,11 @@ static RcclApi g_rccl;
 static int rccl_load(fr_ctx* ctx)
 {
     if (g_rccl.handle) return FR_OK;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // The RCCL build must match the process's HIP runtime (torch bundles its own pair): the host names it.
+    void* h = nullptr;
+    if (const char* p = getenv("FRIEDRICH_AMD_RCCL_PATH")) h = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // already loaded (e.g. by torch)
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return set_err(ctx, FR_RCCL_ERROR, "cannot load librccl: %s", dlerror());

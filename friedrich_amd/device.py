@@ -6,6 +6,7 @@ Matrices may be
 All numerical work happens inside libfriedrich_amd.so; this file only marshals pointers, sizes and statuses.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -85,9 +86,12 @@ class Context:
         if st != C.FR_OK:
             raise FriedrichError(st, "fr_ctx_create failed (is a gfx950 GPU visible?)")
         self.h = h
+        self._children = weakref.WeakSet()  # live Cholesky handles: freed before the context goes away
 
     def close(self):
         if getattr(self, "h", None):
+            for child in list(self._children):
+                child.free()
             self.lib.fr_ctx_destroy(self.h)
             self.h = None
 
@@ -223,10 +227,12 @@ class Cholesky:
         self.ctx = ctx
         self.lib = ctx.lib
         self.h = handle
+        ctx._children.add(self)
 
     def free(self):
         if getattr(self, "h", None):
-            self.lib.fr_chol_free(self.h)
+            if getattr(self.ctx, "h", None):  # the factor's stream lives in the context
+                self.lib.fr_chol_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -183,8 +183,8 @@ def _ld(a):
     """leading dimension of a column-major 2-D array (supports row-sliced views of F arrays)"""
     if a.ndim == 1:
         return a.shape[0]
-    assert a.strides[0] == 8, "need unit row stride (column-major)"
-    return a.strides[1] // 8 if a.shape[1] > 1 else max(a.shape[0], 1)
+    assert a.shape[0] <= 1 or a.strides[0] == 8, "need unit row stride (column-major)"
+    return max(a.strides[1] // 8, a.shape[0], 1) if a.shape[1] > 1 else max(a.shape[0], 1)
 
 
 def _vec(a):
