@@ -95,8 +95,36 @@ static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, doubl
     return FR_OK;
 }
 
+// Factor the kb-wide column block starting at (j0, j0): diagonal 128-blocks, the TRSM of everything below them
+// and the left-looking update of the block's remaining columns.  Needs the block fully updated by earlier panels.
+static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
+                        double sub, double* dinv, int64_t* info, double* T)
+{
+    for (int64_t s = 0; s < kb; s += IB) {
+        const int64_t j = k + s, sb = imin(IB, kb - s);
+        double* inv = dinv + (j / IB) * INV_ELEMS;
+        FR_TRY(factor_block128(ctx, A + j + j * ld, ld, sb, col0 + j, mode, sub, inv, info, T));
+        const int64_t below = n - (j + sb);
+        if (below > 0) {
+            // K5: panel TRSM  B <- B * L_jj^-T  as a GEMM against the explicit inverse
+            double* B = A + (j + sb) + j * ld;
+            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, sb, sb, B, ld, false, inv, IB, false, 1.0, 0.0, B, ld));
+            const int64_t right = kb - (s + sb);
+            if (right > 0)  // remaining columns of this outer block (left-looking inside the block)
+                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, right, sb, B, ld, false, B, ld, false, -1.0, 1.0,
+                            A + (j + sb) + (j + sb) * ld, ld));
+        }
+    }
+    return FR_OK;
+}
+
 // In-place blocked Cholesky of the n x n lower triangle at A.  dinv receives the inverses of the diagonal
 // 128-blocks (block i of this sub-matrix at dinv + i*INV_ELEMS).
+//
+// Look-ahead: the panel path (K4 + K5: ~10 small, latency-bound launches per 128 columns) would otherwise
+// serialise with the big trailing SYRK.  Step k's trailing update is therefore split: the next panel's nb columns
+// are updated first, then that panel is factored on a second, high-priority HIP stream while the main stream
+// updates the rest of the trailing matrix (K6).  The two streams touch disjoint columns; events order them.
 static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
                          int64_t* info, int64_t nb)
 {
@@ -104,31 +132,63 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     WsGuard tg(ctx);
     double* T = tg.get(sizeof(double) * 64 * 64);
     if (!T) return FR_OUT_OF_MEMORY;
-    for (int64_t k = 0; k < n; k += nb) {
-        const int64_t kb = imin(nb, n - k);
-        for (int64_t s = 0; s < kb; s += IB) {
-            const int64_t j = k + s, sb = imin(IB, kb - s);
-            double* inv = dinv + (j / IB) * INV_ELEMS;
-            FR_TRY(factor_block128(ctx, A + j + j * ld, ld, sb, col0 + j, mode, sub, inv, info, T));
-            const int64_t below = n - (j + sb);
-            if (below > 0) {
-                // K5: panel TRSM  B <- B * L_jj^-T  as a GEMM against the explicit inverse
-                double* B = A + (j + sb) + j * ld;
-                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, sb, sb, B, ld, false, inv, IB, false, 1.0, 0.0, B, ld));
-                const int64_t right = kb - (s + sb);
-                if (right > 0)  // remaining columns of this outer block (left-looking inside the block)
-                    FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, right, sb, B, ld, false, B, ld, false, -1.0, 1.0,
-                                A + (j + sb) + (j + sb) * ld, ld));
+    const bool la = ctx->lookahead && ctx->stream2 && n > 2 * nb && ctx->ls == ctx->stream;
+    if (!la) {
+        for (int64_t k = 0; k < n; k += nb) {
+            const int64_t kb = imin(nb, n - k);
+            FR_TRY(factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T));
+            const int64_t rest = n - (k + kb);
+            if (rest > 0) {
+                // K6: trailing update, lower triangle only
+                const double* P = A + (k + kb) + k * ld;
+                FR_TRY(gemm(ctx, FR_PROF_SYRK, rest, rest, kb, P, ld, false, P, ld, false, -1.0, 1.0,
+                            A + (k + kb) + (k + kb) * ld, ld, true));
             }
         }
+        return FR_OK;
+    }
+    hipStream_t S0 = ctx->stream, S1 = ctx->stream2;
+    int st = FR_OK;
+    auto fail = [&](int code) {
+        ctx->ls = S0;
+        (void)hipStreamSynchronize(S1);
+        return code;
+    };
+    // the panel stream starts after everything already queued on the main stream (Gram assembly)
+    FR_HIP(ctx, hipEventRecord(ctx->ev_la, S0));
+    FR_HIP(ctx, hipStreamWaitEvent(S1, ctx->ev_la, 0));
+    ctx->ls = S1;
+    st = factor_panel(ctx, A, ld, n, 0, imin(nb, n), col0, mode, sub, dinv, info, T);
+    if (st != FR_OK) return fail(st);
+    if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
+    for (int64_t k = 0; k < n; k += nb) {
+        const int64_t kb = imin(nb, n - k);
         const int64_t rest = n - (k + kb);
-        if (rest > 0) {
-            // K6: trailing update, lower triangle only
-            const double* P = A + (k + kb) + k * ld;
-            FR_TRY(gemm(ctx, FR_PROF_SYRK, rest, rest, kb, P, ld, false, P, ld, false, -1.0, 1.0,
-                        A + (k + kb) + (k + kb) * ld, ld, true));
+        ctx->ls = S0;
+        if (hipStreamWaitEvent(S0, ctx->ev_panel, 0) != hipSuccess) return fail(FR_HIP_ERROR);
+        if (rest <= 0) break;
+        const int64_t kb2 = imin(nb, rest);
+        const double* P = A + (k + kb) + k * ld;
+        // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
+        st = gemm(ctx, FR_PROF_SYRK, rest, kb2, kb, P, ld, false, P, ld, false, -1.0, 1.0, A + (k + kb) + (k + kb) * ld, ld);
+        if (st != FR_OK) return fail(st);
+        if (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess)
+            return fail(FR_HIP_ERROR);
+        ctx->ls = S1;
+        st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T);
+        if (st != FR_OK) return fail(st);
+        if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
+        ctx->ls = S0;
+        const int64_t rest2 = rest - kb2;
+        if (rest2 > 0) {
+            // K6: the rest of the trailing update runs under the next panel
+            const double* P2 = P + kb2;
+            st = gemm(ctx, FR_PROF_SYRK, rest2, rest2, kb, P2, ld, false, P2, ld, false, -1.0, 1.0,
+                      A + (k + kb + kb2) + (k + kb + kb2) * ld, ld, true);
+            if (st != FR_OK) return fail(st);
         }
     }
+    ctx->ls = S0;
     return FR_OK;
 }
 

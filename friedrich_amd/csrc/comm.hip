@@ -58,14 +58,14 @@ int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root)
 {
     if (ctx->world <= 1) return FR_OK;
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count);
-    FR_NCCL(ctx, g_rccl.Broadcast(buf, buf, count, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->stream));
+    FR_NCCL(ctx, g_rccl.Broadcast(buf, buf, count, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
 
 int comm_bcast_i64(fr_ctx* ctx, int64_t* buf, size_t count, int root)
 {
     if (ctx->world <= 1) return FR_OK;
-    FR_NCCL(ctx, g_rccl.Broadcast(buf, buf, count, ncclInt64, root, (ncclComm_t)ctx->comm, ctx->stream));
+    FR_NCCL(ctx, g_rccl.Broadcast(buf, buf, count, ncclInt64, root, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
 
@@ -76,7 +76,7 @@ int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_p
         return FR_OK;
     }
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count_per_rank * ctx->world);
-    FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, (ncclComm_t)ctx->comm, ctx->stream));
+    FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
 

@@ -186,13 +186,13 @@ ProfScope::ProfScope(fr_ctx* c, int cls_, double flops, double bytes) : ctx(c), 
     ctx->prof_bytes[cls] += bytes;
     a = get_event(ctx);
     b = get_event(ctx);
-    if (a) (void)hipEventRecord(a, ctx->stream);
+    if (a) (void)hipEventRecord(a, ctx->ls);
 }
 
 ProfScope::~ProfScope()
 {
     if (!ctx->prof || !a || !b) return;
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, ctx->ls);
     ProfRec r;
     r.a = a;
     r.b = b;
@@ -249,6 +249,15 @@ int fr_ctx_create(fr_ctx** out, int device)
         return FR_HIP_ERROR;
     }
     ctx->own_stream = true;
+    ctx->ls = ctx->stream;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+    if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_la, hipEventDisableTiming) != hipSuccess) {
+        fr_ctx_destroy(ctx);
+        return FR_HIP_ERROR;
+    }
     *out = ctx;
     return FR_OK;
 }
@@ -267,6 +276,12 @@ void fr_ctx_destroy(fr_ctx* ctx)
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     for (auto& b : ctx->pool)
         if (b.p) (void)hipFree(b.p);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
+    if (ctx->ev_panel) (void)hipEventDestroy(ctx->ev_panel);
+    if (ctx->ev_la) (void)hipEventDestroy(ctx->ev_la);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -277,6 +292,7 @@ int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
+    ctx->ls = ctx->stream;
     ctx->own_stream = false;
     return FR_OK;
 }
@@ -300,6 +316,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         int64_t v = value / kDiagBlock;
         if (v & (v - 1)) return set_err(ctx, FR_INVALID_ARGUMENT, "nb / %d must be a power of two", kDiagBlock);
         ctx->nb = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "lookahead")) {
+        ctx->lookahead = value != 0;
         return FR_OK;
     }
     if (!strcmp(name, "gemm_tile")) {

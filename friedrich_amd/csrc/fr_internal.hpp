@@ -34,8 +34,12 @@ struct ProfRec {
 
 struct fr_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // main stream (memcpys, host synchronisation)
     bool own_stream = true;
+    hipStream_t ls = nullptr;       // stream the kernel launchers enqueue on (== stream except inside look-ahead)
+    hipStream_t stream2 = nullptr;  // high-priority panel stream of the look-ahead Cholesky
+    hipEvent_t ev_panel = nullptr, ev_la = nullptr;
+    int64_t lookahead = 1;
     std::string err;
     // grow-only workspace pool (stream-ordered reuse inside one context)
     std::vector<fr::DevBuf> pool;

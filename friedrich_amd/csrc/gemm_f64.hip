@@ -78,6 +78,22 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ P, int64_t 
     }
 }
 
+// Branch-free variant for tiles that lie entirely inside the operand (every tile but the last row / column of
+// tiles, every K-step but a ragged last one).  The predicated loader above compiles to one exec-masked branch per
+// element -- ~300 scalar/branch instructions per K-step in front of the MFMAs -- so the hot path must avoid it.
+template <bool KMAJ>
+__device__ __forceinline__ void load_tile_fast(const double* __restrict__ p, int64_t ld, double (&reg)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reg[i] = p[(int64_t)(KMAJ ? 16 * i : 2 * i) * ld];
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ const double* tile_thread_base(const double* P, int64_t ld, int64_t x0, int t)
+{
+    return KMAJ ? P + (t & 15) + (x0 + (t >> 4)) * ld : P + (x0 + (t & 127)) + (int64_t)(t >> 7) * ld;
+}
+
 template <bool KMAJ>
 __device__ __forceinline__ void store_tile(double* __restrict__ S, int t, const double (&reg)[8])
 {
@@ -97,8 +113,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
 {
     __shared__ double lds[4 * TILE_ELEMS];  // [stage][A|B][TILE_ELEMS]
 
-    // XCD-aware tile assignment: block b runs on XCD b % 8; give each XCD a contiguous run of tiles so
-    // neighbouring tiles (shared operand panels) hit the same private L2.
+    // XCD-aware tile assignment: block b runs on XCD b % 8 (observed dispatch rule; speed only); give each XCD a
+    // contiguous run of tiles so neighbouring tiles (shared operand panels) hit the same private L2.
+    // (An 8x8 "super-tile" order was measured and lost 7 % on the SYRK and 30 % on the solves: dropped.)
     const int64_t nblk = gridDim.x;
     const int64_t b = blockIdx.x;
     const int64_t q = nblk >> 3, r8 = nblk & 7, xcd = b & 7;
@@ -130,11 +147,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
         for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
 
     const int64_t nk = (g.K + BK - 1) / BK;
+    const int64_t nk_full = g.K / BK;  // K-steps that need no k predicate
+    const bool a_fast = (m0 + BM) <= g.M, b_fast = (n0 + BN) <= g.N;
+    // per-thread pointers of the branch-free loader, advanced by one K-step at a time
+    const double* pa = tile_thread_base<A_KMAJ>(g.A, g.lda, m0, t);
+    const double* pb = tile_thread_base<B_KMAJ>(g.B, g.ldb, n0, t);
+    const int64_t step_a = A_KMAJ ? BK : BK * g.lda, step_b = B_KMAJ ? BK : BK * g.ldb;
     double ra[8], rb[8];
     if (nk > 0) {
-        load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, 0, g.K, t, ra);
+        if (a_fast && nk_full > 0)
+            load_tile_fast<A_KMAJ>(pa, g.lda, ra);
+        else
+            load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, 0, g.K, t, ra);
         // op(B) element (k, n): B_KMAJ -> B[k + n*ldb] (k contiguous), else B[n + k*ldb]
-        load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, 0, g.K, t, rb);
+        if (b_fast && nk_full > 0)
+            load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+        else
+            load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, 0, g.K, t, rb);
         store_tile<A_KMAJ>(lds, t, ra);
         store_tile<B_KMAJ>(lds + TILE_ELEMS, t, rb);
     }
@@ -144,8 +173,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
     for (int64_t kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1) < nk;
         if (more) {
-            load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, t, ra);
-            load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, t, rb);
+            pa += step_a;
+            pb += step_b;
+            const bool kfull = (kt + 1) < nk_full;
+            if (a_fast && kfull)
+                load_tile_fast<A_KMAJ>(pa, g.lda, ra);
+            else
+                load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, t, ra);
+            if (b_fast && kfull)
+                load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+            else
+                load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, t, rb);
         }
         const double* As = lds + cur * 2 * TILE_ELEMS;
         const double* Bs = As + TILE_ELEMS;
@@ -174,20 +212,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
     }
 
     // epilogue: accumulator register r of tile (nt, mt) holds D[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
+    //
+    // D may alias Cin, so the compiler must keep every Cin load behind the preceding D stores; a naive
+    // load-modify-store loop therefore pays one full memory round trip per element (64 per lane).  The loads
+    // of a whole 16-column strip are issued back to back into registers, one strip ahead of the stores.
     const bool use_c = g.beta != 0.0;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    double cv[2][16];
+    auto load_strip = [&](int nt, double (&c)[16]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t n = n0 + wn * 64 + nt * 16 + lq + 4 * r;
-            if (n >= g.N) continue;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int64_t m = m0 + wm * 64 + mt * 16 + l15;
-                if (m >= g.M) continue;
+                c[r * 4 + mt] = (n < g.N && m < g.M) ? g.Cin[m + n * g.ldcin] : 0.0;
+            }
+        }
+    };
+    if (use_c) load_strip(0, cv[0]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        if (use_c && nt + 1 < 4) load_strip(nt + 1, cv[(nt + 1) & 1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t n = n0 + wn * 64 + nt * 16 + lq + 4 * r;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int64_t m = m0 + wm * 64 + mt * 16 + l15;
                 double v = g.alpha * acc[nt][mt][r];
-                if (use_c) v += g.beta * g.Cin[m + n * g.ldcin];
-                g.D[m + n * g.ldd] = v;
+                if (use_c) v += g.beta * cv[nt & 1][r * 4 + mt];
+                if (n < g.N && m < g.M) g.D[m + n * g.ldd] = v;
             }
         }
     }
@@ -228,13 +282,13 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
     ProfScope ps(ctx, d.prof_cls, flops, bytes);
     dim3 grid((unsigned)ntiles), block(256);
     if (!d.a_kmajor && !d.b_kmajor)
-        hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, ctx->stream, g);
+        hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && d.b_kmajor)
-        hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, ctx->stream, g);
+        hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, ctx->ls, g);
     else if (d.a_kmajor && d.b_kmajor)
-        hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, ctx->stream, g);
+        hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, ctx->ls, g);
     else
-        hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, ctx->stream, g);
+        hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, ctx->ls, g);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

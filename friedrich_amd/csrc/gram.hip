@@ -246,11 +246,11 @@ static int launch_gram(fr_ctx* ctx, const GramArgs& a, int64_t nblocks, int need
     ProfScope ps(ctx, FR_PROF_GRAM, pairs * (3.0 * (double)a.d + 20.0), pairs * 8.0);
     dim3 grid((unsigned)nblocks), block(256);
     if (needs == NEED_S)
-        hipLaunchKernelGGL(gram_kernel<NEED_S>, grid, block, 0, ctx->stream, a);
+        hipLaunchKernelGGL(gram_kernel<NEED_S>, grid, block, 0, ctx->ls, a);
     else if (needs == NEED_U)
-        hipLaunchKernelGGL(gram_kernel<NEED_U>, grid, block, 0, ctx->stream, a);
+        hipLaunchKernelGGL(gram_kernel<NEED_U>, grid, block, 0, ctx->ls, a);
     else
-        hipLaunchKernelGGL(gram_kernel<NEED_S | NEED_U>, grid, block, 0, ctx->stream, a);
+        hipLaunchKernelGGL(gram_kernel<NEED_S | NEED_U>, grid, block, 0, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
@@ -304,7 +304,7 @@ int launch_gram_diag(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t
 {
     if (n == 0) return FR_OK;
     ProfScope ps(ctx, FR_PROF_GRAM, 0.0, (double)n * 8.0);
-    hipLaunchKernelGGL(gram_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, prog, X, n, ldx,
+    hipLaunchKernelGGL(gram_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->ls, prog, X, n, ldx,
                        d, add, out);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
@@ -320,9 +320,9 @@ int launch_pairwise_distance_sum(fr_ctx* ctx, const double* X, int64_t n, int64_
     const double npairs = (double)((n * n - n) / 2);  // kernel.rs:108-109
     {
         ProfScope ps(ctx, FR_PROF_GRAM, npairs * (3.0 * (double)d + 10.0), (double)n * (double)d * 8.0);
-        hipLaunchKernelGGL(pairdist_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, X, n, ldx, d, partials);
+        hipLaunchKernelGGL(pairdist_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->ls, X, n, ldx, d, partials);
         FR_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)partials, nblocks,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, ctx->ls, (const double*)partials, nblocks,
                            1.0 / npairs, out_dev);
         FR_HIP(ctx, hipGetLastError());
     }

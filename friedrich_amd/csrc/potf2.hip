@@ -93,7 +93,7 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
     if (nbk <= 0) return FR_OK;
     if (nbk > PB) return set_err(ctx, FR_INVALID_ARGUMENT, "potf2 block too large");
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, (int)nbk, col0, mode, sub, inv, ldinv,
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv,
                        info);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;

@@ -119,7 +119,7 @@ int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, 
     if (rows <= 0 || cols <= 0) return FR_OK;
     for (int64_t c0 = 0; c0 < cols; c0 += 65535) {
         const int64_t cc = (cols - c0) < 65535 ? (cols - c0) : 65535;
-        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)cc), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)cc), dim3(256), 0, ctx->ls,
                            p + c0 * ld, rows, cc, ld, v);
     }
     FR_HIP(ctx, hipGetLastError());
@@ -129,7 +129,7 @@ int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, 
 int launch_copy(fr_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols)
 {
     if (rows <= 0 || cols <= 0) return FR_OK;
-    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((rows + 255) / 256), ydim(cols)), dim3(256), 0, ctx->stream, src,
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((rows + 255) / 256), ydim(cols)), dim3(256), 0, ctx->ls, src,
                        lds, dst, ldd, rows, cols);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
@@ -138,7 +138,7 @@ int launch_copy(fr_ctx* ctx, const double* src, int64_t lds, double* dst, int64_
 int launch_set_identity(fr_ctx* ctx, double* p, int64_t n, int64_t ld)
 {
     if (n <= 0) return FR_OK;
-    hipLaunchKernelGGL(identity_kernel, dim3((unsigned)((n + 255) / 256), ydim(n)), dim3(256), 0, ctx->stream, p, n, ld);
+    hipLaunchKernelGGL(identity_kernel, dim3((unsigned)((n + 255) / 256), ydim(n)), dim3(256), 0, ctx->ls, p, n, ld);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
@@ -146,7 +146,7 @@ int launch_set_identity(fr_ctx* ctx, double* p, int64_t n, int64_t ld)
 int launch_tri_fill(fr_ctx* ctx, double* p, int64_t n, int64_t ld, double v)
 {
     if (n <= 0) return FR_OK;
-    hipLaunchKernelGGL(tri_fill_kernel, dim3((unsigned)((n + 255) / 256), ydim(n)), dim3(256), 0, ctx->stream, p, n, ld,
+    hipLaunchKernelGGL(tri_fill_kernel, dim3((unsigned)((n + 255) / 256), ydim(n)), dim3(256), 0, ctx->ls, p, n, ld,
                        v);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
@@ -157,7 +157,7 @@ int launch_symmetrize(fr_ctx* ctx, double* p, int64_t n, int64_t ld)
     if (n <= 0) return FR_OK;
     const int64_t nbk = (n + 63) / 64;
     if (nbk > 65535) return set_err(ctx, FR_INVALID_ARGUMENT, "matrix too large to symmetrize");
-    hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)nbk, (unsigned)nbk), dim3(256), 0, ctx->stream, p, n, ld);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)nbk, (unsigned)nbk), dim3(256), 0, ctx->ls, p, n, ld);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
@@ -167,7 +167,7 @@ int launch_col_dot(fr_ctx* ctx, const double* U, int64_t ldu, const double* V, i
 {
     if (m <= 0) return FR_OK;
     ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)n * m, 8.0 * (double)n * m * (U == V ? 1.0 : 2.0));
-    hipLaunchKernelGGL(col_dot_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, U, ldu, V, ldv, n, out);
+    hipLaunchKernelGGL(col_dot_kernel, dim3((unsigned)m), dim3(256), 0, ctx->ls, U, ldu, V, ldv, n, out);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
@@ -182,7 +182,7 @@ int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ld
 {
     if (m <= 0) return FR_OK;
     ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)n * m, 8.0 * (double)n * m);
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, V, n, ldv, y, alpha, beta, out);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)m), dim3(256), 0, ctx->ls, V, n, ldv, y, alpha, beta, out);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
@@ -190,7 +190,7 @@ int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ld
 int launch_axpby_vec(fr_ctx* ctx, int64_t n, double a, const double* x, double b, double* y)
 {
     if (n <= 0) return FR_OK;
-    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, a, x, b, y);
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->ls, n, a, x, b, y);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
@@ -198,14 +198,14 @@ int launch_axpby_vec(fr_ctx* ctx, int64_t n, double a, const double* x, double b
 int launch_diag_check_zero(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t* flag)
 {
     if (n <= 0) return FR_OK;
-    hipLaunchKernelGGL(diag_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, n, lda, flag);
+    hipLaunchKernelGGL(diag_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->ls, A, n, lda, flag);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
 
 int launch_sum_log_abs(fr_ctx* ctx, const double* v, int64_t n, double* out)
 {
-    hipLaunchKernelGGL(sum_log_abs_kernel, dim3(1), dim3(256), 0, ctx->stream, v, n, out);
+    hipLaunchKernelGGL(sum_log_abs_kernel, dim3(1), dim3(256), 0, ctx->ls, v, n, out);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
