@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- GP fit + predict on synthetic N x d f64 data through the C ABI (libfriedrich_amd.so).
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+    fit      Gram assembly (lower + noise^2) + blocked Cholesky      fr_chol_refactor   (algebra/mod.rs:59-92)
+    predict  cross-Gram + K^-1 K* solve + mean epilogue, m queries   fr_predict_mean    (mod.rs:226-244)
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on; it fits one MI355X):
+N = 32768, d = 16, RBF kernel with friedrich's default hyper-parameters, m = 4096 query rows.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 3 --warmup 1
+
+N > 1: one process per GPU.  The factorisation is sharded (block-cyclic column panels, RCCL panel broadcast
+over xGMI, every rank ends with the full factor); the m query rows are split across ranks.  Total work is
+fixed => "scaling": "strong".  Inputs (X, y, X*) are resident in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the FP64-MFMA trailing SYRK update) with
+HIP events recorded inside the library on the stream the kernel runs on; `cpu_baseline` times the CPU oracle
+(oracle/, the restatement of the reference's nalgebra path) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; scripts/mfma_f64_peak measures 77.0-77.6 on the box
+
+
+def flops_fit(n, d):
+    return n ** 3 / 3.0 + 0.5 * n * (n + 1) * (3.0 * d + 20.0)
+
+
+def flops_predict(n, m, d):
+    return n * m * (3.0 * d + 20.0) + 2.0 * n * n * m + 2.0 * n * m
+
+
+def cpu_baseline(n, d, m, cfg):
+    """The reference's CPU path (oracle restatement, one thread) on a bounded sample of the workload."""
+    from friedrich_amd import synth
+    from oracle import oracle as O
+
+    X, y, Xq = synth.make_problem(n, d, cfg=cfg, m=m)
+    ls = O.fit_bandwidth_mean(X[:1024])  # heuristic on a sub-sample: only conditions the sample problem
+    hp = synth.default_hyperparameters(X, y, ls)
+    k = ("squared_exp", hp["ls"], hp["ampl"])
+    t0 = time.perf_counter()
+    gp = O.OracleGP(O.ConstantPrior(hp["prior"]), k, hp["noise"], None, X, y)
+    t1 = time.perf_counter()
+    gp.predict(Xq)
+    t2 = time.perf_counter()
+    fl = flops_fit(n, d) + flops_predict(n, m, d)
+    return {
+        "value": fl / (t2 - t0) / 1e9,
+        "unit": "GFLOP/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"N={n} d={d} m={m} same generator/kernel, oracle fit {t1 - t0:.1f}s + predict {t2 - t1:.1f}s, 1 thread",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--d", type=int, default=16)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--nb", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=6144)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+
+    from friedrich_amd import synth
+    from friedrich_amd.device import Context
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    ctx = Context(local_rank)
+    ctx.set_option("nb", args.nb)
+    if world > 1:
+        ids = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(rank, world, ids[0])
+
+    n, d, m = args.n, args.d, args.m
+    cfg = 4
+    X, y, Xq = synth.make_problem(n, d, cfg=cfg, m=m)
+    # friedrich's builder defaults (builder.rs:73, kernel.rs:594-600); the bandwidth heuristic itself runs on the GPU
+    ls = ctx.mean_pairwise_distance(X)
+    hp = synth.default_hyperparameters(X, y, ls)
+    kernel = ("squared_exp", hp["ls"], hp["ampl"])
+    noise = hp["noise"]
+
+    # query rows are sharded across ranks; everything the timed region touches is resident in HBM
+    lo, hi = (m * rank) // world, (m * (rank + 1)) // world
+    m_loc = hi - lo
+    Xq_d = torch.from_numpy(np.ascontiguousarray(Xq[lo:hi].T)).to(dev).t() if m_loc > 0 else torch.empty((0, d), dtype=torch.float64, device=dev)
+    y_d = torch.from_numpy(y - hp["prior"]).to(dev)
+    prior_d = torch.full((m_loc,), hp["prior"], dtype=torch.float64, device=dev)
+    mean_d = torch.empty((m_loc,), dtype=torch.float64, device=dev)
+    X_d = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev).t()
+    chol = ctx.cholesky_from_inputs(kernel, X_d, noise, capacity_hint=n)  # allocates + first (untimed) factorisation
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    fit_ms, pred_ms = [], []
+
+    def step(record):
+        t0 = time.perf_counter()
+        chol.refactor(kernel, noise)  # Gram + Cholesky (host returns after the status read-back)
+        t1 = time.perf_counter()
+        if m_loc > 0:
+            chol.predict_mean(kernel, y_d, Xq_d, prior_d, out=mean_d)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        if record:
+            fit_ms.append(1e3 * (t1 - t0))
+            pred_ms.append(1e3 * (t2 - t1))
+
+    for _ in range(args.warmup):
+        step(False)
+    ctx.profile_reset()
+    ctx.profile_enable(True, classes=["syrk"])
+    sync()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync()
+    elapsed = time.perf_counter() - t_start
+    prof = ctx.profile()
+    ctx.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    info = chol.info()
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        total_flops = flops_fit(n, d) + flops_predict(n, m, d)
+        syrk = prof["syrk"]
+        achieved = syrk["flops"] / max(syrk["ms"], 1e-9) / 1e9  # TFLOP/s
+        out = {
+            "metric": "gp_fit_predict_gflops",
+            "value": total_flops / (ms_per_step * 1e-3) / 1e9,
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"GP fit (Gram + Cholesky) + predict, N={n} d={d} RBF, m={m} queries, friedrich default hyper-parameters",
+                "n": n, "d": d, "m": m, "kernel": "squared_exp", "nb": args.nb,
+                "parallelism": "1 GPU" if world == 1 else f"block-cyclic column panels over {world} GPUs (RCCL broadcast), queries sharded",
+            },
+            "fit_ms": float(np.mean(fit_ms)),
+            "predict_ms": float(np.mean(pred_ms)),
+            "cholesky_tflops": (n ** 3 / 3.0) / (np.mean(fit_ms) * 1e-3) / 1e12,
+            "n_substitutions": info["n_subst"],
+            "roofline": {
+                "kernel": "gemm_f64_kernel<false,false> (trailing SYRK update, v_mfma_f64_16x16x4_f64)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F64_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F64_MFMA_TFLOPS,
+                "traffic": None,
+                "launches": syrk["launches"],
+                "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
+                "flops_per_launch": syrk["flops"] / max(syrk["launches"], 1),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, d, 256, cfg)
+        print(json.dumps(out), flush=True)
+
+    chol.free()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,7 @@ struct fr_ctx {
     int64_t gemm_tile = 0;  // reserved
     // profiling
     bool prof = false;
+    unsigned prof_mask = ~0u;
     std::vector<fr::ProfRec> recs;
     std::vector<hipEvent_t> free_events;
     double prof_ms[FR_PROF_COUNT] = {0};

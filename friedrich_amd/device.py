@@ -116,8 +116,14 @@ class Context:
         self.check(self.lib.fr_ctx_synchronize(self.h))
 
     # profiling ------------------------------------------------------------------------------------
-    def profile_enable(self, on=True):
-        self.check(self.lib.fr_ctx_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, on=True, classes=None):
+        """classes: iterable of class names (see _capi.PROF_NAMES) to time; None = all"""
+        flag = 1 if on else 0
+        if on and classes is not None:
+            flag = 0
+            for name in classes:
+                flag |= 1 << (C.PROF_NAMES.index(name) + 1)
+        self.check(self.lib.fr_ctx_profile_enable(self.h, flag))
 
     def profile_reset(self):
         self.check(self.lib.fr_ctx_profile_reset(self.h))

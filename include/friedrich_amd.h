@@ -105,6 +105,7 @@ typedef enum {
     FR_PROF_COMM = 6,      /* RCCL collectives */
     FR_PROF_COUNT = 7
 } fr_prof_class;
+/* enable: 0 = off, 1 = every class, otherwise a mask with bit (class + 1) set for each class to time */
 int fr_ctx_profile_enable(fr_ctx* ctx, int enable);
 int fr_ctx_profile_reset(fr_ctx* ctx);
 /* total milliseconds, launch count, and algorithmic flops / bytes accumulated for one class */
