@@ -18,6 +18,8 @@
 //   nb   (default 256) outer block: the trailing update A22 -= P P^T is one lower-triangular SYRK launch with
 //        K = nb, the dominant FP64-MFMA kernel (n^3/3 of the flops).
 #include "fr_internal.hpp"
+#include <algorithm>
+
 #include "kprog_device.hpp"
 
 namespace fr {
@@ -118,6 +120,30 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
     return FR_OK;
 }
 
+// Multi-GPU: block column b (width nb) of the matrix being factored is owned by rank b % world.
+static inline int owner_of(int64_t col, int64_t nb, int world) { return (int)((col / nb) % world); }
+
+// Replicate the factored panel (rows k..n of block column k, plus its inverse blocks) from its owner to every rank:
+// pack -> one broadcast over xGMI -> unpack.  Enqueued on ctx->ls by every rank in the same order.
+static int exchange_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, double* dinv, double* buf,
+                          int owner)
+{
+    const int64_t rows = n - k;
+    const int64_t nblk = (kb + IB - 1) / IB;
+    double* tail = buf + rows * kb;
+    double* dblk = dinv + (k / IB) * INV_ELEMS;
+    if (ctx->rank == owner) {
+        FR_TRY(launch_copy(ctx, A + k + k * ld, ld, buf, rows, rows, kb));
+        FR_HIP(ctx, hipMemcpyAsync(tail, dblk, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, ctx->ls));
+    }
+    FR_TRY(comm_bcast(ctx, buf, (size_t)(rows * kb + nblk * INV_ELEMS), owner));
+    if (ctx->rank != owner) {
+        FR_TRY(launch_copy(ctx, buf, rows, A + k + k * ld, ld, rows, kb));
+        FR_HIP(ctx, hipMemcpyAsync(dblk, tail, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, ctx->ls));
+    }
+    return FR_OK;
+}
+
 // In-place blocked Cholesky of the n x n lower triangle at A.  dinv receives the inverses of the diagonal
 // 128-blocks (block i of this sub-matrix at dinv + i*INV_ELEMS).
 //
@@ -125,14 +151,22 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
 // serialise with the big trailing SYRK.  Step k's trailing update is therefore split: the next panel's nb columns
 // are updated first, then that panel is factored on a second, high-priority HIP stream while the main stream
 // updates the rest of the trailing matrix (K6).  The two streams touch disjoint columns; events order them.
+//
+// dist (and ctx->world > 1): the block columns are dealt round-robin to the ranks.  Only the owner factors a panel;
+// the panel then travels to every rank with one broadcast on the panel stream (so it overlaps the trailing updates
+// still running on the main stream), and every rank updates only the trailing block columns it owns.  Because every
+// panel is broadcast, each rank ends up holding the complete factor -- no final all-gather is needed.
 static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
-                         int64_t* info, int64_t nb)
+                         int64_t* info, int64_t nb, bool dist = false)
 {
     if (n <= 0) return FR_OK;
-    WsGuard tg(ctx);
+    WsGuard tg(ctx), pg(ctx);
     double* T = tg.get(sizeof(double) * 64 * 64);
     if (!T) return FR_OUT_OF_MEMORY;
-    const bool la = ctx->lookahead && ctx->stream2 && n > 2 * nb && ctx->ls == ctx->stream;
+    const int world = dist ? ctx->world : 1;
+    const int rank = ctx->rank;
+    if (world > 1 && nb % IB != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "multi-GPU factorisation needs nb %% 128 == 0");
+    const bool la = (world > 1) || (ctx->lookahead && ctx->stream2 && n > 2 * nb && ctx->ls == ctx->stream);
     if (!la) {
         for (int64_t k = 0; k < n; k += nb) {
             const int64_t kb = imin(nb, n - k);
@@ -147,6 +181,11 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         }
         return FR_OK;
     }
+    double* pbuf = nullptr;
+    if (world > 1) {
+        pbuf = pg.get(sizeof(double) * (size_t)(n * imin(nb, n) + ((nb + IB - 1) / IB) * INV_ELEMS));
+        if (!pbuf) return FR_OUT_OF_MEMORY;
+    }
     hipStream_t S0 = ctx->stream, S1 = ctx->stream2;
     int st = FR_OK;
     auto fail = [&](int code) {
@@ -158,8 +197,12 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     FR_HIP(ctx, hipEventRecord(ctx->ev_la, S0));
     FR_HIP(ctx, hipStreamWaitEvent(S1, ctx->ev_la, 0));
     ctx->ls = S1;
-    st = factor_panel(ctx, A, ld, n, 0, imin(nb, n), col0, mode, sub, dinv, info, T);
-    if (st != FR_OK) return fail(st);
+    {
+        const int64_t kb0 = imin(nb, n);
+        if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T);
+        if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
+        if (st != FR_OK) return fail(st);
+    }
     if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
     for (int64_t k = 0; k < n; k += nb) {
         const int64_t kb = imin(nb, n - k);
@@ -169,22 +212,34 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         if (rest <= 0) break;
         const int64_t kb2 = imin(nb, rest);
         const double* P = A + (k + kb) + k * ld;
+        const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
-        st = gemm(ctx, FR_PROF_SYRK, rest, kb2, kb, P, ld, false, P, ld, false, -1.0, 1.0, A + (k + kb) + (k + kb) * ld, ld);
-        if (st != FR_OK) return fail(st);
+        if (own_next) {
+            st = gemm(ctx, FR_PROF_SYRK, rest, kb2, kb, P, ld, false, P, ld, false, -1.0, 1.0, A + (k + kb) + (k + kb) * ld,
+                      ld);
+            if (st != FR_OK) return fail(st);
+        }
         if (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess)
             return fail(FR_HIP_ERROR);
         ctx->ls = S1;
-        st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T);
+        if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T);
+        if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
         if (st != FR_OK) return fail(st);
         if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
         ctx->ls = S0;
         const int64_t rest2 = rest - kb2;
         if (rest2 > 0) {
-            // K6: the rest of the trailing update runs under the next panel
+            // K6: the rest of the trailing update runs under the next panel; multi-GPU: owned block columns only
             const double* P2 = P + kb2;
-            st = gemm(ctx, FR_PROF_SYRK, rest2, rest2, kb, P2, ld, false, P2, ld, false, -1.0, 1.0,
-                      A + (k + kb + kb2) + (k + kb + kb2) * ld, ld, true);
+            GemmDesc g;
+            g.M = rest2; g.N = rest2; g.K = kb;
+            g.A = P2; g.lda = ld; g.a_kmajor = false;
+            g.B = P2; g.ldb = ld; g.b_kmajor = false;
+            g.D = A + (k + kb + kb2) + (k + kb + kb2) * ld; g.ldd = ld;
+            g.Cin = g.D; g.ldcin = ld;
+            g.alpha = -1.0; g.beta = 1.0; g.lower = true; g.prof_cls = FR_PROF_SYRK;
+            g.own_world = world; g.own_rank = rank; g.own_nb = nb; g.own_col0 = k + kb + kb2;
+            st = launch_gemm(ctx, g);
             if (st != FR_OK) return fail(st);
         }
     }
@@ -308,6 +363,33 @@ int chol_fetch_info(fr_chol* c)
     return FR_OK;
 }
 
+// Multi-GPU: every rank logged only the pivots of the panels it owned; gather and merge the logs on the host.
+static int merge_info(fr_chol* c)
+{
+    fr_ctx* ctx = c->ctx;
+    const int W = ctx->world;
+    const int64_t len = 3 + c->n;
+    WsGuard g(ctx);
+    int64_t* all = (int64_t*)g.get(sizeof(int64_t) * (size_t)(len * W));
+    if (!all) return FR_OUT_OF_MEMORY;
+    FR_TRY(comm_allgather_i64(ctx, c->info, all, (size_t)len));
+    std::vector<int64_t> host((size_t)(len * W));
+    FR_HIP(ctx, hipMemcpyAsync(host.data(), all, sizeof(int64_t) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t fail = -1;
+    std::vector<int64_t> subst;
+    for (int r = 0; r < W; ++r) {
+        const int64_t* h = host.data() + (size_t)r * len;
+        if (h[0] > 0 && (fail < 0 || h[0] - 1 < fail)) fail = h[0] - 1;
+        for (int64_t i = 0; i < h[1] && i < c->n; ++i) subst.push_back(h[3 + i]);
+    }
+    std::sort(subst.begin(), subst.end());
+    c->fail_col = fail;
+    c->n_subst = (int64_t)subst.size();
+    c->subst = subst;
+    return FR_OK;
+}
+
 int potrf_device(fr_ctx* ctx, fr_chol* c, int64_t j0, int64_t n, int mode, double sub)
 {
     return potrf_blocked(ctx, c->A + j0 + j0 * c->ld_a, c->ld_a, n, j0, mode, sub, c->dinv + (j0 / IB) * INV_ELEMS, c->info,
@@ -338,9 +420,11 @@ static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise,
 {
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
-    FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a));
-    FR_TRY(potrf_device(ctx, c, 0, c->n, has_eps ? 1 : 0, eps));
+    FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank,
+                           c->nb));
+    FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true));
     FR_TRY(chol_fetch_info(c));
+    if (ctx->world > 1) FR_TRY(merge_info(c));
     if (c->fail_col >= 0)
         return set_err(ctx, FR_NOT_POSITIVE_DEFINITE,
                        has_eps ? "Cholesky decomposition failed even though we used `cholesky_epsilon` value of %g (column %lld)"

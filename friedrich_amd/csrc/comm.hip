@@ -1,8 +1,20 @@
-// comm.hip -- RCCL plumbing (one process per GPU; collectives over xGMI).  librccl is loaded lazily with
-// dlopen so single-GPU users never pay for it; there is no other transport.
+// comm.hip -- collectives of the sharded Cholesky.
+//
+// Transport 1 (production): RCCL over xGMI, one process per GPU.  librccl is loaded lazily with dlopen so
+// single-GPU users never pay for it; the RCCL build has to match the process's HIP runtime (torch bundles its
+// own pair), so the host may name it through FRIEDRICH_AMD_RCCL_PATH.
+// Transport 2 ("local"): the ranks are host threads of ONE process that share a device; a broadcast is a
+// device-to-device copy between the ranks' buffers, synchronised with a host barrier.  It exists so the sharded
+// code path (ownership maps, panel pack/broadcast/unpack, stream ordering, info merge) can be exercised on a
+// 1-GPU box; it is not a performance path.
 #include <dlfcn.h>
-#include <cstdlib>
 #include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "fr_internal.hpp"
 
@@ -15,7 +27,6 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -24,7 +35,6 @@ static RcclApi g_rccl;
 static int rccl_load(fr_ctx* ctx)
 {
     if (g_rccl.handle) return FR_OK;
-    // The RCCL build must match the process's HIP runtime (torch bundles its own pair): the host names it.
     void* h = nullptr;
     if (const char* p = getenv("FRIEDRICH_AMD_RCCL_PATH")) h = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // already loaded (e.g. by torch)
@@ -32,50 +42,141 @@ static int rccl_load(fr_ctx* ctx)
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return set_err(ctx, FR_RCCL_ERROR, "cannot load librccl: %s", dlerror());
-#define LOAD(name)                                                               \
-    g_rccl.name = (decltype(g_rccl.name))dlsym(h, "nccl" #name);                 \
+#define LOAD(name)                                               \
+    g_rccl.name = (decltype(g_rccl.name))dlsym(h, "nccl" #name); \
     if (!g_rccl.name) return set_err(ctx, FR_RCCL_ERROR, "librccl lacks nccl" #name)
     LOAD(GetUniqueId);
     LOAD(CommInitRank);
     LOAD(CommDestroy);
     LOAD(Broadcast);
     LOAD(AllGather);
-    LOAD(AllReduce);
     LOAD(GetErrorString);
 #undef LOAD
     g_rccl.handle = h;
     return FR_OK;
 }
 
-#define FR_NCCL(ctx, call)                                                                                   \
-    do {                                                                                                     \
-        ncclResult_t r__ = (call);                                                                           \
-        if (r__ != ncclSuccess)                                                                              \
-            return set_err((ctx), FR_RCCL_ERROR, "%s failed: %s", #call, g_rccl.GetErrorString(r__));       \
+#define FR_NCCL(ctx, call)                                                                            \
+    do {                                                                                              \
+        ncclResult_t r__ = (call);                                                                    \
+        if (r__ != ncclSuccess)                                                                       \
+            return set_err((ctx), FR_RCCL_ERROR, "%s failed: %s", #call, g_rccl.GetErrorString(r__)); \
     } while (0)
 
+// ---- local transport ---------------------------------------------------------------------------------
+struct LocalGroup {
+    int world = 0;
+    int attached = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    const void* ptrs[2][64] = {{nullptr}};  // double-buffered by barrier generation parity
+    bool broken = false;
+};
+struct LocalComm {
+    LocalGroup* g;
+    int group_id;
+};
+
+static std::mutex g_local_mutex;
+static std::map<int, LocalGroup*> g_local_groups;
+
+// host barrier; every rank publishes one pointer first and gets a snapshot of all of them (taken from the slot of
+// THIS barrier generation: a fast rank entering the next barrier writes the other slot).  false on timeout.
+static bool local_barrier(LocalGroup* g, int rank, const void* publish, const void** snapshot = nullptr)
+{
+    std::unique_lock<std::mutex> lk(g->m);
+    if (g->broken) return false;
+    const uint64_t my_gen = g->gen;
+    const void** slot = g->ptrs[my_gen & 1];
+    slot[rank] = publish;
+    struct Snap {
+        const void** dst;
+        const void** src;
+        int n;
+        ~Snap()
+        {
+            if (dst)
+                for (int i = 0; i < n; ++i) dst[i] = src[i];
+        }
+    } snap{snapshot, slot, g->world};
+    if (++g->arrived == g->world) {
+        g->arrived = 0;
+        ++g->gen;
+        g->cv.notify_all();
+        return true;
+    }
+    const bool ok = g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->gen != my_gen || g->broken; });
+    if (!ok || g->broken) {
+        g->broken = true;
+        g->cv.notify_all();
+        return false;
+    }
+    return true;
+}
+
+static int local_bcast(fr_ctx* ctx, void* buf, size_t bytes, int root)
+{
+    LocalGroup* g = ((LocalComm*)ctx->local)->g;
+    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    const void* all[64];
+    if (!local_barrier(g, ctx->rank, buf, all)) return set_err(ctx, FR_RCCL_ERROR, "local broadcast: barrier timed out");
+    const void* src = all[root];
+    if (ctx->rank != root && bytes > 0) {
+        FR_HIP(ctx, hipMemcpyAsync(buf, src, bytes, hipMemcpyDeviceToDevice, ctx->ls));
+        FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    }
+    if (!local_barrier(g, ctx->rank, nullptr)) return set_err(ctx, FR_RCCL_ERROR, "local broadcast: barrier timed out");
+    return FR_OK;
+}
+
+static int local_allgather(fr_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank)
+{
+    LocalGroup* g = ((LocalComm*)ctx->local)->g;
+    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    const void* srcs[64];
+    if (!local_barrier(g, ctx->rank, send, srcs)) return set_err(ctx, FR_RCCL_ERROR, "local allgather: barrier timed out");
+    for (int r = 0; r < g->world; ++r)
+        if (bytes_per_rank > 0)
+            FR_HIP(ctx, hipMemcpyAsync((char*)recv + (size_t)r * bytes_per_rank, srcs[r], bytes_per_rank,
+                                       hipMemcpyDeviceToDevice, ctx->ls));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    if (!local_barrier(g, ctx->rank, nullptr)) return set_err(ctx, FR_RCCL_ERROR, "local allgather: barrier timed out");
+    return FR_OK;
+}
+
+// ---- dispatch ----------------------------------------------------------------------------------------
 int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root)
 {
     if (ctx->world <= 1) return FR_OK;
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count);
+    if (ctx->local) return local_bcast(ctx, buf, 8 * count, root);
     FR_NCCL(ctx, g_rccl.Broadcast(buf, buf, count, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
 
-int comm_bcast_i64(fr_ctx* ctx, int64_t* buf, size_t count, int root)
+int comm_allgather_i64(fr_ctx* ctx, const int64_t* send, int64_t* recv, size_t count_per_rank)
 {
-    if (ctx->world <= 1) return FR_OK;
-    FR_NCCL(ctx, g_rccl.Broadcast(buf, buf, count, ncclInt64, root, (ncclComm_t)ctx->comm, ctx->ls));
+    if (ctx->world <= 1) {
+        if (send != recv)
+            FR_HIP(ctx, hipMemcpyAsync(recv, send, 8 * count_per_rank, hipMemcpyDeviceToDevice, ctx->ls));
+        return FR_OK;
+    }
+    if (ctx->local) return local_allgather(ctx, send, recv, 8 * count_per_rank);
+    FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclInt64, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
 
 int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_per_rank)
 {
     if (ctx->world <= 1) {
-        if (send != recv) FR_HIP(ctx, hipMemcpyAsync(recv, send, 8 * count_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
+        if (send != recv)
+            FR_HIP(ctx, hipMemcpyAsync(recv, send, 8 * count_per_rank, hipMemcpyDeviceToDevice, ctx->ls));
         return FR_OK;
     }
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count_per_rank * ctx->world);
+    if (ctx->local) return local_allgather(ctx, send, recv, 8 * count_per_rank);
     FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
@@ -91,6 +192,18 @@ void fr_comm_destroy_internal(fr_ctx* ctx)
     if (ctx->comm && g_rccl.CommDestroy) {
         g_rccl.CommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
+    }
+    if (ctx->local) {
+        LocalComm* lc = (LocalComm*)ctx->local;
+        {
+            std::lock_guard<std::mutex> lk(g_local_mutex);
+            if (--lc->g->attached == 0) {
+                g_local_groups.erase(lc->group_id);
+                delete lc->g;
+            }
+        }
+        delete lc;
+        ctx->local = nullptr;
     }
 }
 
@@ -109,9 +222,12 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
 {
     if (!ctx || world_size < 1 || rank < 0 || rank >= world_size) return FR_INVALID_ARGUMENT;
     FR_HIP(ctx, hipSetDevice(ctx->device));
-    ctx->rank = rank;
-    ctx->world = world_size;
-    if (world_size == 1) return FR_OK;
+    if (ctx->comm || ctx->local) return set_err(ctx, FR_INVALID_ARGUMENT, "communicator already initialised");
+    if (world_size == 1 && !unique_id) {
+        ctx->rank = 0;
+        ctx->world = 1;
+        return FR_OK;
+    }
     if (!unique_id) return FR_INVALID_ARGUMENT;
     FR_TRY(rccl_load(ctx));
     ncclUniqueId id;
@@ -119,6 +235,29 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
     ncclComm_t comm = nullptr;
     FR_NCCL(ctx, g_rccl.CommInitRank(&comm, world_size, id, rank));
     ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->world = world_size;
+    return FR_OK;
+}
+
+int fr_ctx_comm_init_local(fr_ctx* ctx, int group_id, int rank, int world_size)
+{
+    if (!ctx || world_size < 1 || world_size > 64 || rank < 0 || rank >= world_size) return FR_INVALID_ARGUMENT;
+    if (ctx->comm || ctx->local) return set_err(ctx, FR_INVALID_ARGUMENT, "communicator already initialised");
+    std::lock_guard<std::mutex> lk(g_local_mutex);
+    LocalGroup*& g = g_local_groups[group_id];
+    if (!g) {
+        g = new LocalGroup();
+        g->world = world_size;
+    }
+    if (g->world != world_size) return set_err(ctx, FR_INVALID_ARGUMENT, "local group %d has world size %d", group_id, g->world);
+    g->attached += 1;
+    LocalComm* lc = new LocalComm();
+    lc->g = g;
+    lc->group_id = group_id;
+    ctx->local = lc;
+    ctx->rank = rank;
+    ctx->world = world_size;
     return FR_OK;
 }
 

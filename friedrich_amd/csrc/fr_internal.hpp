@@ -56,7 +56,8 @@ struct fr_ctx {
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
     // RCCL
-    void* comm = nullptr;  // ncclComm_t
+    void* comm = nullptr;   // ncclComm_t
+    void* local = nullptr;  // in-process ("local") communicator: ranks are host threads sharing one device
     int rank = 0;
     int world = 1;
 };
@@ -167,8 +168,9 @@ struct ProfScope {
 int launch_gram_cross(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_t n1, int64_t lda, const double* B,
                       int64_t n2, int64_t ldb, int64_t d, double* out, int64_t ldo);
 // lower triangle (full 128x128 diagonal tiles) + noise^2 on the diagonal, rows/cols [r0, n) x [c0, n)
+// own_world > 1: only the block columns (width own_nb) owned by own_rank are assembled
 int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,
-                    double noise2, double* out, int64_t ldo);
+                    double noise2, double* out, int64_t ldo, int own_world = 1, int own_rank = 0, int64_t own_nb = 1);
 // out[i] = k(x_i, x_i) (+ add)
 int launch_gram_diag(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,
                      double add, double* out);
@@ -194,6 +196,9 @@ struct GemmDesc {
     double alpha, beta;
     bool lower;
     int prof_cls;
+    // multi-GPU column-ownership filter (see gemm_f64.hip); defaults: disabled
+    int own_world = 1, own_rank = 0;
+    int64_t own_nb = 1, own_col0 = 0;
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 
@@ -217,6 +222,11 @@ int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ld
 int launch_axpby_vec(fr_ctx* ctx, int64_t n, double a, const double* x, double b, double* y);  // y = a*x + b*y
 int launch_diag_check_zero(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t* flag);
 int launch_sum_log_abs(fr_ctx* ctx, const double* v, int64_t n, double* out);
+
+// ---- collectives (comm.hip): RCCL over xGMI, or the in-process local transport; enqueue on ctx->ls ----------
+int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root);
+int comm_allgather_i64(fr_ctx* ctx, const int64_t* send, int64_t* recv, size_t count_per_rank);
+int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_per_rank);
 
 // ---- blocked algorithms (chol.hip) ------------------------------------------------------------------
 // in-place Cholesky of the lower triangle of the n x n block at A (rows/cols offset col0 for bookkeeping)

@@ -44,6 +44,10 @@ struct GemmArgs {
     double alpha, beta;
     int lower;
     int64_t tiles_m, tiles_n;
+    // multi-GPU column ownership: a tile is computed only by the rank owning its block column
+    // ((own_col0 + n0) / own_nb) % own_world == own_rank; own_world <= 1 disables the filter
+    int own_world, own_rank;
+    int64_t own_nb, own_col0;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
         tn = tlin / g.tiles_m;
     }
     const int64_t m0 = tm * BM, n0 = tn * BN;
+    if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) return;
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -265,6 +270,10 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
     g.alpha = d.alpha;
     g.beta = d.beta;
     g.lower = d.lower ? 1 : 0;
+    g.own_world = d.own_world;
+    g.own_rank = d.own_rank;
+    g.own_nb = d.own_nb > 0 ? d.own_nb : 1;
+    g.own_col0 = d.own_col0;
     g.tiles_m = (d.M + BM - 1) / BM;
     g.tiles_n = (d.N + BN - 1) / BN;
     int64_t ntiles;

@@ -30,6 +30,8 @@ struct GramArgs {
     int sym;  // 1: A == B, only tiles touching the lower triangle (by 128-blocks), + noise2 on the diagonal
     double noise2;
     int64_t tiles_n;  // cross mode: tiles along n2
+    int own_world, own_rank;  // sym mode, multi-GPU: only block columns (width own_nb) of own_rank are assembled
+    int64_t own_nb;
 };
 
 __device__ __forceinline__ void sym_tile(int64_t t, int64_t& bi, int64_t& tj)
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a)
         tj = (int64_t)blockIdx.x % a.tiles_n;
     }
     const int64_t i0 = ti * GT_M, j0 = tj * GT_N;
+    if (a.own_world > 1 && (int)((j0 / a.own_nb) % a.own_world) != a.own_rank) return;
     const int t = threadIdx.x;
     const int r = t & 63;
     const int g = t >> 6;
@@ -272,13 +275,16 @@ int launch_gram_cross(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_
     a.ldo = ldo;
     a.sym = 0;
     a.noise2 = 0.0;
+    a.own_world = 1;
+    a.own_rank = 0;
+    a.own_nb = 1;
     a.tiles_n = (n2 + GT_N - 1) / GT_N;
     const int64_t tiles_m = (n1 + GT_M - 1) / GT_M;
     return launch_gram(ctx, a, tiles_m * a.tiles_n, kprog_needs(prog), (double)n1 * (double)n2);
 }
 
 int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,
-                    double noise2, double* out, int64_t ldo)
+                    double noise2, double* out, int64_t ldo, int own_world, int own_rank, int64_t own_nb)
 {
     if (n == 0) return FR_OK;
     GramArgs a;
@@ -295,6 +301,9 @@ int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t 
     a.sym = 1;
     a.noise2 = noise2;
     a.tiles_n = 0;
+    a.own_world = own_world;
+    a.own_rank = own_rank;
+    a.own_nb = own_nb > 0 ? own_nb : 1;
     const int64_t nbk = (n + GT_M - 1) / GT_M;
     return launch_gram(ctx, a, nbk * (nbk + 1), kprog_needs(prog), 0.5 * (double)n * (double)(n + 1));
 }

@@ -149,6 +149,10 @@ class Context:
         buf = ctypes.create_string_buffer(unique_id, C.FR_COMM_ID_BYTES) if unique_id is not None else None
         self.check(self.lib.fr_ctx_comm_init(self.h, int(rank), int(world_size), buf))
 
+    def comm_init_local(self, group_id, rank, world_size):
+        """in-process transport (ranks = threads sharing one GPU); see fr_ctx_comm_init_local"""
+        self.check(self.lib.fr_ctx_comm_init_local(self.h, int(group_id), int(rank), int(world_size)))
+
     # src/algebra/mod.rs ---------------------------------------------------------------------------
     def gram(self, kernel, A, B, out=None):
         """make_covariance_matrix (algebra/mod.rs:41-54)"""

@@ -1,0 +1,37 @@
+"""Host-side description of how the hot path is sharded across the GPUs of one node (mirrors chol.hip).
+
+  * Gram + Cholesky: block column b (width nb) of the n x n matrix belongs to rank b % world (`owner_of`).  The owner
+    assembles, updates and factors it; after factoring, the panel (rows k..n of the block column plus its 128 x 128
+    inverse blocks) is broadcast to every rank, so all ranks end with the complete factor.
+  * predict family: the m query rows are split into contiguous slices (`query_slice`), no communication.
+
+`panel_schedule` enumerates, per outer step, who factors / broadcasts and which block columns each rank updates;
+tests/test_sharding_gloo.py replays it with numpy tiles over a 2-rank gloo group and bench.py uses `query_slice`.
+"""
+
+
+def owner_of(col, nb, world):
+    return (col // nb) % world
+
+
+def query_slice(m, rank, world):
+    return (m * rank) // world, (m * (rank + 1)) // world
+
+
+def panel_bytes(n, k, kb, inv_block=128):
+    """bytes one panel broadcast moves: (n-k) x kb factor rows + the inverse blocks of the kb columns"""
+    return 8 * ((n - k) * kb + ((kb + inv_block - 1) // inv_block) * inv_block * inv_block)
+
+
+def panel_schedule(n, nb, world):
+    """yield dicts {k, kb, owner, updates: {rank: [block column starts it updates with this panel]}}"""
+    k = 0
+    while k < n:
+        kb = min(nb, n - k)
+        updates = {r: [] for r in range(world)}
+        j = k + kb
+        while j < n:
+            updates[owner_of(j, nb, world)].append(j)
+            j += nb
+        yield {"k": k, "kb": kb, "owner": owner_of(k, nb, world), "updates": updates}
+        k += kb

@@ -115,6 +115,9 @@ int fr_ctx_profile_get(fr_ctx* ctx, int prof_class, double* ms, int64_t* launche
 #define FR_COMM_ID_BYTES 128
 int fr_comm_unique_id(void* out_id /* FR_COMM_ID_BYTES */);
 int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_id);
+/* In-process transport: the ranks are host threads of one process sharing a device (all contexts naming the same
+ * group_id form one communicator).  Lets the sharded path run on a 1-GPU box; not a performance path. */
+int fr_ctx_comm_init_local(fr_ctx* ctx, int group_id, int rank, int world_size);
 int fr_ctx_comm_info(const fr_ctx* ctx, int* rank, int* world_size);
 
 /* ---- src/algebra/mod.rs --------------------------------------------------------------------------- */

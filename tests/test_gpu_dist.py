@@ -1,0 +1,129 @@
+"""Sharded (multi-rank) Cholesky exercised on ONE GPU through the in-process "local" transport: every rank is a
+host thread with its own fr_ctx; panels travel by device-to-device copies instead of RCCL broadcasts.  Same code
+path as the multi-GPU run (ownership filters in the Gram / SYRK kernels, panel pack -> broadcast -> unpack on the
+panel stream, substitution-log merge); only the transport differs."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import rand_inputs, rel_err
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+_group = [1000]
+
+
+def run_ranks(world, fn):
+    from friedrich_amd.device import Context
+
+    _group[0] += 1
+    gid = _group[0]
+    results, errors = [None] * world, [None] * world
+
+    def worker(rank):
+        ctx = None
+        try:
+            ctx = Context()
+            ctx.comm_init_local(gid, rank, world)
+            results[rank] = fn(ctx, rank)
+        except BaseException as e:  # noqa: BLE001
+            errors[rank] = e
+        finally:
+            if ctx is not None:
+                ctx.close()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    for e in errors:
+        if e is not None:
+            raise e
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("n,nb", [(1500, 128), (1024, 256), (700, 128), (100, 128)])
+def test_sharded_cholesky_matches_oracle(world, n, nb):
+    k = ("matern2", 0.7, 1.2)
+    X = rand_inputs(n, 5, n)
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    Lref = np.tril(L_o)
+    B = np.asfortranarray(np.random.default_rng(1).standard_normal((n, 5)))
+    Zref = O.chol_solve(L_o, B)
+
+    def fn(ctx, rank):
+        ctx.set_option("nb", nb)
+        chol = ctx.cholesky_from_inputs(k, X, 0.1)
+        out = (chol.l(), chol.solve(B), chol.info())
+        chol.refactor(k, 0.1)  # the optimizer's re-fit takes the same sharded path
+        out = out + (chol.l(),)
+        chol.free()
+        return out
+
+    for L, Z, info, L2 in run_ranks(world, fn):
+        # every rank ends with the complete factor (each panel was broadcast) and the inverse blocks for the solves
+        assert rel_err(L, Lref) < TOL
+        assert rel_err(L2, Lref) < TOL
+        assert rel_err(Z, Zref) < TOL
+        assert info["n_subst"] == 0 and info["fail_col"] == -1
+
+
+def test_sharded_substitution_log_is_merged():
+    n = 600
+    X = rand_inputs(n, 2, 5) * 3.0
+    k = ("hyper_tan", 1.0, 0.0)
+    st, L_o, idx_o = O.make_cholesky_cov_matrix(k, X, 0.0, 1e-6)
+    assert st == 0 and len(idx_o) > 100
+
+    def fn(ctx, rank):
+        ctx.set_option("nb", 128)
+        chol = ctx.cholesky_from_inputs(k, X, 0.0, eps=1e-6)
+        idx = chol.substitutions()
+        chol.free()
+        return idx
+
+    for idx in run_ranks(3, fn):
+        assert idx.tolist() == idx_o.tolist()
+
+
+def test_sharded_failure_column():
+    # noiseless duplicated design far beyond round-off: the first failing column must be the same on every rank
+    n = 400
+    X = rand_inputs(n, 2, 9) * 3.0
+    k = ("hyper_tan", 1.0, 0.0)
+    st, _, _ = O.make_cholesky_cov_matrix(k, X, 0.0)
+    assert st > 0
+
+    def fn(ctx, rank):
+        ctx.set_option("nb", 128)
+        chol = ctx.cholesky_from_inputs(k, X, 0.0, allow_failure=True)
+        col = chol.info()["fail_col"]
+        chol.free()
+        return col
+
+    assert run_ranks(2, fn) == [st - 1, st - 1]
+
+
+def test_sharded_fit_predict_queries_split():
+    # bench.py's N > 1 recipe at small scale: sharded fit, query rows split across ranks
+    n, m, d, world = 900, 64, 4, 4
+    k = ("squared_exp", 0.9, 1.1)
+    X, Xq = rand_inputs(n, d, 3), rand_inputs(m, d, 4)
+    y = np.sin(X.sum(axis=1))
+    gp = O.OracleGP(O.ZeroPrior(), k, 0.1, None, X, y)
+    want = gp.predict(Xq)
+
+    def fn(ctx, rank):
+        ctx.set_option("nb", 128)
+        chol = ctx.cholesky_from_inputs(k, X, 0.1)
+        lo, hi = (m * rank) // world, (m * (rank + 1)) // world
+        out = chol.predict_mean(k, y, Xq[lo:hi])
+        chol.free()
+        return out
+
+    got = np.concatenate(run_ranks(world, fn))
+    assert rel_err(got, want) < TOL
