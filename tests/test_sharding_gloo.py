@@ -1,0 +1,89 @@
+"""N > 1 path on CPU: a 2-rank gloo group replays friedrich_amd.sharding.panel_schedule -- the same ownership map
+and panel-broadcast order as chol.hip -- with numpy tiles (scipy for the tile factorisation) and checks that every
+rank ends with the oracle's factor, and that bench.py's query split covers every row exactly once."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rand_inputs, rel_err
+
+
+def _worker(rank, world, port, n, nb, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scipy.linalg as sl
+    import torch
+    import torch.distributed as dist
+
+    from friedrich_amd import sharding
+    from oracle import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k = ("matern2", 0.7, 1.2)
+    X = rand_inputs(n, 3, 42)
+    A = np.full((n, n), np.nan)
+    # Gram: owned block columns only
+    for j in range(0, n, nb):
+        if sharding.owner_of(j, nb, world) == rank:
+            w = min(nb, n - j)
+            A[j:, j:j + w] = O.make_covariance_matrix(k, X[j:], X[j:j + w])
+            A[j:j + w, j:j + w] += 0.01 * np.eye(w)
+    moved = 0
+    for step in sharding.panel_schedule(n, nb, world):
+        kk, kb, owner = step["k"], step["kb"], step["owner"]
+        panel = np.zeros((n - kk, kb))
+        if rank == owner:
+            L11 = sl.cholesky(A[kk:kk + kb, kk:kk + kb], lower=True)
+            A[kk:kk + kb, kk:kk + kb] = L11
+            if kk + kb < n:
+                A[kk + kb:, kk:kk + kb] = sl.solve_triangular(L11, A[kk + kb:, kk:kk + kb].T, lower=True).T
+            panel = np.tril(A[kk:, kk:kk + kb], 0) if False else A[kk:, kk:kk + kb].copy()
+        t = torch.from_numpy(np.ascontiguousarray(panel))
+        dist.broadcast(t, src=owner)
+        moved += sharding.panel_bytes(n, kk, kb)
+        A[kk:, kk:kk + kb] = t.numpy()
+        P = A[kk + kb:, kk:kk + kb]
+        for j in step["updates"][rank]:
+            w = min(nb, n - j)
+            A[j:, j:j + w] -= P[j - kk - kb:] @ P[j - kk - kb:j - kk - kb + w].T
+    np.save(os.path.join(out_dir, f"L{rank}.npy"), np.tril(A))
+    lo, hi = sharding.query_slice(37, rank, world)
+    np.save(os.path.join(out_dir, f"q{rank}.npy"), np.arange(lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,nb", [(300, 64), (257, 128)])
+def test_two_rank_panel_schedule(tmp_path, n, nb):
+    import torch.multiprocessing as tmp_mp
+
+    from oracle import oracle as O
+
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + n % 7
+    tmp_mp.spawn(_worker, args=(world, port, n, nb, str(tmp_path)), nprocs=world, join=True)
+    X = rand_inputs(n, 3, 42)
+    st, L_o, _ = O.make_cholesky_cov_matrix(("matern2", 0.7, 1.2), X, 0.1)
+    for r in range(world):
+        L = np.load(tmp_path / f"L{r}.npy")
+        assert rel_err(L, np.tril(L_o)) < 1e-11
+    q = np.concatenate([np.load(tmp_path / f"q{r}.npy") for r in range(world)])
+    assert q.tolist() == list(range(37))
+
+
+def test_schedule_covers_every_block_once():
+    from friedrich_amd import sharding
+
+    for n, nb, world in [(1000, 128, 3), (4096, 512, 8), (100, 256, 4)]:
+        steps = list(sharding.panel_schedule(n, nb, world))
+        assert [s["k"] for s in steps] == list(range(0, n, nb))
+        for s in steps:
+            assert s["owner"] == (s["k"] // nb) % world
+            cols = sorted(c for r in s["updates"].values() for c in r)
+            assert cols == list(range(s["k"] + s["kb"], n, nb))
+            for r, cs in s["updates"].items():
+                assert all(sharding.owner_of(c, nb, world) == r for c in cs)
