@@ -175,45 +175,104 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
     __syncthreads();
 
     int cur = 0;
-    for (int64_t kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            pa += step_a;
-            pb += step_b;
-            const bool kfull = (kt + 1) < nk_full;
-            if (a_fast && kfull)
-                load_tile_fast<A_KMAJ>(pa, g.lda, ra);
-            else
-                load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, t, ra);
-            if (b_fast && kfull)
-                load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
-            else
-                load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, t, rb);
-        }
-        const double* As = lds + cur * 2 * TILE_ELEMS;
-        const double* Bs = As + TILE_ELEMS;
+    if (a_fast && b_fast && nk_full == nk) {
+        // Interior tile, K a multiple of 16: one branch-free basic block per K-step, with the instruction order
+        // pinned by sched_group_barrier.  A wave issues its next MFMA only when the matrix pipe is free (64 cycles
+        // each), so everything else -- the 16 global loads of the next K-slice, the LDS fragment reads of the next
+        // k-substep, the 16 LDS stores of the prefetched slice -- is slotted BETWEEN MFMAs instead of in front of /
+        // behind the 64-MFMA block, which leaves only the barrier and the first fragment read exposed per K-step.
+        // The last K-step re-loads its own slice (pointer not advanced) into the unused buffer: harmless, and it
+        // keeps the loop body free of branches.
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1) < nk;
+            pa += more ? step_a : 0;
+            pb += more ? step_b : 0;
+            load_tile_fast<A_KMAJ>(pa, g.lda, ra);
+            load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+            const double* As = lds + cur * 2 * TILE_ELEMS;
+            const double* Bs = As + TILE_ELEMS;
 #pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            const int kq = ks * 4 + lq;
-            double af[4], bf[4];
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const int kq = ks * 4 + lq;
+                double af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = As[lds_idx<A_KMAJ>(wm * 64 + i * 16 + l15, kq)];
-                bf[i] = Bs[lds_idx<B_KMAJ>(wn * 64 + i * 16 + l15, kq)];
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = As[lds_idx<A_KMAJ>(wm * 64 + i * 16 + l15, kq)];
+                    bf[i] = Bs[lds_idx<B_KMAJ>(wn * 64 + i * 16 + l15, kq)];
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
             }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-        }
-        if (more) {
             double* An = lds + (cur ^ 1) * 2 * TILE_ELEMS;
             store_tile<A_KMAJ>(An, t, ra);
             store_tile<B_KMAJ>(An + TILE_ELEMS, t, rb);
+            // pipeline description (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // fragments of k-substep 0
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // k-substep 0: 16 MFMA + the 16 global loads (+ fragments of substep 1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                if (j >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int ks = 1; ks < 3; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // k-substeps 1, 2: 16 MFMA + the fragments of the next substep
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (j >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // k-substep 3: 16 MFMA + the 16 LDS stores of the prefetched slice
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            }
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
-        cur ^= 1;
+    } else {
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1) < nk;
+            if (more) {
+                pa += step_a;
+                pb += step_b;
+                const bool kfull = (kt + 1) < nk_full;
+                if (a_fast && kfull)
+                    load_tile_fast<A_KMAJ>(pa, g.lda, ra);
+                else
+                    load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, t, ra);
+                if (b_fast && kfull)
+                    load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+                else
+                    load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, t, rb);
+            }
+            const double* As = lds + cur * 2 * TILE_ELEMS;
+            const double* Bs = As + TILE_ELEMS;
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const int kq = ks * 4 + lq;
+                double af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = As[lds_idx<A_KMAJ>(wm * 64 + i * 16 + l15, kq)];
+                    bf[i] = Bs[lds_idx<B_KMAJ>(wn * 64 + i * 16 + l15, kq)];
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            }
+            if (more) {
+                double* An = lds + (cur ^ 1) * 2 * TILE_ELEMS;
+                store_tile<A_KMAJ>(An, t, ra);
+                store_tile<B_KMAJ>(An + TILE_ELEMS, t, rb);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // epilogue: accumulator register r of tile (nt, mt) holds D[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
