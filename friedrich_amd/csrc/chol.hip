@@ -10,9 +10,8 @@
 //   DMatrix::cholesky().unpack()    src/gaussian_process/multivariate_normal.rs:57
 //
 // Structure.  Three block sizes:
-//   64   K4 potf2: one workgroup factors + inverts a diagonal block in LDS (potf2.hip)
-//   128  "inverse block": L's diagonal is covered by 128 x 128 blocks whose explicit inverses are kept next to
-//        the factor (fr_chol::dinv).  Every triangular solve -- inside the factorisation and in the predict
+//   128  K4 potf2 + "inverse block": one workgroup factors a 128 x 128 diagonal block in LDS and emits its explicit
+//        inverse (potf2.hip); the inverses are kept next to the factor (fr_chol::dinv).  Every triangular solve -- inside the factorisation and in the predict
 //        family -- is a chain of FP64-MFMA GEMMs against these inverses; with N (or M) <= 128 the GEMM has a
 //        single tile column (row), so it can safely run in place.
 //   nb   (default 256) outer block: the trailing update A22 -= P P^T is one lower-triangular SYRK launch with
@@ -55,46 +54,17 @@ static int gemm(fr_ctx* ctx, int cls, int64_t M, int64_t N, int64_t K, const dou
     return launch_gemm(ctx, g);
 }
 
-// inv21 = -inv22 * L21 * inv11 for a 128-block split at n1 (inverse of a 2x2 block lower-triangular matrix)
-static int combine_inverse(fr_ctx* ctx, const double* L21, int64_t ldl, double* inv, int64_t n1, int64_t n2, double* T)
-{
-    // T (n2 x n1) = L21 * inv11
-    FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n2, n1, n1, L21, ldl, false, inv, IB, true, 1.0, 0.0, T, 64));
-    // inv21 = -inv22 * T
-    return gemm(ctx, FR_PROF_GEMM_PANEL, n2, n1, n2, inv + n1 + n1 * IB, IB, false, T, 64, true, -1.0, 0.0, inv + n1, IB);
-}
-
-// Factor the sb x sb (sb <= 128) diagonal block at A and produce its inverse in `inv` (ld 128).
+// Factor the sb x sb (sb <= 128) diagonal block at A and produce its inverse in `inv` (ld 128): one K4 launch.
 static int factor_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, int64_t col, int mode, double sub, double* inv,
-                           int64_t* info, double* T)
+                           int64_t* info, double* /*T*/)
 {
-    const int64_t n1 = imin(kDiagBlock, sb), n2 = sb - n1;
-    FR_TRY(launch_fill(ctx, inv, IB, IB, IB, 0.0));
-    FR_TRY(launch_potf2(ctx, A, ld, n1, col, mode, sub, inv, IB, info));
-    if (n2 > 0) {
-        double* A21 = A + n1;
-        double* A22 = A + n1 + n1 * ld;
-        // A21 <- A21 * inv11^T   (op(B)[k][n] = inv11[n][k]: n-major)
-        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n2, n1, n1, A21, ld, false, inv, IB, false, 1.0, 0.0, A21, ld));
-        // A22 -= A21 * A21^T
-        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n2, n2, n1, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
-        FR_TRY(launch_potf2(ctx, A22, ld, n2, col + n1, mode, sub, inv + n1 + n1 * IB, IB, info));
-        FR_TRY(combine_inverse(ctx, A21, ld, inv, n1, n2, T));
-    }
-    return FR_OK;
+    return launch_potf2(ctx, A, ld, sb, col, mode, sub, inv, IB, info);
 }
 
 // Rebuild the inverse of an already factored 128-block (serde upload, add_rows re-alignment).
-static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, double* inv, double* T)
+static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, double* inv, double* /*T*/)
 {
-    const int64_t n1 = imin(kDiagBlock, sb), n2 = sb - n1;
-    FR_TRY(launch_fill(ctx, inv, IB, IB, IB, 0.0));
-    FR_TRY(launch_potf2(ctx, A, ld, n1, 0, 3, 0.0, inv, IB, nullptr));
-    if (n2 > 0) {
-        FR_TRY(launch_potf2(ctx, A + n1 + n1 * ld, ld, n2, 0, 3, 0.0, inv + n1 + n1 * IB, IB, nullptr));
-        FR_TRY(combine_inverse(ctx, A + n1, ld, inv, n1, n2, T));
-    }
-    return FR_OK;
+    return launch_potf2(ctx, A, ld, sb, 0, 3, 0.0, inv, IB, nullptr);
 }
 
 // Factor the kb-wide column block starting at (j0, j0): diagonal 128-blocks, the TRSM of everything below them

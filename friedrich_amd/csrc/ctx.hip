@@ -310,11 +310,8 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return FR_INVALID_ARGUMENT;
     if (!strcmp(name, "nb")) {
-        if (value < kDiagBlock || value % kDiagBlock != 0 || value > 1024)
-            return set_err(ctx, FR_INVALID_ARGUMENT, "nb must be a multiple of %d in [%d, 1024]", kDiagBlock, kDiagBlock);
-        // power-of-two multiples only: the diagonal-block recursion halves down to kDiagBlock
-        int64_t v = value / kDiagBlock;
-        if (v & (v - 1)) return set_err(ctx, FR_INVALID_ARGUMENT, "nb / %d must be a power of two", kDiagBlock);
+        if (value < 128 || value % 128 != 0 || value > 4096)
+            return set_err(ctx, FR_INVALID_ARGUMENT, "nb must be a multiple of 128 in [128, 4096]");
         ctx->nb = value;
         return FR_OK;
     }

@@ -1,31 +1,9 @@
-// potf2.hip -- K4: Cholesky of one diagonal block (<= 128 x 128) with friedrich's pivot rules, fused with the
-// explicit inverse of the factored block (consumed by the GEMM-recast triangular solves).
-//
-// Pivot rule = nalgebra 0.31.4 Cholesky::new_internal (called from src/algebra/mod.rs:83,:90 and
-// src/gaussian_process/multivariate_normal.rs:57):
-//   d > 0            -> sqrt(d)
-//   otherwise (0, negative, NaN):
-//       mode 1 (cholesky_epsilon = Some(sub), sub > 0) -> sqrt(sub), column index appended to the log
-//       else                                           -> failure, first failing column recorded
-//   mode 2 (add_rows / Cholesky::insert_column, algebra/mod.rs:124; Appendix A.3): plain sqrt(d), NaN and
-//   division by zero propagate exactly as in the reference, nothing is recorded.
-//   mode 3: the block already holds a factor; only its inverse is produced (serde upload, re-alignment).
-// Column scaling is a true division (`col /= denom`).
-//
-// One workgroup of 512 threads; the block lives in REGISTERS: thread (i = t & 127, cg = t >> 7) owns the 32
-// elements (i, c = cg + 4k), statically indexed.  Right-looking, one column per step, two barriers per step; the only
-// LDS traffic is one 128-entry vector V per step:
-//   Lc[x] = L[x, j] (scaled column j),   Vc[c] = L[c, j] for c > j,   Vc[128 + c] = X[j, c] (row j of the inverse, c < j)
-// so that BOTH rank-1 updates of the step are the same predicate-free expression  a(i, c) -= Lc[i] * Vc[..c..]:
-//   c > j : trailing factor update   A[i, c] -= L[i, j] L[c, j]                (c <= i)
-//   c < j : forward substitution     X[i, c] -= L[i, j] X[j, c]               (the inverse rides in the dead columns)
-//   c = j : new inverse column       X[i, j]  = -L[i, j] / p
-// Column j is stored to global memory by its owners as soon as it is scaled (the barriers order LDS only).  Bound by
-// (~1k cycles per column: sqrt -> divide -> barrier -> 17 LDS reads + 16 FMAs -> barrier), one launch per block.
-#include "fr_internal.hpp"
-
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <cmath>
 namespace fr {
-
 constexpr int PB = 128;
 constexpr int PT = 512;  // threads: 8 waves x <= 128 VGPRs fit beside ONE resident GEMM workgroup (look-ahead overlap)
 constexpr int PE = 32;   // elements per thread
@@ -70,7 +48,8 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
     const bool row_ok = i < n;
     const int wave_row0 = i & 64;  // first row held by this wave
 
-    double a[PE];  // working element (i, cg + 4k): A, then (once column c is done) the inverse X
+    double a[PE];  // working element (i, cg + 8k): A, then (once column c is done) the inverse X
+    double l[PE];  // finished factor entries L(i, cg + 8k), stored after the loop (no global traffic inside it)
 #pragma unroll
     for (int k = 0; k < PE; ++k) {
         const int c = cg + PG * k;
@@ -82,7 +61,7 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
         piv[1] = 1.0 / p0;
     }
     lds_barrier();
-
+    const long long tc0 = __builtin_amdgcn_s_memtime();
     for (int j = 0; j < n; ++j) {
         const int jcg = j & (PG - 1), jk = j / PG;
         // ---- phase 1: owners of column j / row j scale and publish (sqrt and reciprocal were computed by ONE thread
@@ -103,7 +82,7 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
                 }
             }
         }
-        if (i == j) {  // the 4 threads holding row j: scale and publish X(j, c), c < j
+        if (i == j) {  // the 8 threads holding row j: scale and publish X(j, c), c < j
 #pragma unroll
             for (int k = 0; k < PE; ++k) {
                 const int c = cg + PG * k;
@@ -156,15 +135,17 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
     }
 }
 
-int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub, double* inv,
-                 int64_t ldinv, int64_t* info)
-{
-    if (nbk <= 0) return FR_OK;
-    if (nbk > PB) return set_err(ctx, FR_INVALID_ARGUMENT, "potf2 block too large");
-    ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(PT), 0, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv, info);
-    FR_HIP(ctx, hipGetLastError());
-    return FR_OK;
 }
-
-}  // namespace fr
+int main(){
+  const int n=128; std::vector<double> h(n*n);
+  for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
+  double *A,*inv; int64_t* info; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n));
+  hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for(int rep=0;rep<4;++rep){
+    (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
+    (void)hipEventRecord(e0); hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),0,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info); (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms,e0,e1); int64_t hi[3]; (void)hipMemcpy(hi,info,24,hipMemcpyDeviceToHost);
+    printf("rep %d: %.1f us, loop ticks %lld (%.0f per step), fail=%lld\n",rep,ms*1e3,(long long)hi[2],hi[2]/128.0,(long long)hi[0]);
+  }
+  std::vector<double> L(n*n); (void)hipMemcpy(L.data(),A,n*n*8,hipMemcpyDeviceToHost); printf("L00=%.6f L10=%.6f L[127,126]=%.6f\n",L[0],L[1],L[127+126*n]);
+  return 0; }

@@ -1,35 +1,12 @@
-// potf2.hip -- K4: Cholesky of one diagonal block (<= 128 x 128) with friedrich's pivot rules, fused with the
-// explicit inverse of the factored block (consumed by the GEMM-recast triangular solves).
-//
-// Pivot rule = nalgebra 0.31.4 Cholesky::new_internal (called from src/algebra/mod.rs:83,:90 and
-// src/gaussian_process/multivariate_normal.rs:57):
-//   d > 0            -> sqrt(d)
-//   otherwise (0, negative, NaN):
-//       mode 1 (cholesky_epsilon = Some(sub), sub > 0) -> sqrt(sub), column index appended to the log
-//       else                                           -> failure, first failing column recorded
-//   mode 2 (add_rows / Cholesky::insert_column, algebra/mod.rs:124; Appendix A.3): plain sqrt(d), NaN and
-//   division by zero propagate exactly as in the reference, nothing is recorded.
-//   mode 3: the block already holds a factor; only its inverse is produced (serde upload, re-alignment).
-// Column scaling is a true division (`col /= denom`).
-//
-// One workgroup of 512 threads; the block lives in REGISTERS: thread (i = t & 127, cg = t >> 7) owns the 32
-// elements (i, c = cg + 4k), statically indexed.  Right-looking, one column per step, two barriers per step; the only
-// LDS traffic is one 128-entry vector V per step:
-//   Lc[x] = L[x, j] (scaled column j),   Vc[c] = L[c, j] for c > j,   Vc[128 + c] = X[j, c] (row j of the inverse, c < j)
-// so that BOTH rank-1 updates of the step are the same predicate-free expression  a(i, c) -= Lc[i] * Vc[..c..]:
-//   c > j : trailing factor update   A[i, c] -= L[i, j] L[c, j]                (c <= i)
-//   c < j : forward substitution     X[i, c] -= L[i, j] X[j, c]               (the inverse rides in the dead columns)
-//   c = j : new inverse column       X[i, j]  = -L[i, j] / p
-// Column j is stored to global memory by its owners as soon as it is scaled (the barriers order LDS only).  Bound by
-// (~1k cycles per column: sqrt -> divide -> barrier -> 17 LDS reads + 16 FMAs -> barrier), one launch per block.
-#include "fr_internal.hpp"
-
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <cmath>
 namespace fr {
-
 constexpr int PB = 128;
-constexpr int PT = 512;  // threads: 8 waves x <= 128 VGPRs fit beside ONE resident GEMM workgroup (look-ahead overlap)
-constexpr int PE = 32;   // elements per thread
-constexpr int PG = 4;    // column groups
+constexpr int PT = 1024;  // threads
+constexpr int PE = 16;    // elements per thread
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the
 // column store of every step to be acknowledged by memory (~2 us per step, 6x the rest of the step).
@@ -66,15 +43,17 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
     __shared__ __attribute__((aligned(16))) double piv[2];  // {pivot, 1/pivot} of the current step
     const int t = threadIdx.x;
     const int i = t & (PB - 1);
-    const int cg = t >> 7;  // 4 column groups of 128 threads (two waves): cg is wave-uniform
+    const int cg = t >> 7;  // 8 column groups of 128 threads (two waves): cg is wave-uniform
     const bool row_ok = i < n;
     const int wave_row0 = i & 64;  // first row held by this wave
 
-    double a[PE];  // working element (i, cg + 4k): A, then (once column c is done) the inverse X
+    double a[PE];  // working element (i, cg + 8k): A, then (once column c is done) the inverse X
+    double l[PE];  // finished factor entries L(i, cg + 8k), stored after the loop (no global traffic inside it)
 #pragma unroll
     for (int k = 0; k < PE; ++k) {
-        const int c = cg + PG * k;
+        const int c = cg + 8 * k;
         a[k] = (row_ok && c < n && i >= c) ? A[i + (int64_t)c * lda] : 0.0;
+        l[k] = 0.0;
     }
     if (t == 0) {
         const double p0 = pivot_of(a[0], mode, sub, col0, info);
@@ -83,8 +62,10 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
     }
     lds_barrier();
 
+    long long s1=0,s2=0,s3=0,s4=0;
     for (int j = 0; j < n; ++j) {
-        const int jcg = j & (PG - 1), jk = j / PG;
+        const long long q0 = __builtin_amdgcn_s_memtime();
+        const int jcg = j & 7, jk = j >> 3;
         // ---- phase 1: owners of column j / row j scale and publish (sqrt and reciprocal were computed by ONE thread
         //      at the end of the previous step)
         const double p = piv[0], ip = piv[1];
@@ -98,32 +79,34 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
                     const double lv = diag ? p : q;  // L(i, j)
                     Lc[i] = lv;
                     Vc[i] = (mode == 3) ? 0.0 : lv;
-                    if (mode != 3) A[i + (int64_t)j * lda] = lv;  // fire and forget: the barriers wait on LDS only
+                    l[k] = lv;
                     a[k] = diag ? ip : -q * ip;  // X(i, j): 1/p on the diagonal, else 0 - L(i,j) X(j,j)
                 }
             }
         }
-        if (i == j) {  // the 4 threads holding row j: scale and publish X(j, c), c < j
+        if (i == j) {  // the 8 threads holding row j: scale and publish X(j, c), c < j
 #pragma unroll
             for (int k = 0; k < PE; ++k) {
-                const int c = cg + PG * k;
+                const int c = cg + 8 * k;
                 const double sc = a[k] * ip;
                 const bool lt = c < j;
                 a[k] = lt ? sc : a[k];
                 Vc[PB + c] = lt ? sc : 0.0;  // zero for c >= j: the update of column j itself must be a no-op
             }
         }
+        const long long q1 = __builtin_amdgcn_s_memtime();
         lds_barrier();
+        const long long q2 = __builtin_amdgcn_s_memtime();
         // ---- phase 2: a(i, c) -= L(i, j) * (c > j ? L(c, j) : X(j, c)).  One LDS read + one FMA per element; waves whose
         //      rows are all finished skip it (the block is VALU-throughput bound: 1024 threads x 16 elements per step)
         if (wave_row0 + 63 > j) {
             const bool act = (i > j) && row_ok;
             const double lraw = Lc[i];
             const double lij = act ? lraw : 0.0;
-            if (act && i == j + 1 && cg == ((j + 1) & (PG - 1))) {
+            if (act && i == j + 1 && cg == ((j + 1) & 7)) {
                 // owner of the next diagonal element: take the next pivot now; the other waves overlap it with their
                 // 16 updates
-                const int nk = (j + 1) / PG;
+                const int nk = (j + 1) >> 3;
                 double nd = 0.0;
 #pragma unroll
                 for (int k = 0; k < PE; ++k)
@@ -136,19 +119,24 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
             double vc[PE];
 #pragma unroll
             for (int k = 0; k < PE; ++k) {
-                const int c = cg + PG * k;
+                const int c = cg + 8 * k;
                 vc[k] = Vc[c + ((c > j) ? 0 : PB)];
             }
 #pragma unroll
             for (int k = 0; k < PE; ++k) a[k] = __builtin_fma(-lij, vc[k], a[k]);
         }
+        const long long q3 = __builtin_amdgcn_s_memtime();
         lds_barrier();
+        const long long q4 = __builtin_amdgcn_s_memtime();
+        s1+=q1-q0; s2+=q2-q1; s3+=q3-q2; s4+=q4-q3;
     }
 
+    if ((t & 63) == 0 && info) { int w = t >> 6; info[8+4*w]=s1; info[9+4*w]=s2; info[10+4*w]=s3; info[11+4*w]=s4; }
 #pragma unroll
     for (int k = 0; k < PE; ++k) {
-        const int c = cg + PG * k;
+        const int c = cg + 8 * k;
         if (row_ok && c < n && i >= c) {
+            if (mode != 3) A[i + (int64_t)c * lda] = l[k];
             if (inv) inv[i + (int64_t)c * ldinv] = a[k];
         } else if (row_ok && c < n && inv) {
             inv[i + (int64_t)c * ldinv] = 0.0;
@@ -156,15 +144,15 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
     }
 }
 
-int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub, double* inv,
-                 int64_t ldinv, int64_t* info)
-{
-    if (nbk <= 0) return FR_OK;
-    if (nbk > PB) return set_err(ctx, FR_INVALID_ARGUMENT, "potf2 block too large");
-    ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(PT), 0, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv, info);
-    FR_HIP(ctx, hipGetLastError());
-    return FR_OK;
 }
-
-}  // namespace fr
+int main(){
+  const int n=128; std::vector<double> h(n*n);
+  for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
+  double *A,*inv; int64_t* info; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n));
+  for(int rep=0;rep<2;++rep){
+    (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
+    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(1024),0,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info); (void)hipDeviceSynchronize();
+    int64_t hi[80]; (void)hipMemcpy(hi,info,8*80,hipMemcpyDeviceToHost);
+    if (rep) for (int w=0; w<16; w+=3) printf("wave %2d: per-step ticks P1 %5.0f  bar1 %5.0f  P2 %5.0f  bar2 %5.0f\n",w,hi[8+4*w]/128.0,hi[9+4*w]/128.0,hi[10+4*w]/128.0,hi[11+4*w]/128.0);
+  }
+  return 0; }

@@ -88,7 +88,7 @@ def test_cholesky_kernels_and_block_sizes(ctx, kernel):
     X = rand_inputs(n, 6, 11)
     st, L_o, _ = O.make_cholesky_cov_matrix(kernel, X, 0.05)
     assert st == 0
-    for nb in (64, 128, 256, 512):
+    for nb in (128, 256, 384, 512):
         ctx.set_option("nb", nb)
         chol = ctx.cholesky_from_inputs(kernel, X, 0.05)
         assert rel_err(chol.l(), np.tril(L_o)) < TOL
