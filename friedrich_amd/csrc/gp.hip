@@ -268,12 +268,4 @@ int fr_gemm(fr_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t
     return c.commit();
 }
 
-int fr_grad_terms(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, int scaled, double* out_grad,
-                  double* out_scale)
-{
-    (void)kernel; (void)y; (void)noise; (void)scaled; (void)out_grad; (void)out_scale;
-    if (!c) return FR_INVALID_ARGUMENT;
-    return set_err(c->ctx, FR_UNSUPPORTED_KERNEL, "fr_grad_terms: not implemented in this build");
-}
-
 }  // extern "C"

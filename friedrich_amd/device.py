@@ -353,6 +353,18 @@ class Cholesky:
                                                       max(q.rows, 1)))
         return cov
 
+    def grad_terms(self, kernel, y, noise, scaled, nb_parameters):
+        """gradient_marginal_likelihood (optimizer.rs:24-60) / scaled_gradient_marginal_likelihood (:159-203)
+        -> (gradients [nb_parameters (+1 noise when not scaled)], scale)"""
+        p = C.kprog(kernel)
+        yp, _, k1 = _vecptr(y)
+        out = (ctypes.c_double * (nb_parameters + 1))()
+        scale = ctypes.c_double()
+        self.ctx.check(self.lib.fr_grad_terms(self.h, ctypes.byref(p), yp, float(noise), 1 if scaled else 0, out,
+                                              ctypes.byref(scale)))
+        n = nb_parameters + (0 if scaled else 1)
+        return np.array(out[:n]), scale.value
+
     def posterior(self, kernel, y, Xq, prior_q=None):
         """sample_at: -> (mean, cov, cholesky(cov).unpack())"""
         p = C.kprog(kernel)

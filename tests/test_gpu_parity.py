@@ -331,3 +331,32 @@ def test_large_factor_properties(ctx):
     var = chol.predict_variance(k, Xq)
     assert np.all(var > -1e-10) and np.all(var <= hp["ampl"] + 1e-12)
     chol.free()
+
+
+# ---- optimizer reductions ------------------------------------------------
+@pytest.mark.parametrize("kernel", ALL_KERNELS, ids=lambda k: k[0] + str(len(k)))
+def test_grad_terms_match_oracle(ctx, kernel):
+    n, d = 300, 3
+    X = rand_inputs(n, d, 31)
+    y = np.sin(X.sum(axis=1))
+    noise = 0.3
+    # make the factorisation succeed for every kernel (indefinite ones take the substitute, as the reference would)
+    gp = O.OracleGP(O.ZeroPrior(), kernel, noise, 1e-3, X, y)
+    chol = ctx.cholesky_from_inputs(kernel, X, noise, eps=1e-3)
+    if len(gp.subst) > 0:
+        chol.free()
+        pytest.skip("indefinite kernel matrix: K^-1 is not defined by the substituted factor")
+    npar = O.nb_parameters(kernel)
+    g_o = gp.gradient()
+    g, _ = chol.grad_terms(kernel, y, noise, scaled=False, nb_parameters=npar)
+    assert g.shape == g_o.shape
+    fin = np.isfinite(g_o)
+    assert np.array_equal(np.isfinite(g), fin)
+    assert np.max(np.abs(g[fin] - g_o[fin])) < 1e-8 * (np.max(np.abs(g_o[fin])) + 1.0)
+    scale_o, gs_o = gp.scaled_gradient()
+    gs, scale = chol.grad_terms(kernel, y, noise, scaled=True, nb_parameters=npar)
+    assert abs(scale / scale_o - 1.0) < 1e-9
+    fin = np.isfinite(gs_o)
+    assert np.array_equal(np.isfinite(gs), fin)
+    assert np.max(np.abs(gs[fin] - gs_o[fin])) < 1e-8 * (np.max(np.abs(gs_o[fin])) + 1.0)
+    chol.free()
