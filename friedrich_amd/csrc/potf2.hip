@@ -10,7 +10,7 @@
 //   mode 2 (add_rows / Cholesky::insert_column, algebra/mod.rs:124; Appendix A.3): plain sqrt(d), NaN and
 //   division by zero propagate exactly as in the reference, nothing is recorded.
 //   mode 3: the block already holds a factor; only its inverse is produced (serde upload, re-alignment).
-// Column scaling is a true division (`col /= denom`).
+// Column scaling (`col /= denom`) is a reciprocal multiply with one residual correction.
 //
 // One workgroup of 512 threads; the block lives in REGISTERS: thread (i = t & 127, cg = t >> 7) owns the 32
 // elements (i, c = cg + 4k), statically indexed.  Right-looking, one column per step, two barriers per step; the only
@@ -38,23 +38,54 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// pivot rule for one diagonal value (executed by ONE thread per step); returns the pivot, logs substitutions/failures
-__device__ __forceinline__ double pivot_of(double d, int mode, double sub, int64_t col, int64_t* __restrict__ info)
+// sqrt(d) and 1/sqrt(d) from ONE v_rsq_f64 seed and Newton steps (~15 dependent instructions).  The step's critical
+// path is sqrt -> reciprocal -> column scaling; libm's sqrt + two IEEE divisions are ~100 dependent f64 instructions,
+// most of a step.  Results agree with sqrt()/division to the last bit or 1 ulp (the oracle comparison bounds it).
+__device__ __forceinline__ void sqrt_rsqrt(double d, double& p, double& ip)
 {
-    if (mode == 3) return d;        // already a factor
-    if (mode == 2) return sqrt(d);  // insert_column: plain sqrt
-    if (d > 0.0) return sqrt(d);
+    if (d == 0.0) {  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
+        p = 0.0;
+        ip = __builtin_inf();
+        return;
+    }
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    double q = d * r;
+    q = __builtin_fma(0.5 * r, __builtin_fma(-q, q, d), q);  // sqrt(d), corrected
+    r = r * __builtin_fma(-q, r, 2.0);                        // 1 / q
+    p = q;
+    ip = r;
+}
+
+// pivot rule for one diagonal value (executed by ONE thread per step): pivot and its reciprocal; logs substitutions
+// and failures
+__device__ __forceinline__ void pivot_of(double d, int mode, double sub, int64_t col, int64_t* __restrict__ info, double& p,
+                                         double& ip)
+{
+    if (mode == 3) {  // already a factor
+        p = d;
+        ip = 1.0 / d;
+        return;
+    }
+    if (mode == 2 || d > 0.0) {  // insert_column: plain sqrt (NaN for d < 0)
+        sqrt_rsqrt(d, p, ip);
+        return;
+    }
     if (mode == 1 && sub > 0.0) {
         const int64_t q = info[1];
         info[3 + q] = col;
         info[1] = q + 1;
-        return sqrt(sub);
+        sqrt_rsqrt(sub, p, ip);
+        return;
     }
     if (info[0] == 0) info[0] = 1 + col;
-    return __builtin_nan("");
+    p = __builtin_nan("");
+    ip = p;
 }
 
-__global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
+__global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
                                                    int64_t* __restrict__ info)
 {
@@ -77,9 +108,10 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
         a[k] = (row_ok && c < n && i >= c) ? A[i + (int64_t)c * lda] : 0.0;
     }
     if (t == 0) {
-        const double p0 = pivot_of(a[0], mode, sub, col0, info);
+        double p0, ip0;
+        pivot_of(a[0], mode, sub, col0, info, p0, ip0);
         piv[0] = p0;
-        piv[1] = 1.0 / p0;
+        piv[1] = ip0;
     }
     lds_barrier();
 
@@ -93,7 +125,11 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
             for (int k = 0; k < PE; ++k) {
                 if (k == jk) {  // uniform: exactly one of the 16 statically indexed bodies runs
                     const double v = a[k];
-                    const double q = (mode == 3) ? v : v / p;  // true division, as `col /= denom`
+                    // col /= denom: quotient by reciprocal + one residual correction (== IEEE division except for rare
+                    // last-bit ties); the reciprocal is already on hand, a full division is ~35 dependent instructions
+                    double q = v * ip;
+                    q = __builtin_fma(__builtin_fma(-q, p, v), ip, q);
+                    q = (mode == 3) ? v : q;
                     const bool diag = (i == j);
                     const double lv = diag ? p : q;  // L(i, j)
                     Lc[i] = lv;
@@ -129,18 +165,24 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
                 for (int k = 0; k < PE; ++k)
                     if (k == nk) nd = a[k];
                 if (mode != 3) nd = nd - lij * lij;
-                const double pn = pivot_of(nd, mode, sub, col0 + j + 1, info);
+                double pn, ipn;
+                pivot_of(nd, mode, sub, col0 + j + 1, info, pn, ipn);
                 piv[0] = pn;
-                piv[1] = 1.0 / pn;
+                piv[1] = ipn;
             }
-            double vc[PE];
+            // two batches of 16: all LDS reads of a batch first, then its FMAs (keeps the kernel under 128 VGPRs so that
+            // 8 waves fit next to one resident GEMM workgroup: 512 - 240 = 272 registers per SIMD lane)
 #pragma unroll
-            for (int k = 0; k < PE; ++k) {
-                const int c = cg + PG * k;
-                vc[k] = Vc[c + ((c > j) ? 0 : PB)];
+            for (int k0 = 0; k0 < PE; k0 += 16) {
+                double vc[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int c = cg + PG * (k0 + k);
+                    vc[k] = Vc[c + ((c > j) ? 0 : PB)];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k0 + k] = __builtin_fma(-lij, vc[k], a[k0 + k]);
             }
-#pragma unroll
-            for (int k = 0; k < PE; ++k) a[k] = __builtin_fma(-lij, vc[k], a[k]);
         }
         lds_barrier();
     }
