@@ -63,7 +63,7 @@ __device__ __forceinline__ void pivot_of(double d, int mode, double sub, int64_t
     ip = p;
 }
 
-__global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
+__global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
                                                    int64_t* __restrict__ info)
 {
@@ -148,14 +148,19 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
                 piv[0] = pn;
                 piv[1] = ipn;
             }
-            double vc[PE];
+            // two batches of 16: all LDS reads of a batch first, then its FMAs (keeps the kernel under 128 VGPRs so that
+            // 8 waves fit next to one resident GEMM workgroup: 512 - 240 = 272 registers per SIMD lane)
 #pragma unroll
-            for (int k = 0; k < PE; ++k) {
-                const int c = cg + PG * k;
-                vc[k] = Vc[c + ((c > j) ? 0 : PB)];
+            for (int k0 = 0; k0 < PE; k0 += 16) {
+                double vc[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int c = cg + PG * (k0 + k);
+                    vc[k] = Vc[c + ((c > j) ? 0 : PB)];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k0 + k] = __builtin_fma(-lij, vc[k], a[k0 + k]);
             }
-#pragma unroll
-            for (int k = 0; k < PE; ++k) a[k] = __builtin_fma(-lij, vc[k], a[k]);
         }
         lds_barrier();
     }

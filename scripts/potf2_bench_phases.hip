@@ -5,8 +5,9 @@
 #include <cmath>
 namespace fr {
 constexpr int PB = 128;
-constexpr int PT = 1024;  // threads
-constexpr int PE = 16;    // elements per thread
+constexpr int PT = 512;  // threads: 8 waves x <= 128 VGPRs fit beside ONE resident GEMM workgroup (look-ahead overlap)
+constexpr int PE = 32;   // elements per thread
+constexpr int PG = 4;    // column groups
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the
 // column store of every step to be acknowledged by memory (~2 us per step, 6x the rest of the step).
@@ -15,23 +16,54 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// pivot rule for one diagonal value (executed by ONE thread per step); returns the pivot, logs substitutions/failures
-__device__ __forceinline__ double pivot_of(double d, int mode, double sub, int64_t col, int64_t* __restrict__ info)
+// sqrt(d) and 1/sqrt(d) from ONE v_rsq_f64 seed and Newton steps (~15 dependent instructions).  The step's critical
+// path is sqrt -> reciprocal -> column scaling; libm's sqrt + two IEEE divisions are ~100 dependent f64 instructions,
+// most of a step.  Results agree with sqrt()/division to the last bit or 1 ulp (the oracle comparison bounds it).
+__device__ __forceinline__ void sqrt_rsqrt(double d, double& p, double& ip)
 {
-    if (mode == 3) return d;        // already a factor
-    if (mode == 2) return sqrt(d);  // insert_column: plain sqrt
-    if (d > 0.0) return sqrt(d);
+    if (d == 0.0) {  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
+        p = 0.0;
+        ip = __builtin_inf();
+        return;
+    }
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    double q = d * r;
+    q = __builtin_fma(0.5 * r, __builtin_fma(-q, q, d), q);  // sqrt(d), corrected
+    r = r * __builtin_fma(-q, r, 2.0);                        // 1 / q
+    p = q;
+    ip = r;
+}
+
+// pivot rule for one diagonal value (executed by ONE thread per step): pivot and its reciprocal; logs substitutions
+// and failures
+__device__ __forceinline__ void pivot_of(double d, int mode, double sub, int64_t col, int64_t* __restrict__ info, double& p,
+                                         double& ip)
+{
+    if (mode == 3) {  // already a factor
+        p = d;
+        ip = 1.0 / d;
+        return;
+    }
+    if (mode == 2 || d > 0.0) {  // insert_column: plain sqrt (NaN for d < 0)
+        sqrt_rsqrt(d, p, ip);
+        return;
+    }
     if (mode == 1 && sub > 0.0) {
         const int64_t q = info[1];
         info[3 + q] = col;
         info[1] = q + 1;
-        return sqrt(sub);
+        sqrt_rsqrt(sub, p, ip);
+        return;
     }
     if (info[0] == 0) info[0] = 1 + col;
-    return __builtin_nan("");
+    p = __builtin_nan("");
+    ip = p;
 }
 
-__global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
+__global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
                                                    int64_t* __restrict__ info)
 {
@@ -43,29 +75,26 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
     __shared__ __attribute__((aligned(16))) double piv[2];  // {pivot, 1/pivot} of the current step
     const int t = threadIdx.x;
     const int i = t & (PB - 1);
-    const int cg = t >> 7;  // 8 column groups of 128 threads (two waves): cg is wave-uniform
+    const int cg = t >> 7;  // 4 column groups of 128 threads (two waves): cg is wave-uniform
     const bool row_ok = i < n;
     const int wave_row0 = i & 64;  // first row held by this wave
 
-    double a[PE];  // working element (i, cg + 8k): A, then (once column c is done) the inverse X
-    double l[PE];  // finished factor entries L(i, cg + 8k), stored after the loop (no global traffic inside it)
+    double a[PE];  // working element (i, cg + 4k): A, then (once column c is done) the inverse X
 #pragma unroll
     for (int k = 0; k < PE; ++k) {
-        const int c = cg + 8 * k;
+        const int c = cg + PG * k;
         a[k] = (row_ok && c < n && i >= c) ? A[i + (int64_t)c * lda] : 0.0;
-        l[k] = 0.0;
     }
     if (t == 0) {
-        const double p0 = pivot_of(a[0], mode, sub, col0, info);
+        double p0, ip0;
+        pivot_of(a[0], mode, sub, col0, info, p0, ip0);
         piv[0] = p0;
-        piv[1] = 1.0 / p0;
+        piv[1] = ip0;
     }
     lds_barrier();
 
-    long long s1=0,s2=0,s3=0,s4=0;
     for (int j = 0; j < n; ++j) {
-        const long long q0 = __builtin_amdgcn_s_memtime();
-        const int jcg = j & 7, jk = j >> 3;
+        const int jcg = j & (PG - 1), jk = j / PG;
         // ---- phase 1: owners of column j / row j scale and publish (sqrt and reciprocal were computed by ONE thread
         //      at the end of the previous step)
         const double p = piv[0], ip = piv[1];
@@ -74,20 +103,24 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
             for (int k = 0; k < PE; ++k) {
                 if (k == jk) {  // uniform: exactly one of the 16 statically indexed bodies runs
                     const double v = a[k];
-                    const double q = (mode == 3) ? v : v / p;  // true division, as `col /= denom`
+                    // col /= denom: quotient by reciprocal + one residual correction (== IEEE division except for rare
+                    // last-bit ties); the reciprocal is already on hand, a full division is ~35 dependent instructions
+                    double q = v * ip;
+                    q = __builtin_fma(__builtin_fma(-q, p, v), ip, q);
+                    q = (mode == 3) ? v : q;
                     const bool diag = (i == j);
                     const double lv = diag ? p : q;  // L(i, j)
                     Lc[i] = lv;
                     Vc[i] = (mode == 3) ? 0.0 : lv;
-                    l[k] = lv;
+                    if (mode != 3) A[i + (int64_t)j * lda] = lv;  // fire and forget: the barriers wait on LDS only
                     a[k] = diag ? ip : -q * ip;  // X(i, j): 1/p on the diagonal, else 0 - L(i,j) X(j,j)
                 }
             }
         }
-        if (i == j) {  // the 8 threads holding row j: scale and publish X(j, c), c < j
+        if (i == j) {  // the 4 threads holding row j: scale and publish X(j, c), c < j
 #pragma unroll
             for (int k = 0; k < PE; ++k) {
-                const int c = cg + 8 * k;
+                const int c = cg + PG * k;
                 const double sc = a[k] * ip;
                 const bool lt = c < j;
                 a[k] = lt ? sc : a[k];
@@ -103,27 +136,33 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
             const bool act = (i > j) && row_ok;
             const double lraw = Lc[i];
             const double lij = act ? lraw : 0.0;
-            if (act && i == j + 1 && cg == ((j + 1) & 7)) {
+            if (act && i == j + 1 && cg == ((j + 1) & (PG - 1))) {
                 // owner of the next diagonal element: take the next pivot now; the other waves overlap it with their
                 // 16 updates
-                const int nk = (j + 1) >> 3;
+                const int nk = (j + 1) / PG;
                 double nd = 0.0;
 #pragma unroll
                 for (int k = 0; k < PE; ++k)
                     if (k == nk) nd = a[k];
                 if (mode != 3) nd = nd - lij * lij;
-                const double pn = pivot_of(nd, mode, sub, col0 + j + 1, info);
+                double pn, ipn;
+                pivot_of(nd, mode, sub, col0 + j + 1, info, pn, ipn);
                 piv[0] = pn;
-                piv[1] = 1.0 / pn;
+                piv[1] = ipn;
             }
-            double vc[PE];
+            // two batches of 16: all LDS reads of a batch first, then its FMAs (keeps the kernel under 128 VGPRs so that
+            // 8 waves fit next to one resident GEMM workgroup: 512 - 240 = 272 registers per SIMD lane)
 #pragma unroll
-            for (int k = 0; k < PE; ++k) {
-                const int c = cg + 8 * k;
-                vc[k] = Vc[c + ((c > j) ? 0 : PB)];
+            for (int k0 = 0; k0 < PE; k0 += 16) {
+                double vc[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int c = cg + PG * (k0 + k);
+                    vc[k] = Vc[c + ((c > j) ? 0 : PB)];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k0 + k] = __builtin_fma(-lij, vc[k], a[k0 + k]);
             }
-#pragma unroll
-            for (int k = 0; k < PE; ++k) a[k] = __builtin_fma(-lij, vc[k], a[k]);
         }
         const long long q3 = __builtin_amdgcn_s_memtime();
         lds_barrier();
@@ -131,12 +170,10 @@ __global__ __launch_bounds__(PT) void potf2_kernel(double* __restrict__ A, int64
         s1+=q1-q0; s2+=q2-q1; s3+=q3-q2; s4+=q4-q3;
     }
 
-    if ((t & 63) == 0 && info) { int w = t >> 6; info[8+4*w]=s1; info[9+4*w]=s2; info[10+4*w]=s3; info[11+4*w]=s4; }
 #pragma unroll
     for (int k = 0; k < PE; ++k) {
-        const int c = cg + 8 * k;
+        const int c = cg + PG * k;
         if (row_ok && c < n && i >= c) {
-            if (mode != 3) A[i + (int64_t)c * lda] = l[k];
             if (inv) inv[i + (int64_t)c * ldinv] = a[k];
         } else if (row_ok && c < n && inv) {
             inv[i + (int64_t)c * ldinv] = 0.0;
@@ -151,7 +188,7 @@ int main(){
   double *A,*inv; int64_t* info; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n));
   for(int rep=0;rep<2;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
-    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(1024),0,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info); (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),0,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info); (void)hipDeviceSynchronize();
     int64_t hi[80]; (void)hipMemcpy(hi,info,8*80,hipMemcpyDeviceToHost);
     if (rep) for (int w=0; w<16; w+=3) printf("wave %2d: per-step ticks P1 %5.0f  bar1 %5.0f  P2 %5.0f  bar2 %5.0f\n",w,hi[8+4*w]/128.0,hi[9+4*w]/128.0,hi[10+4*w]/128.0,hi[11+4*w]/128.0);
   }
