@@ -67,27 +67,33 @@ static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, doubl
     return launch_potf2(ctx, A, ld, sb, 0, 3, 0.0, inv, IB, nullptr);
 }
 
-// Factor the kb-wide column block starting at (j0, j0): diagonal 128-blocks, the TRSM of everything below them
-// and the left-looking update of the block's remaining columns.  Needs the block fully updated by earlier panels.
+// Factor the kb-wide column block starting at column k (rows k..n), which must already carry every update of the
+// earlier panels.  Recursive halving down to the 128-wide inverse blocks: the second half of the block is updated by
+// the first with ONE GEMM of depth kb/2 (instead of a depth-128 GEMM per 128 columns) -- the read-modify-write of the
+// result tile is a fixed cost per tile, so the deeper the contraction the closer the GEMM runs to the MFMA rate.
 static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
                         double sub, double* dinv, int64_t* info, double* T)
 {
-    for (int64_t s = 0; s < kb; s += IB) {
-        const int64_t j = k + s, sb = imin(IB, kb - s);
-        double* inv = dinv + (j / IB) * INV_ELEMS;
-        FR_TRY(factor_block128(ctx, A + j + j * ld, ld, sb, col0 + j, mode, sub, inv, info, T));
-        const int64_t below = n - (j + sb);
+    if (kb <= IB) {
+        double* inv = dinv + (k / IB) * INV_ELEMS;
+        FR_TRY(factor_block128(ctx, A + k + k * ld, ld, kb, col0 + k, mode, sub, inv, info, T));
+        const int64_t below = n - (k + kb);
         if (below > 0) {
-            // K5: panel TRSM  B <- B * L_jj^-T  as a GEMM against the explicit inverse
-            double* B = A + (j + sb) + j * ld;
-            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, sb, sb, B, ld, false, inv, IB, false, 1.0, 0.0, B, ld));
-            const int64_t right = kb - (s + sb);
-            if (right > 0)  // remaining columns of this outer block (left-looking inside the block)
-                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, right, sb, B, ld, false, B, ld, false, -1.0, 1.0,
-                            A + (j + sb) + (j + sb) * ld, ld));
+            // K5: panel TRSM  B <- B * L_kk^-T  as a GEMM against the explicit inverse (in place: one tile column)
+            double* B = A + (k + kb) + k * ld;
+            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, kb, kb, B, ld, false, inv, IB, false, 1.0, 0.0, B, ld));
         }
+        return FR_OK;
     }
-    return FR_OK;
+    const int64_t kb1 = ((kb / IB + 1) / 2) * IB;  // first half, a multiple of 128
+    FR_TRY(factor_panel(ctx, A, ld, n, k, kb1, col0, mode, sub, dinv, info, T));
+    const int64_t below = n - (k + kb1);
+    if (below > 0) {
+        const double* P1 = A + (k + kb1) + k * ld;  // rows below the first half, its kb1 columns
+        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, kb - kb1, kb1, P1, ld, false, P1, ld, false, -1.0, 1.0,
+                    A + (k + kb1) + (k + kb1) * ld, ld));
+    }
+    return factor_panel(ctx, A, ld, n, k + kb1, kb - kb1, col0, mode, sub, dinv, info, T);
 }
 
 // Multi-GPU: block column b (width nb) of the matrix being factored is owned by rank b % world.

@@ -92,6 +92,9 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
     // Lc[x]      : L(x, j), the scaled column j (x > j)                          -- the row multiplier of the step
     // Vc[c]      : L(c, j) for c > j (0 in mode 3: no factor update), Vc[PB + c] : X(j, c) for c < j (0 for c >= j)
     // so that the update of element (i, c) is  a -= Lc[i] * Vc[c > j ? c : PB + c]  with no per-element predicate.
+    // The panel is the critical path of the look-ahead pipeline and this workgroup shares its CU with a trailing-update
+    // GEMM workgroup: take the issue slots first (raised wave priority), the GEMM waves fill what is left.
+    __builtin_amdgcn_s_setprio(3);
     __shared__ double Lc[PB];
     __shared__ double Vc[2 * PB];
     __shared__ __attribute__((aligned(16))) double piv[2];  // {pivot, 1/pivot} of the current step
