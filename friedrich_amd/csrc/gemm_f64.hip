@@ -44,6 +44,8 @@ struct GemmArgs {
     double alpha, beta;
     int lower;
     int64_t tiles_m, tiles_n;
+    int sw_log2;                       // super-tile = (64 >> sw_log2) x (1 << sw_log2) tiles
+    int64_t super_m, nsuper, per_xcd;  // super-tiles along m, in total, per XCD
     // multi-GPU column ownership: a tile is computed only by the rank owning its block column
     // ((own_col0 + n0) / own_nb) % own_world == own_rank; own_world <= 1 disables the filter
     int own_world, own_rank;
@@ -117,24 +119,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
 {
     __shared__ double lds[4 * TILE_ELEMS];  // [stage][A|B][TILE_ELEMS]
 
-    // XCD-aware tile assignment: block b runs on XCD b % 8 (observed dispatch rule; speed only); give each XCD a
-    // contiguous run of tiles so neighbouring tiles (shared operand panels) hit the same private L2.
-    // (An 8x8 "super-tile" order was measured and lost 7 % on the SYRK and 30 % on the solves: dropped.)
-    const int64_t nblk = gridDim.x;
+    // Tile assignment.  Block b runs on XCD b % 8 (observed dispatch rule; used for speed only).  Each XCD gets a
+    // contiguous run of 64-tile "super-tiles" (8 x 8 tiles): an XCD keeps ~64 workgroups resident (32 CUs x 2), i.e. about
+    // one super-tile at a time, whose K-slices of 8 + 8 operand panels are each fetched into the XCD's L2 once and hit 7
+    // times -- with a row-major tile order every B slice misses (L2 hit rate 46 %, measured) and the fabric traffic
+    // (operand misses + the C read-modify-write) approaches what HBM/Infinity Cache can deliver.
+    // Deep contractions (the recursive solves, K up to n/2) keep the plain order instead: over hundreds of K-steps the
+    // workgroups of a super-tile drift apart and 16 live panels no longer fit the 4 MiB L2 (measured: -35 % on predict).
     const int64_t b = blockIdx.x;
-    const int64_t q = nblk >> 3, r8 = nblk & 7, xcd = b & 7;
-    const int64_t tlin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
-
+    const int64_t xcd = b & 7;
     int64_t tm, tn;
-    if (g.lower) {
-        int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
-        while (row * (row + 1) / 2 > tlin) --row;
-        while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
-        tm = row;
-        tn = tlin - row * (row + 1) / 2;
+    if (g.nsuper > 0) {
+        const int64_t tlin = xcd * (g.per_xcd * 64) + (b >> 3);
+        const int64_t sidx = tlin >> 6;
+        const int within = (int)(tlin & 63);
+        if (sidx >= g.nsuper) return;
+        if (g.lower) {
+            int64_t row = (int64_t)((sqrt(8.0 * (double)sidx + 1.0) - 1.0) * 0.5);
+            while (row * (row + 1) / 2 > sidx) --row;
+            while ((row + 1) * (row + 2) / 2 <= sidx) ++row;
+            tm = row * 8 + (within & 7);
+            tn = (sidx - row * (row + 1) / 2) * 8 + (within >> 3);
+            if (tn > tm || tm >= g.tiles_m) return;
+        } else {
+            const int sh = 64 >> g.sw_log2;
+            tm = (sidx % g.super_m) * sh + (within & (sh - 1));
+            tn = (sidx / g.super_m) * (1 << g.sw_log2) + (within >> (6 - g.sw_log2));
+            if (tm >= g.tiles_m || tn >= g.tiles_n) return;
+        }
     } else {
-        tm = tlin % g.tiles_m;
-        tn = tlin / g.tiles_m;
+        // plain order: each XCD gets a contiguous run of the tile list
+        const int64_t nblk = gridDim.x;
+        const int64_t q = nblk >> 3, r8 = nblk & 7;
+        const int64_t tlin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+        if (g.lower) {
+            int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
+            while (row * (row + 1) / 2 > tlin) --row;
+            while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
+            tm = row;
+            tn = tlin - row * (row + 1) / 2;
+        } else {
+            tm = tlin % g.tiles_m;
+            tn = tlin / g.tiles_m;
+        }
     }
     const int64_t m0 = tm * BM, n0 = tn * BN;
     if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) return;
@@ -281,14 +308,49 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
     // load-modify-store loop therefore pays one full memory round trip per element (64 per lane).  The loads
     // of a whole 16-column strip are issued back to back into registers, one strip ahead of the stores.
     const bool use_c = g.beta != 0.0;
+    const bool interior = a_fast && b_fast;  // whole 128 x 128 tile inside D: no per-element predicate
+    auto c_index = [&](int nt, int r, int mt, int64_t& m, int64_t& n) {
+        n = n0 + wn * 64 + nt * 16 + lq + 4 * r;
+        m = m0 + wm * 64 + mt * 16 + l15;
+    };
+    if (interior && use_c) {
+        // Interior tile: straight-line code, THREE of the four 16-column strips of C in flight at once (the registers of
+        // the K-loop's prefetch / fragment buffers are dead here); the fourth is issued as soon as strip 0 is stored.
+        // Measured before this change: the epilogue was 38 % of a K = 512 tile's lifetime (4 dependent round trips).
+        const double* cbase = g.Cin + (m0 + wm * 64 + l15) + (n0 + wn * 64 + lq) * g.ldcin;
+        double* dbase = g.D + (m0 + wm * 64 + l15) + (n0 + wn * 64 + lq) * g.ldd;
+        double c0[16], c1[16], c2[16];
+        auto ld_strip = [&](int nt, double (&c)[16]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) c[r * 4 + mt] = cbase[mt * 16 + (int64_t)(nt * 16 + 4 * r) * g.ldcin];
+        };
+        auto st_strip = [&](int nt, const double (&c)[16]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    dbase[mt * 16 + (int64_t)(nt * 16 + 4 * r) * g.ldd] = g.alpha * acc[nt][mt][r] + g.beta * c[r * 4 + mt];
+        };
+        ld_strip(0, c0);
+        ld_strip(1, c1);
+        ld_strip(2, c2);
+        st_strip(0, c0);
+        ld_strip(3, c0);
+        st_strip(1, c1);
+        st_strip(2, c2);
+        st_strip(3, c0);
+        return;
+    }
     double cv[2][16];
     auto load_strip = [&](int nt, double (&c)[16]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t n = n0 + wn * 64 + nt * 16 + lq + 4 * r;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int64_t m = m0 + wm * 64 + mt * 16 + l15;
+                int64_t m, n;
+                c_index(nt, r, mt, m, n);
                 c[r * 4 + mt] = (n < g.N && m < g.M) ? g.Cin[m + n * g.ldcin] : 0.0;
             }
         }
@@ -299,10 +361,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
         if (use_c && nt + 1 < 4) load_strip(nt + 1, cv[(nt + 1) & 1]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t n = n0 + wn * 64 + nt * 16 + lq + 4 * r;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int64_t m = m0 + wm * 64 + mt * 16 + l15;
+                int64_t m, n;
+                c_index(nt, r, mt, m, n);
                 double v = g.alpha * acc[nt][mt][r];
                 if (use_c) v += g.beta * cv[nt & 1][r * 4 + mt];
                 if (n < g.N && m < g.M) g.D[m + n * g.ldd] = v;
@@ -335,16 +397,34 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
     g.own_col0 = d.own_col0;
     g.tiles_m = (d.M + BM - 1) / BM;
     g.tiles_n = (d.N + BN - 1) / BN;
-    int64_t ntiles;
     double flops;
+    int64_t ntiles;
     if (d.lower) {
         if (d.M != d.N) return set_err(ctx, FR_INVALID_ARGUMENT, "lower-mode GEMM needs a square result");
+        g.sw_log2 = 3;
+        g.super_m = (g.tiles_m + 7) / 8;
+        g.nsuper = g.super_m * (g.super_m + 1) / 2;
         ntiles = g.tiles_m * (g.tiles_m + 1) / 2;
         flops = (double)d.M * (double)(d.M + 1) * (double)g.K;  // 2 * M(M+1)/2 * K
     } else {
+        int swl = 0;
+        while ((1 << swl) < g.tiles_n && swl < 3) ++swl;
+        g.sw_log2 = swl;
+        const int64_t sh = 64 >> swl, sw = 1 << swl;
+        g.super_m = (g.tiles_m + sh - 1) / sh;
+        g.nsuper = g.super_m * ((g.tiles_n + sw - 1) / sw);
         ntiles = g.tiles_m * g.tiles_n;
         flops = 2.0 * (double)d.M * (double)d.N * (double)g.K;
     }
+    g.per_xcd = (g.nsuper + 7) / 8;
+    bool use_super = g.K <= 2048 && g.nsuper >= 128;
+    if (ctx->gemm_tile == 1) use_super = false;
+    if (ctx->gemm_tile == 2 && d.lower) use_super = false;
+    if (ctx->gemm_tile == 3 && !d.lower) use_super = false;
+    if (use_super)
+        ntiles = g.per_xcd * 8 * 64;
+    else
+        g.nsuper = 0;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
     const double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
     ProfScope ps(ctx, d.prof_cls, flops, bytes);

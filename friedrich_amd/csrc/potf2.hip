@@ -30,6 +30,7 @@ constexpr int PB = 128;
 constexpr int PT = 512;  // threads: 8 waves x <= 128 VGPRs fit beside ONE resident GEMM workgroup (look-ahead overlap)
 constexpr int PE = 32;   // elements per thread
 constexpr int PG = 4;    // column groups
+constexpr int PBATCH = 8;  // LDS reads in flight per thread in the update phase
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the
 // column store of every step to be acknowledged by memory (~2 us per step, 6x the rest of the step).
@@ -176,15 +177,15 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
             // two batches of 16: all LDS reads of a batch first, then its FMAs (keeps the kernel under 128 VGPRs so that
             // 8 waves fit next to one resident GEMM workgroup: 512 - 240 = 272 registers per SIMD lane)
 #pragma unroll
-            for (int k0 = 0; k0 < PE; k0 += 16) {
-                double vc[16];
+            for (int k0 = 0; k0 < PE; k0 += PBATCH) {
+                double vc[PBATCH];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
+                for (int k = 0; k < PBATCH; ++k) {
                     const int c = cg + PG * (k0 + k);
                     vc[k] = Vc[c + ((c > j) ? 0 : PB)];
                 }
 #pragma unroll
-                for (int k = 0; k < 16; ++k) a[k0 + k] = __builtin_fma(-lij, vc[k], a[k0 + k]);
+                for (int k = 0; k < PBATCH; ++k) a[k0 + k] = __builtin_fma(-lij, vc[k], a[k0 + k]);
             }
         }
         lds_barrier();
