@@ -330,6 +330,12 @@ int chol_fetch_info(fr_chol* c)
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     c->fail_col = head[0] - 1;
     c->n_subst = head[1];
+    if (c->n_subst < 0 || c->n_subst > c->n) {
+        char msg[128];
+        snprintf(msg, sizeof(msg), "corrupt substitution log: %lld entries for n = %lld", (long long)head[1], (long long)c->n);
+        c->n_subst = 0;
+        return set_err(ctx, FR_HIP_ERROR, msg);
+    }
     c->subst.resize((size_t)c->n_subst);
     if (c->n_subst > 0) {
         FR_HIP(ctx, hipMemcpyAsync(c->subst.data(), c->info + 3, sizeof(int64_t) * (size_t)c->n_subst,
