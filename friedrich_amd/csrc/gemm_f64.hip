@@ -417,9 +417,12 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
         flops = 2.0 * (double)d.M * (double)d.N * (double)g.K;
     }
     g.per_xcd = (g.nsuper + 7) / 8;
+    // measured inside the factorisation (scripts/order_ab.py): super-tiles pay for large shallow full products only; the
+    // lower-mode SYRK next to the panel stream is ~4 % faster in plain order.  Option gemm_tile: 0 = this default,
+    // 1 = never, 2 = both modes, 3 = lower mode only (A/B probes).
     bool use_super = g.K <= 2048 && g.nsuper >= 128;
+    if (ctx->gemm_tile == 0 && d.lower) use_super = false;
     if (ctx->gemm_tile == 1) use_super = false;
-    if (ctx->gemm_tile == 2 && d.lower) use_super = false;
     if (ctx->gemm_tile == 3 && !d.lower) use_super = false;
     if (use_super)
         ntiles = g.per_xcd * 8 * 64;

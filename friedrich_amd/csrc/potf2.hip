@@ -14,17 +14,21 @@
 //
 // The factorisation of a diagonal block is a chain of n dependent pivots: what matters is the latency of ONE step, and
 // this kernel sits on the critical path of the look-ahead pipeline (N such steps per fit, next to a chip full of GEMM
-// workgroups).  So the serial part runs inside ONE wavefront with no barrier and no LDS round trip:
+// workgroups).  So the serial part runs inside ONE wavefront with no barrier:
 //
 //   * the 128 x 128 block is cut into 32 x 32 sub-blocks kept in LDS (lower triangle: 10 slots, 80 KiB, which still
 //     fits beside one resident GEMM workgroup);
-//   * F_b: wave 0 factors diagonal sub-block b wave-synchronously.  Lane i (< 32) owns row i of the sub-block in 32
-//     registers; step j broadcasts the pivot and L(c, j) with v_readlane (scalar operands of the FMAs) -- ~120
-//     instructions per step, fully unrolled.  The inverse rides in the dead columns (slot c < j holds X(i, c)), and
-//     lanes 32..63 carry the 32 rows below the sub-block, whose triangular solve is the same instruction stream;
-//   * the block row/column updates between two F steps are small 32^3 products spread over all 8 waves (LDS-broadcast
-//     operands):  T: L_ib = A_ib X_bb^T,  U: A_ik -= L_ib L_kb^T,  and the inverse W = L^-1 by block elimination
-//     (W_bc = X_bb W_bc;  W_ic -= L_ib W_bc;  W_ib = -L_ib X_bb), which overwrites the L sub-blocks once they are dead.
+//   * F_b: wave 0 factors diagonal sub-block b wave-synchronously.  Row i of the sub-block is split over lanes i and
+//     i + 32 (16 register slots each).  Step j writes the scaled column to LDS (one ds_write: the sub-block's own slot,
+//     dead once it is in registers) and reads L(c, j) back as broadcasts (operands of the rank-1 FMAs), all in flight
+//     at once.  The next pivot does not wait for that
+//     round trip: lane j + 1 updates its own diagonal element from its own L(j + 1, j), one v_readlane publishes it,
+//     and the sqrt / reciprocal chain is interleaved stage by stage with the rank-1 updates;
+//   * T: the rows below (sub-blocks b + 1 .. 3) are solved by one update wave each with the same right-looking
+//     recurrence (L_bb broadcast from LDS); X_bb = L_bb^-1 comes from the same routine applied to e_c;
+//   * the other updates are 32^3 products spread over the update waves (LDS-broadcast operands):
+//     U: A_ik -= L_ib L_kb^T, and the inverse W = L^-1 by block elimination (W_bc = X_bb W_bc;  W_ic -= L_ib W_bc;
+//     W_ib = -L_ib X_bb), which overwrites the L sub-blocks once they are dead.
 //
 // Factor columns are stored to global memory as they are produced (fire and forget: barriers order LDS only).
 #include "fr_internal.hpp"
@@ -74,6 +78,14 @@ __device__ __forceinline__ int slot_of(int i, int k)
     return (i * (i + 1) / 2 + k) * SBE;
 }
 
+// Optimisation barrier: the value must be materialised in a VGPR at this point of the program.  Without it the
+// instruction selector's scheduler sinks every rank-1 FMA down to the step that next reads the slot (a legal but
+// pathological order: all multipliers and broadcast values of all steps stay live, hundreds of spills).
+__device__ __forceinline__ void pin(double& x)
+{
+    asm volatile("" : "+v"(x));
+}
+
 // 32^3 products of the update waves.  Lane (r, h) accumulates NC consecutive result columns of row r; the row operand
 // A(r, k) is read from LDS as it is needed (a rolled k loop: with the row held in registers and the loop unrolled the
 // instruction selector hoists every LDS read to the top and spills hundreds of registers).
@@ -84,7 +96,7 @@ __device__ __forceinline__ void prod_nt(const double* Arow, const double* B, int
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0;
     const double* bp = B + c0;
-#pragma unroll 2
+#pragma unroll 4
     for (int k = 0; k < SB; ++k) {
         const double a = Arow[SB * k];
         const double2* b2 = reinterpret_cast<const double2*>(bp + SB * k);
@@ -116,28 +128,56 @@ __device__ __forceinline__ void prod_nn(const double* Arow, const double* B, int
     }
 }
 
+// ---- split-row layout of the wave-synchronous routines -------------------------------------------------------------
+// A vector of 32 (a row of a sub-block, or a column of the inverse) is held by TWO lanes: lane (r, h) = r + 32 h owns
+// the 16 slots c = 16 h + k.  64 lanes work on one 32 x 32 sub-block, a lane needs 32 VGPRs for its slots and 32 for a
+// whole column of broadcasts, so every LDS read of a step is in flight at once (a ~130-cycle latency paid once per
+// step, behind the pivot chain, instead of once per FMA).
+constexpr int HB = 16;  // slots per lane
+
+// value of the same row in half H, delivered to both halves (one v_permlane32_swap per dword)
+template <int H>
+__device__ __forceinline__ double bcast_half(double x)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[H], (int)rl[H]);
+}
+
+// broadcasts of one column J of the factor image: L(16 h + k, J) for the lane's 16 slots, as 8 aligned pairs
+struct ColBcast {
+    double2 v[HB / 2];
+};
+
+constexpr int first_live_slot(int J)  // slots k >= this are still live in some half after column J
+{
+    return J < HB ? 0 : (J % HB) + 1;
+}
+
+template <int J, int P>
+__device__ __forceinline__ void col_load(ColBcast& cb, const double* bufh)
+{
+    if constexpr (P < HB / 2) {
+        if constexpr (2 * P + 1 >= first_live_slot(J)) cb.v[P] = *reinterpret_cast<const double2*>(bufh + 2 * P + SB * J);
+        col_load<J, P + 1>(cb, bufh);
+    }
+}
+
 // ---- F_b: wave-synchronous factorisation of diagonal sub-block b (executed by wave 0 only) --------------------------
-// lanes 0..31 : row (lane) of sub-block (b, b);  lanes 32..63 : row (lane - 32) of sub-block (b + 1, b) (ride-along solve)
 struct FState {
-    double* gptr;    // &A[row of this lane, current column]
-    double* rslot;   // ride-along L sub-block in LDS
+    double* gptr;       // &A[row r, current column]
+    double* cptr;       // &image[r]: where the owner half writes its element of the current column
+    const double* bufh; // &image[16 h]: base of this lane's broadcast reads
     int64_t lda, colbase;  // colbase: global column index of the sub-block's first column
     double p_exc, ip_exc;  // replacement pivot of the exception rule (NaN = failure)
-    int lane, r, mode, ncols_ok;  // ncols_ok: columns j < ncols_ok lie inside the matrix
-    bool lo, ride, grow_ok;
+    int r, h, lane, mode, ncols_ok;  // ncols_ok: columns j < ncols_ok lie inside the matrix
+    bool row_ok;
 };
 
 // The pivot of step J + 1 (sqrt and reciprocal of the next diagonal value) is a chain of ~13 dependent f64 operations.
-// It is cut into stages that the step interleaves with its 30 independent rank-1 updates (two updates per stage,
-// pinned with sched_barrier) so that the chain's latency disappears behind the update stream.
-// Optimisation barrier: the value must be materialised in a VGPR at this point of the program.  Without it the
-// instruction selector's scheduler sinks every rank-1 FMA down to the step that next reads the slot (a legal but
-// pathological order: all multipliers and broadcast scalars of all steps stay live, hundreds of spills).
-__device__ __forceinline__ void pin(double& x)
-{
-    asm volatile("" : "+v"(x));
-}
-
+// It is cut into stages: the first ones run while the broadcast reads of the step are in flight, the others are
+// interleaved with the rank-1 updates (pinned with sched_barrier) so that the chain's latency hides behind them.
 struct PivotChain {
     double d, r, h, q, t;
 };
@@ -154,7 +194,10 @@ __device__ __forceinline__ void chain_stage(PivotChain& c)
         if constexpr (K == 5) c.q = c.d;
         if constexpr (K == 0 || K == 2 || K == 4) pin(c.r);
         if constexpr (K == 1 || K == 3) pin(c.t);
-    } else {  // same arithmetic as sqrt_rsqrt()
+    } else {
+        // v_rsq_f64 seed + two Newton steps give r = 1 / sqrt(d) to about an ulp: that IS the reciprocal pivot (the
+        // column scaling below corrects its quotient with one residual step against p, so r needs no further polish);
+        // p = sqrt(d) = d r with one Heron correction.  r is ready after stage 6, p after stage 9.
         if constexpr (K == 0) {
             c.r = __builtin_amdgcn_rsq(c.d);
             c.h = -0.5 * c.d;
@@ -171,17 +214,30 @@ __device__ __forceinline__ void chain_stage(PivotChain& c)
         }
         if constexpr (K == 8) c.t = __builtin_fma(-c.q, c.q, c.d);
         if constexpr (K == 9) c.q = __builtin_fma(c.h, c.t, c.q);
-        if constexpr (K == 10) c.t = __builtin_fma(-c.q, c.r, 2.0);
-        if constexpr (K == 11) c.r = c.r * c.t;
-        if constexpr (K == 12) {
+        if constexpr (K == 10) {
             const bool zero = (c.d == 0.0);  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
             c.q = zero ? 0.0 : c.q;
             c.r = zero ? __builtin_inf() : c.r;
         }
-        if constexpr (K == 0 || K == 3 || K == 6 || K == 11 || K == 12) pin(c.r);
-        if constexpr (K == 1 || K == 2 || K == 4 || K == 5 || K == 8 || K == 10) pin(c.t);
-        if constexpr (K == 7 || K == 9 || K == 12) pin(c.q);
+        if constexpr (K == 0 || K == 3 || K == 6 || K == 10) pin(c.r);
+        if constexpr (K == 1 || K == 2 || K == 4 || K == 5 || K == 8) pin(c.t);
+        if constexpr (K == 7 || K == 9 || K == 10) pin(c.q);
         if constexpr (K == 0 || K == 7) pin(c.h);
+    }
+}
+
+template <bool M3>
+struct ChainShape {
+    static constexpr int NST = M3 ? 6 : 11;
+    static constexpr int HEAD = M3 ? 6 : 11;  // stages issued back to back while the broadcasts are in flight
+};
+
+template <bool M3, int K0, int K1>
+__device__ __forceinline__ void chain_run(PivotChain& c)
+{
+    if constexpr (K0 < K1) {
+        chain_stage<M3, K0>(c);
+        chain_run<M3, K0 + 1, K1>(c);
     }
 }
 
@@ -197,72 +253,72 @@ __device__ __forceinline__ void pivot_select(const FState& st, double d, int j, 
     excmask |= bad ? (1u << j) : 0u;
 }
 
-// the u-th independent update of step J: slots J + 2 .. 31 (factor: A(i, c) -= L(i, J) L(c, J)), then slots 0 .. J - 1
-// (inverse, riding in the dead columns: X(i, c) -= L(i, J) / p * X'(J, c))
-template <bool M3, int J, int U>
-__device__ __forceinline__ void step_update(double (&a)[SB], double l, double m)
+// pairs P .. of step J: a(r, c) -= L(r, J) L(c, J) for the lane's slots, one chain stage per pair.  Slots whose column
+// is already final are dead registers in this routine: they are updated along with the others (no predicate).
+template <int J, int P>
+__device__ __forceinline__ void f_pairs(double (&a)[HB], double l, PivotChain& ch, const ColBcast& cb)
 {
-    constexpr int NF = M3 ? 0 : ((SB - J - 2) > 0 ? (SB - J - 2) : 0);
-    if constexpr (U < NF) {
-        constexpr int c = J + 2 + U;
-        const double s = readlane_f64(l, c);  // L(c, J)
-        a[c] = __builtin_fma(-l, s, a[c]);
-        pin(a[c]);
-    } else if constexpr (U - NF < J) {
-        constexpr int c = U - NF;
-        const double s = readlane_f64(a[c], J);  // X'(J, c)
-        a[c] = __builtin_fma(-m, s, a[c]);
-        pin(a[c]);
-    }
-}
-
-template <bool M3, int J, int U, int K>
-__device__ __forceinline__ void step_interleave(double (&a)[SB], double l, double m, PivotChain& ch)
-{
-    constexpr int NUPD = (M3 ? 0 : ((SB - J - 2) > 0 ? (SB - J - 2) : 0)) + J;
-    constexpr int NST = M3 ? 6 : 13;
-    if constexpr (U < NUPD || K < NST) {
-        if constexpr (K < NST && J + 1 < SB) chain_stage<M3, K>(ch);
-        step_update<M3, J, U>(a, l, m);
-        step_update<M3, J, U + 1>(a, l, m);
+    constexpr int NST = ChainShape<false>::NST, HEAD = ChainShape<false>::HEAD;
+    constexpr int P0 = first_live_slot(J) / 2;
+    if constexpr (P < HB / 2) {
+        if constexpr (2 * P >= first_live_slot(J)) {
+            a[2 * P] = __builtin_fma(-l, cb.v[P].x, a[2 * P]);
+            pin(a[2 * P]);
+        }
+        if constexpr (2 * P + 1 >= first_live_slot(J)) {
+            a[2 * P + 1] = __builtin_fma(-l, cb.v[P].y, a[2 * P + 1]);
+            pin(a[2 * P + 1]);
+        }
+        if constexpr (P >= P0 && HEAD + (P - P0) < NST && J + 1 < SB) chain_stage<false, HEAD + (P - P0)>(ch);
         __builtin_amdgcn_sched_barrier(0);
-        step_interleave<M3, J, U + 2, K + 1>(a, l, m, ch);
+        f_pairs<J, P + 1>(a, l, ch, cb);
     }
 }
 
 // one elimination step; J is a compile-time constant so that every register index and lane select is static
 // (template recursion instead of `#pragma unroll`: the body is beyond clang's pragma-unroll budget)
 template <bool M3, int J>
-__device__ __forceinline__ void f_step(double (&a)[SB], FState& st, double p, double ip, unsigned& excmask)
+__device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double p, double ip, unsigned& excmask)
 {
-    const int lane = st.lane;
-    // column J: col /= denom as reciprocal multiply + one residual correction
-    const double v = a[J];
+    constexpr int hJ = J / HB, kJ = J % HB;
+    // column J (owner half): col /= denom as reciprocal multiply + one residual correction
+    const double v = a[kJ];
     double q = v * ip;
     q = __builtin_fma(__builtin_fma(-q, p, v), ip, q);
     if constexpr (M3) q = v;
-    // L(i, J); the ride-along lanes are all below.  Padding rows / columns (block smaller than 128) are forced to
-    // stay the identity: 0 * inf = NaN would otherwise leak from an overflowing substituted factor into the log
-    const double l = (lane > J && st.grow_ok && J < st.ncols_ok) ? q : 0.0;
-    if constexpr (!M3) {
-        if (lane >= J && st.grow_ok && J < st.ncols_ok) *st.gptr = (lane == J) ? p : q;
-        st.gptr += st.lda;
-        if (!st.lo && st.ride) st.rslot[st.r + SB * J] = q;
+    // Padding rows / columns (block smaller than 128) are forced to stay the identity: 0 * inf = NaN would otherwise
+    // leak from an overflowing substituted factor into the log
+    const bool live = st.row_ok && J < st.ncols_ok;
+    const double l_own = (st.r > J && live) ? q : 0.0;
+    if (st.h == hJ) {
+        // the LDS image of column J: 1 / pivot on the diagonal, L below, zeros above
+        st.cptr[SB * J] = (st.r == J) ? ip : l_own;
+        if constexpr (!M3) {
+            if (st.r >= J && live) *st.gptr = (st.r == J) ? p : q;
+        }
     }
-    // inverse multiplier: the pivot row itself is scaled by 1/p, written as a - (1 - 1/p) a so that it is the same FMA
-    const double m = (lane == J) ? (1.0 - ip) : (st.lo ? l * ip : 0.0);
+    if constexpr (!M3) st.gptr += st.lda;
+    const double l = bcast_half<hJ>(l_own);  // L(r, J) in both halves
+    ColBcast cb;
+    if constexpr (!M3) col_load<J, 0>(cb, st.bufh);
     PivotChain ch;
     if constexpr (J + 1 < SB) {
-        if constexpr (!M3) {
-            const double s = readlane_f64(l, J + 1);
-            a[J + 1] = __builtin_fma(-l, s, a[J + 1]);
-            pin(a[J + 1]);
-        }
-        ch.d = readlane_f64(a[J + 1], J + 1);  // next pivot candidate (uniform)
+        // the next diagonal value needs no broadcast: its lane multiplies by its own L(J + 1, J)
+        constexpr int hN = (J + 1) / HB, kN = (J + 1) % HB;
+        // (when that lane sits in the owner half it does not even wait for the exchange between the halves)
+        double dn = a[kN];
+        if constexpr (!M3) dn = (hN == hJ) ? __builtin_fma(-q, q, dn) : __builtin_fma(-l, l, dn);
+        ch.d = readlane_f64(dn, (J + 1) + SB * hN);  // next pivot candidate (uniform)
+        chain_run<M3, 0, ChainShape<M3>::HEAD>(ch);
     }
     __builtin_amdgcn_sched_barrier(0);
-    step_interleave<M3, J, 0, 0>(a, l, m, ch);
-    a[J] = (lane == J) ? ip : -m;  // X(i, J) = -L(i, J) / p below the diagonal, 0 above
+    if constexpr (!M3) {
+        f_pairs<J, 0>(a, l, ch, cb);
+        if constexpr (J + 1 < SB) {
+            constexpr int done = ChainShape<false>::HEAD + (HB / 2 - first_live_slot(J) / 2);
+            chain_run<false, (done < ChainShape<false>::NST ? done : ChainShape<false>::NST), ChainShape<false>::NST>(ch);
+        }
+    }
     if constexpr (J + 1 < SB) {
         double pn = ch.q, ipn = ch.r;
         if constexpr (!M3) pivot_select(st, ch.d, J + 1, pn, ipn, excmask);
@@ -271,19 +327,18 @@ __device__ __forceinline__ void f_step(double (&a)[SB], FState& st, double p, do
 }
 
 template <bool M3>
-__device__ __forceinline__ void factor_subblock(double* lds, int b, int nblk, int lane, double* __restrict__ A, int64_t lda,
-                                                int n, int64_t col0, int mode, double sub, int64_t* __restrict__ info,
-                                                bool want_inv)
+__device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, double* __restrict__ A, int64_t lda, int n,
+                                                int64_t col0, int mode, double sub, int64_t* __restrict__ info)
 {
     FState st;
     st.lane = lane;
-    st.lo = lane < SB;
     st.r = lane & (SB - 1);
-    st.ride = (b + 1 < nblk);
-    double* dslot = lds + slot_of(b, b);
-    st.rslot = lds + slot_of(st.ride ? b + 1 : b, b);
-    st.gptr = A + (SB * b + lane) + (int64_t)(SB * b) * lda;
-    st.grow_ok = SB * b + lane < n;
+    st.h = lane >> 5;
+    double* image = lds + slot_of(b, b);
+    st.cptr = image + st.r;
+    st.bufh = image + HB * st.h;
+    st.gptr = A + (SB * b + st.r) + (int64_t)(SB * b) * lda;
+    st.row_ok = SB * b + st.r < n;
     st.ncols_ok = n - SB * b;
     st.lda = lda;
     st.colbase = col0 + SB * b;
@@ -292,27 +347,19 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int nblk, in
     st.ip_exc = st.p_exc;
     const bool substitute = (mode == 1 && sub > 0.0);
     if (substitute) sqrt_rsqrt(sub, st.p_exc, st.ip_exc);
-    double a[SB];
-    {
-        const double* src = st.lo ? dslot : st.rslot;
-        const bool ok = st.lo || st.ride;
+    double a[HB];
 #pragma unroll
-        for (int c = 0; c < SB; ++c) {
-            const double v = src[st.r + SB * c];
-            a[c] = ok ? v : 0.0;
-        }
-    }
+    for (int k = 0; k < HB; ++k) a[k] = image[st.r + SB * (HB * st.h + k)];
     // first pivot
     unsigned excmask = 0;
-    PivotChain ch;
-    ch.d = readlane_f64(a[0], 0);
+    const double d0 = readlane_f64(a[0], 0);
     double p, ip;
     if constexpr (M3) {
-        p = ch.d;
-        ip = 1.0 / ch.d;
+        p = d0;
+        ip = 1.0 / d0;
     } else {
-        sqrt_rsqrt(ch.d, p, ip);
-        pivot_select(st, ch.d, 0, p, ip, excmask);
+        sqrt_rsqrt(d0, p, ip);
+        pivot_select(st, d0, 0, p, ip, excmask);
     }
     f_step<M3, 0>(a, st, p, ip, excmask);
     if (st.ncols_ok < SB) excmask &= (1u << (st.ncols_ok > 0 ? st.ncols_ok : 0)) - 1u;
@@ -326,10 +373,51 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int nblk, in
             info[0] = 1 + st.colbase + (__builtin_ffs((int)excmask) - 1);
         }
     }
-    if (want_inv && st.lo) {
-#pragma unroll
-        for (int c = 0; c < SB; ++c) dslot[st.r + SB * c] = (c <= st.r) ? a[c] : 0.0;
+}
+
+// ---- triangular solve against the LDS image of L_bb (one wave, 32 vectors of 32, split-row layout) -------------------
+// x <- solution of  L y = x  (forward substitution, right-looking):  y[J] = x[J] / L(J, J);  x[c] -= y[J] L(c, J), c > J.
+// Used for T (x = a row of A_ib: the row of L_ib is y) and for X_bb (x = e_c: y is column c of L_bb^-1).  Here the slots
+// of finished columns hold results, so a slot is updated only where 16 h + k > J (two multipliers per step).  The
+// broadcasts of column J + 1 are issued while column J is applied (the image is read-only in this phase).
+template <int J>
+__device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, int h, const ColBcast& cb, double ipj)
+{
+    constexpr int hJ = J / HB, kJ = J % HB;
+    ColBcast nx;
+    double ipn = 0.0;
+    if constexpr (J + 1 < SB) {
+        col_load<J + 1, 0>(nx, bufh);
+        ipn = bufh[(J + 1) + SB * (J + 1) - HB * h];  // image[(J+1) + 32 (J+1)], uniform
     }
+    const double y_own = x[kJ] * ipj;
+    x[kJ] = (h == hJ) ? y_own : x[kJ];
+    pin(x[kJ]);
+    const double y = bcast_half<hJ>(y_own);
+    const double m_ge = (hJ == 0) ? y : ((h == 1) ? y : 0.0);  // halves h >= hJ
+    const double m_gt = (h == 1) ? y : 0.0;                    // halves h >  hJ (only when hJ == 0)
+#pragma unroll
+    for (int k = 0; k < HB; ++k) {
+        const double lv = (k & 1) ? cb.v[k >> 1].y : cb.v[k >> 1].x;
+        if (k > kJ) {
+            x[k] = __builtin_fma(-m_ge, lv, x[k]);
+            pin(x[k]);
+        } else if (hJ == 0) {
+            x[k] = __builtin_fma(-m_gt, lv, x[k]);
+            pin(x[k]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (J + 1 < SB) trsm_step<J + 1>(x, bufh, h, nx, ipn);
+}
+
+__device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, int h)
+{
+    const double* bufh = image + HB * h;
+    ColBcast cb;
+    col_load<0, 0>(cb, bufh);
+    const double ip0 = image[0];
+    trsm_step<0>(x, bufh, h, cb, ip0);
 }
 
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
@@ -346,124 +434,148 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
     const bool want_inv = inv != nullptr;
     const bool m3 = (mode == 3);
 
-    // ---- load the lower triangle into the LDS slots; rows / columns >= n are padded with the identity
+    // ---- load the lower triangle into the LDS slots; rows / columns >= n are padded with the identity.  All 20 loads
+    //      of a thread are issued before the first LDS write (one memory round trip, not ten)
     {
         const int cg = t >> 5;  // 16 column groups, 2 columns each per slot
-        for (int i = 0; i < nblk; ++i)
-            for (int k = 0; k <= i; ++k) {
-                double* s = lds + slot_of(i, k);
+        double v[2 * NSLOT];
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const int c = cg * 2 + cc;
-                    const int gr = SB * i + r, gc = SB * k + c;
-                    double v = (gr == gc) ? 1.0 : 0.0;
-                    if (gr < n && gc < n) v = (gr >= gc) ? A[gr + (int64_t)gc * lda] : 0.0;
-                    s[r + SB * c] = v;
-                }
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int i = (sl >= 6) ? 3 : ((sl >= 3) ? 2 : ((sl >= 1) ? 1 : 0));
+            const int k = sl - i * (i + 1) / 2;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int gr = SB * i + r, gc = SB * k + cg * 2 + cc;
+                double x = (gr == gc) ? 1.0 : 0.0;
+                if (gr < n && gc < n && gr >= gc) x = A[gr + (int64_t)gc * lda];
+                if (gr < n && gc < n && gr < gc) x = 0.0;
+                v[2 * sl + cc] = x;
             }
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int i = (sl >= 6) ? 3 : ((sl >= 3) ? 2 : ((sl >= 1) ? 1 : 0));
+            if (i < nblk) {
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) lds[sl * SBE + r + SB * (cg * 2 + cc)] = v[2 * sl + cc];
+            }
+        }
     }
     lds_barrier();
 
-    // Wave 0 is the panel wave (the serial pivot chain), waves 1..7 are the update waves (the 32^3 products); both sides
-    // execute the same barriers per stage: A (F done) | B (T rows loaded) | C (T, (1) done) | D (U, (2) done) |
-    // E1 ((3) rows loaded) | E2 ((3) done) -- the last two only when the inverse is wanted.
+    // Wave 0 is the panel wave (the serial pivot chain), waves 1..7 are the update waves; both sides execute the same
+    // barriers per stage:  A (F done) | B (T, X solved) | C (X stored, U done) | D ((1) done) | E ((2) done) |
+    // F ((3) read) | G ((3) stored).
     if (w == 0) {
         for (int b = 0; b < nblk; ++b) {
             if (m3)
-                factor_subblock<true>(lds, b, nblk, lane, A, lda, n, col0, mode, sub, info, want_inv);
+                factor_subblock<true>(lds, b, lane, A, lda, n, col0, mode, sub, info);
             else
-                factor_subblock<false>(lds, b, nblk, lane, A, lda, n, col0, mode, sub, info, want_inv);
-            lds_barrier();  // A
-            lds_barrier();  // B
-            lds_barrier();  // C
-            lds_barrier();  // D
-            if (want_inv) {
-                lds_barrier();  // E1
-                lds_barrier();  // E2
-            }
+                factor_subblock<false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) lds_barrier();
         }
     } else {
         const int u = w - 1;  // update wave 0..6
         for (int b = 0; b < nblk; ++b) {
             lds_barrier();  // A
-            const double* Xbb = lds + slot_of(b, b);
+            double* Lbb = lds + slot_of(b, b);  // image of L_bb (1 / pivot on the diagonal), later X_bb
 
-            // ---- P1: T: L_ib = A_ib X_bb^T for i >= b + 2 (in place: every task finishes reading before anyone
-            //          stores);  (1): W_bc = X_bb W_bc for c < b (in place too, but column-local to one task)
+            // ---- ph1: T (waves 0..2): L_ib = A_ib L_bb^-T for i = b + 1 + u, a row per lane pair;
+            //           X_bb (wave 3): a column per lane pair
             {
-                const int i = b + 2 + (u >> 1);
-                const bool tact = !m3 && u < 4 && i < nblk;
-                double* Tib = lds + slot_of(tact ? i : b, tact ? b : 0);
-                const int tc0 = ((u & 1) * 2 + h) * 8;
-                double tacc[8];
-                if (tact) prod_nt<8>(Tib + r, Xbb, tc0, tacc);
-                if (want_inv) {
-                    // tasks of (1) go to the waves without a T task first
-                    for (int task = (u + 3) % 7; task < 4 * b; task += 7) {
-                        double* Wbc = lds + slot_of(b, task >> 2);
-                        const int c0 = ((task & 3) * 2 + h) * 4;
-                        double acc[4];
-                        prod_nn<4>(Xbb + r, Wbc, c0, acc);
+                const int i = b + 1 + u;
+                const bool do_t = (u < 3) && !m3 && (i < nblk);
+                const bool do_x = (u == 3) && want_inv;
+                double x[HB];
+                double* Tib = lds + slot_of(do_t ? i : b, do_t ? b : 0);
+                if (do_t || do_x) {
+                    double one = 1.0;
+                    pin(one);  // not loop-invariant for the compiler: it would hoist e_c out of the stage loop and spill it
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) Wbc[r + SB * (c0 + c)] = acc[c];
+                    for (int k = 0; k < HB; ++k) x[k] = do_t ? Tib[r + SB * (HB * h + k)] : ((HB * h + k == r) ? one : 0.0);
+                    trsm_fwd(x, Lbb, h);
+                }
+                if (do_t) {
+                    const int gr = SB * i + r;
+#pragma unroll
+                    for (int k = 0; k < HB; ++k) {
+                        Tib[r + SB * (HB * h + k)] = x[k];
+                        const int gc = SB * b + HB * h + k;
+                        if (gr < n && gc < n) A[gr + (int64_t)gc * lda] = x[k];
                     }
                 }
                 lds_barrier();  // B
-                if (tact) {
-                    const int gr = SB * i + r;
+                // ---- ph2: X_bb replaces the image (lane (c, h) holds rows 16 h + k of column c: a strided,
+                //           bank-conflicting store, 16 of them)
+                if (do_x) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        Tib[r + SB * (tc0 + c)] = tacc[c];
-                        const int gc = SB * b + tc0 + c;
-                        if (gr < n && gc < n) A[gr + (int64_t)gc * lda] = tacc[c];
-                    }
+                    for (int k = 0; k < HB; ++k) Lbb[(HB * h + k) + SB * r] = x[k];
                 }
             }
-            lds_barrier();  // C
-
-            // ---- P2: U: A_ik -= L_ib L_kb^T (b < k <= i);  (2): W_ic -= L_ib W_bc (i > b, c < b)
-            {
+            //          U: A_ik -= L_ib L_kb^T (b < k <= i)
+            if (!m3) {
                 const int rem = nblk - b - 1;
-                const int nU = m3 ? 0 : rem * (rem + 1) / 2;
-                const int n2 = want_inv ? rem * b : 0;
-                for (int task = u; task < 4 * (nU + n2); task += 7) {
+                const int nU = rem * (rem + 1) / 2;
+                for (int task = u; task < 4 * nU; task += 7) {
                     const int pidx = task >> 2;
                     const int c0 = ((task & 3) * 2 + h) * 4;
+                    // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b
+                    const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
+                    const int rk = pidx - ri * (ri - 1) / 2 + 1;
+                    const int i = b + ri, k = b + rk;
                     double acc[4];
-                    double* C;
-                    if (pidx < nU) {
-                        // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b
-                        const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
-                        const int rk = pidx - ri * (ri - 1) / 2 + 1;
-                        const int i = b + ri, k = b + rk;
-                        prod_nt<4>(lds + slot_of(i, b) + r, lds + slot_of(k, b), c0, acc);
-                        C = lds + slot_of(i, k);
-                    } else {
-                        const int q = pidx - nU;
-                        const int i = b + 1 + q / b, cb = q % b;
-                        prod_nn<4>(lds + slot_of(i, b) + r, lds + slot_of(b, cb), c0, acc);
-                        C = lds + slot_of(i, cb);
-                    }
+                    prod_nt<4>(lds + slot_of(i, b) + r, lds + slot_of(k, b), c0, acc);
+                    double* C = lds + slot_of(i, k);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) C[r + SB * (c0 + c)] -= acc[c];
                 }
             }
+            lds_barrier();  // C
+
+            // ---- ph3: (1): W_bc = X_bb W_bc for c < b (in place, column-local to one task)
+            if (want_inv) {
+                for (int task = u; task < 4 * b; task += 7) {
+                    double* Wbc = lds + slot_of(b, task >> 2);
+                    const int c0 = ((task & 3) * 2 + h) * 4;
+                    double acc[4];
+                    prod_nn<4>(Lbb + r, Wbc, c0, acc);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Wbc[r + SB * (c0 + c)] = acc[c];
+                }
+            }
             lds_barrier();  // D
 
-            // ---- P3: (3): W_ib = -L_ib X_bb, in place over the now dead L_ib (all reads, a barrier, then the stores)
+            // ---- ph4: (2): W_ic -= L_ib W_bc (i > b, c < b)
             if (want_inv) {
+                const int n2 = (nblk - b - 1) * b;
+                for (int task = u; task < 4 * n2; task += 7) {
+                    const int q = task >> 2;
+                    const int c0 = ((task & 3) * 2 + h) * 4;
+                    const int i = b + 1 + q / b, cb = q % b;
+                    double acc[4];
+                    prod_nn<4>(lds + slot_of(i, b) + r, lds + slot_of(b, cb), c0, acc);
+                    double* C = lds + slot_of(i, cb);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) C[r + SB * (c0 + c)] -= acc[c];
+                }
+            }
+            lds_barrier();  // E
+
+            // ---- ph5: (3): W_ib = -L_ib X_bb, in place over the now dead L_ib (all reads, a barrier, then the stores)
+            {
                 const int i = b + 1 + (u >> 1);
-                const bool act = (u < 6) && i < nblk;
+                const bool act = want_inv && (u < 6) && i < nblk;
                 double* Wib = lds + slot_of(act ? i : b, act ? b : 0);
                 const int c0 = ((u & 1) * 2 + h) * 8;
                 double acc[8];
-                if (act) prod_nn<8>(Wib + r, Xbb, c0, acc);
-                lds_barrier();  // E1
+                if (act) prod_nn<8>(Wib + r, Lbb, c0, acc);
+                lds_barrier();  // F
                 if (act) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) Wib[r + SB * (c0 + c)] = -acc[c];
                 }
-                lds_barrier();  // E2
+                lds_barrier();  // G
             }
         }
     }

@@ -1,28 +1,35 @@
-"""Developer tool: per-phase s_memtime instrumentation of the potf2 kernel (writes scripts/potf2_bench_phases.hip)."""
+"""Developer tool: per-phase s_memtime instrumentation of the diagonal-block kernel (writes scripts/potf2_bench_phases.hip).
+Wave 0 stamps: start | block loaded | after each F_b | after each stage's last barrier | inverse stored."""
 src = open('friedrich_amd/csrc/potf2.hip').read()
 kern = src[src.index("constexpr int PB = 128;"):src.index("int launch_potf2(")]
-kern = kern.replace("    for (int j = 0; j < n; ++j) {\n        const int jcg = j & 7, jk = j >> 3;", "    long long s1=0,s2=0,s3=0,s4=0;\n    for (int j = 0; j < n; ++j) {\n        const long long q0 = __builtin_amdgcn_s_memtime();\n        const int jcg = j & 7, jk = j >> 3;")
-i1 = kern.index("        lds_barrier();\n        // ---- phase 2")
-kern = kern[:i1] + "        const long long q1 = __builtin_amdgcn_s_memtime();\n        lds_barrier();\n        const long long q2 = __builtin_amdgcn_s_memtime();\n" + kern[i1 + len("        lds_barrier();\n"):]
-i2 = kern.index("        lds_barrier();\n    }\n")
-kern = kern[:i2] + "        const long long q3 = __builtin_amdgcn_s_memtime();\n        lds_barrier();\n        const long long q4 = __builtin_amdgcn_s_memtime();\n        s1+=q1-q0; s2+=q2-q1; s3+=q3-q2; s4+=q4-q3;\n    }\n" + kern[i2 + len("        lds_barrier();\n    }\n"):]
-kern = kern.replace("#pragma unroll\n    for (int k = 0; k < PE; ++k) {\n        const int c = cg + 8 * k;\n        if (row_ok && c < n && i >= c) {", "    if ((t & 63) == 0 && info) { int w = t >> 6; info[8+4*w]=s1; info[9+4*w]=s2; info[10+4*w]=s3; info[11+4*w]=s4; }\n#pragma unroll\n    for (int k = 0; k < PE; ++k) {\n        const int c = cg + 8 * k;\n        if (row_ok && c < n && i >= c) {", 1)
+kern = kern.replace("int64_t* __restrict__ info)\n{\n    extern __shared__", "int64_t* __restrict__ info, long long* ts)\n{\n    if (threadIdx.x == 0) ts[0] = __builtin_amdgcn_s_memtime();\n    extern __shared__")
+kern = kern.replace("    if (w == 0) {\n        for (int b = 0; b < nblk; ++b) {", "    if (w == 0) {\n        if (lane == 0) ts[1] = __builtin_amdgcn_s_memtime();\n        for (int b = 0; b < nblk; ++b) {")
+kern = kern.replace("#pragma unroll\n            for (int k = 0; k < 7; ++k) lds_barrier();", "            if (lane == 0) ts[2 + 2 * b] = __builtin_amdgcn_s_memtime();\n#pragma unroll\n            for (int k = 0; k < 7; ++k) lds_barrier();\n            if (lane == 0) ts[3 + 2 * b] = __builtin_amdgcn_s_memtime();")
+i = kern.rindex("}")
+kern = kern[:i] + "    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n}\n"
+assert kern.count("ts[") == 5
 prog = '''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 #include <vector>
 #include <cmath>
+#define FR_OK 0
 namespace fr {
 ''' + kern + '''}
 int main(){
   const int n=128; std::vector<double> h(n*n);
   for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
-  double *A,*inv; int64_t* info; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n));
-  for(int rep=0;rep<2;++rep){
+  double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*16);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
+  for(int rep=0;rep<3;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
-    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),0,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info); (void)hipDeviceSynchronize();
-    int64_t hi[80]; (void)hipMemcpy(hi,info,8*80,hipMemcpyDeviceToHost);
-    if (rep) for (int w=0; w<16; w+=3) printf("wave %2d: per-step ticks P1 %5.0f  bar1 %5.0f  P2 %5.0f  bar2 %5.0f\\n",w,hi[8+4*w]/128.0,hi[9+4*w]/128.0,hi[10+4*w]/128.0,hi[11+4*w]/128.0);
+    hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,0);
+    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,0); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms,e0,e1);
+    long long t[16]; (void)hipMemcpy(t,ts,8*16,hipMemcpyDeviceToHost);
+    if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);
+      long long prev=t[1]; for(int b=0;b<4;++b){ printf(" | F%d %lld upd %lld", b, t[2+2*b]-prev, t[3+2*b]-t[2+2*b]); prev=t[3+2*b]; }
+      printf(" | store %lld | total %lld\\n", t[10]-prev, t[10]-t[0]); }
   }
   return 0; }
 '''

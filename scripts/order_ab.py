@@ -1,5 +1,5 @@
-"""Developer probe: A/B of the GEMM tile orders inside one process (option gemm_tile: 0 auto, 1 plain, 2 super for
-full-mode only, 3 super for lower-mode only)."""
+"""Developer probe: A/B of the GEMM tile orders inside one process (option gemm_tile: 0 default = super-tiles for
+full-mode only, 1 plain, 2 both modes, 3 lower-mode only)."""
 import sys
 import time
 

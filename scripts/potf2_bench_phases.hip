@@ -3,14 +3,17 @@
 #include <cstdint>
 #include <vector>
 #include <cmath>
+#define FR_OK 0
 namespace fr {
-constexpr int PB = 128;
-constexpr int PT = 512;  // threads: 8 waves x <= 128 VGPRs fit beside ONE resident GEMM workgroup (look-ahead overlap)
-constexpr int PE = 32;   // elements per thread
-constexpr int PG = 4;    // column groups
+constexpr int PB = 128;  // largest block
+constexpr int SB = 32;   // sub-block
+constexpr int SBE = SB * SB;
+constexpr int PT = 512;  // 8 waves; <= 128 VGPRs so that they fit beside ONE resident GEMM workgroup
+constexpr int NSLOT = 10;
+constexpr size_t POTF2_LDS = (size_t)NSLOT * SBE * sizeof(double);
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the
-// column store of every step to be acknowledged by memory (~2 us per step, 6x the rest of the step).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every
+// outstanding factor-column store to be acknowledged by memory (microseconds under GEMM load).
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -21,11 +24,6 @@ __device__ __forceinline__ void lds_barrier()
 // most of a step.  Results agree with sqrt()/division to the last bit or 1 ulp (the oracle comparison bounds it).
 __device__ __forceinline__ void sqrt_rsqrt(double d, double& p, double& ip)
 {
-    if (d == 0.0) {  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
-        p = 0.0;
-        ip = __builtin_inf();
-        return;
-    }
     double r = __builtin_amdgcn_rsq(d);
     const double h = 0.5 * d;
     r = r * __builtin_fma(-h * r, r, 1.5);
@@ -33,163 +31,559 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double& p, double& ip)
     double q = d * r;
     q = __builtin_fma(0.5 * r, __builtin_fma(-q, q, d), q);  // sqrt(d), corrected
     r = r * __builtin_fma(-q, r, 2.0);                        // 1 / q
-    p = q;
-    ip = r;
+    const bool zero = (d == 0.0);  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
+    p = zero ? 0.0 : q;
+    ip = zero ? __builtin_inf() : r;
 }
 
-// pivot rule for one diagonal value (executed by ONE thread per step): pivot and its reciprocal; logs substitutions
-// and failures
-__device__ __forceinline__ void pivot_of(double d, int mode, double sub, int64_t col, int64_t* __restrict__ info, double& p,
-                                         double& ip)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
-    if (mode == 3) {  // already a factor
-        p = d;
-        ip = 1.0 / d;
-        return;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int slot_of(int i, int k)
+{
+    return (i * (i + 1) / 2 + k) * SBE;
+}
+
+// Optimisation barrier: the value must be materialised in a VGPR at this point of the program.  Without it the
+// instruction selector's scheduler sinks every rank-1 FMA down to the step that next reads the slot (a legal but
+// pathological order: all multipliers and broadcast values of all steps stay live, hundreds of spills).
+__device__ __forceinline__ void pin(double& x)
+{
+    asm volatile("" : "+v"(x));
+}
+
+// 32^3 products of the update waves.  Lane (r, h) accumulates NC consecutive result columns of row r; the row operand
+// A(r, k) is read from LDS as it is needed (a rolled k loop: with the row held in registers and the loop unrolled the
+// instruction selector hoists every LDS read to the top and spills hundreds of registers).
+//   acc[c] = sum_k A[r + 32 k] * B[(c0 + c) + 32 k]   ("A B^T": B is indexed [column of the result, k])
+template <int NC>
+__device__ __forceinline__ void prod_nt(const double* Arow, const double* B, int c0, double (&acc)[NC])
+{
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    const double* bp = B + c0;
+#pragma unroll 4
+    for (int k = 0; k < SB; ++k) {
+        const double a = Arow[SB * k];
+        const double2* b2 = reinterpret_cast<const double2*>(bp + SB * k);
+#pragma unroll
+        for (int c = 0; c < NC; c += 2) {
+            const double2 v = b2[c >> 1];
+            acc[c] = __builtin_fma(a, v.x, acc[c]);
+            acc[c + 1] = __builtin_fma(a, v.y, acc[c + 1]);
+        }
     }
-    if (mode == 2 || d > 0.0) {  // insert_column: plain sqrt (NaN for d < 0)
-        sqrt_rsqrt(d, p, ip);
-        return;
+}
+
+//   acc[c] = sum_k A[r + 32 k] * B[k + 32 (c0 + c)]   ("A B")
+template <int NC>
+__device__ __forceinline__ void prod_nn(const double* Arow, const double* B, int c0, double (&acc)[NC])
+{
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    const double* bp = B + SB * c0;
+#pragma unroll 2
+    for (int k = 0; k < SB; k += 2) {
+        const double a0 = Arow[SB * k], a1 = Arow[SB * (k + 1)];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double2 v = *reinterpret_cast<const double2*>(bp + k + SB * c);
+            acc[c] = __builtin_fma(a0, v.x, acc[c]);
+            acc[c] = __builtin_fma(a1, v.y, acc[c]);
+        }
     }
-    if (mode == 1 && sub > 0.0) {
-        const int64_t q = info[1];
-        info[3 + q] = col;
-        info[1] = q + 1;
-        sqrt_rsqrt(sub, p, ip);
-        return;
+}
+
+// ---- split-row layout of the wave-synchronous routines -------------------------------------------------------------
+// A vector of 32 (a row of a sub-block, or a column of the inverse) is held by TWO lanes: lane (r, h) = r + 32 h owns
+// the 16 slots c = 16 h + k.  64 lanes work on one 32 x 32 sub-block, a lane needs 32 VGPRs for its slots and 32 for a
+// whole column of broadcasts, so every LDS read of a step is in flight at once (a ~130-cycle latency paid once per
+// step, behind the pivot chain, instead of once per FMA).
+constexpr int HB = 16;  // slots per lane
+
+// value of the same row in half H, delivered to both halves (one v_permlane32_swap per dword)
+template <int H>
+__device__ __forceinline__ double bcast_half(double x)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[H], (int)rl[H]);
+}
+
+// broadcasts of one column J of the factor image: L(16 h + k, J) for the lane's 16 slots, as 8 aligned pairs
+struct ColBcast {
+    double2 v[HB / 2];
+};
+
+constexpr int first_live_slot(int J)  // slots k >= this are still live in some half after column J
+{
+    return J < HB ? 0 : (J % HB) + 1;
+}
+
+template <int J, int P>
+__device__ __forceinline__ void col_load(ColBcast& cb, const double* bufh)
+{
+    if constexpr (P < HB / 2) {
+        if constexpr (2 * P + 1 >= first_live_slot(J)) cb.v[P] = *reinterpret_cast<const double2*>(bufh + 2 * P + SB * J);
+        col_load<J, P + 1>(cb, bufh);
     }
-    if (info[0] == 0) info[0] = 1 + col;
-    p = __builtin_nan("");
-    ip = p;
+}
+
+// ---- F_b: wave-synchronous factorisation of diagonal sub-block b (executed by wave 0 only) --------------------------
+struct FState {
+    double* gptr;       // &A[row r, current column]
+    double* cptr;       // &image[r]: where the owner half writes its element of the current column
+    const double* bufh; // &image[16 h]: base of this lane's broadcast reads
+    int64_t lda, colbase;  // colbase: global column index of the sub-block's first column
+    double p_exc, ip_exc;  // replacement pivot of the exception rule (NaN = failure)
+    int r, h, lane, mode, ncols_ok;  // ncols_ok: columns j < ncols_ok lie inside the matrix
+    bool row_ok;
+};
+
+// The pivot of step J + 1 (sqrt and reciprocal of the next diagonal value) is a chain of ~13 dependent f64 operations.
+// It is cut into stages: the first ones run while the broadcast reads of the step are in flight, the others are
+// interleaved with the rank-1 updates (pinned with sched_barrier) so that the chain's latency hides behind them.
+struct PivotChain {
+    double d, r, h, q, t;
+};
+
+template <bool M3, int K>
+__device__ __forceinline__ void chain_stage(PivotChain& c)
+{
+    if constexpr (M3) {  // the block already holds the factor: p = d, ip = 1 / d (reciprocal seed + two Newton steps)
+        if constexpr (K == 0) c.r = __builtin_amdgcn_rcp(c.d);
+        if constexpr (K == 1) c.t = __builtin_fma(-c.d, c.r, 1.0);
+        if constexpr (K == 2) c.r = __builtin_fma(c.r, c.t, c.r);
+        if constexpr (K == 3) c.t = __builtin_fma(-c.d, c.r, 1.0);
+        if constexpr (K == 4) c.r = __builtin_fma(c.r, c.t, c.r);
+        if constexpr (K == 5) c.q = c.d;
+        if constexpr (K == 0 || K == 2 || K == 4) pin(c.r);
+        if constexpr (K == 1 || K == 3) pin(c.t);
+    } else {
+        // v_rsq_f64 seed + two Newton steps give r = 1 / sqrt(d) to about an ulp: that IS the reciprocal pivot (the
+        // column scaling below corrects its quotient with one residual step against p, so r needs no further polish);
+        // p = sqrt(d) = d r with one Heron correction.  r is ready after stage 6, p after stage 9.
+        if constexpr (K == 0) {
+            c.r = __builtin_amdgcn_rsq(c.d);
+            c.h = -0.5 * c.d;
+        }
+        if constexpr (K == 1) c.t = c.h * c.r;
+        if constexpr (K == 2) c.t = __builtin_fma(c.t, c.r, 1.5);
+        if constexpr (K == 3) c.r = c.r * c.t;
+        if constexpr (K == 4) c.t = c.h * c.r;
+        if constexpr (K == 5) c.t = __builtin_fma(c.t, c.r, 1.5);
+        if constexpr (K == 6) c.r = c.r * c.t;
+        if constexpr (K == 7) {
+            c.q = c.d * c.r;
+            c.h = 0.5 * c.r;
+        }
+        if constexpr (K == 8) c.t = __builtin_fma(-c.q, c.q, c.d);
+        if constexpr (K == 9) c.q = __builtin_fma(c.h, c.t, c.q);
+        if constexpr (K == 10) {
+            const bool zero = (c.d == 0.0);  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
+            c.q = zero ? 0.0 : c.q;
+            c.r = zero ? __builtin_inf() : c.r;
+        }
+        if constexpr (K == 0 || K == 3 || K == 6 || K == 10) pin(c.r);
+        if constexpr (K == 1 || K == 2 || K == 4 || K == 5 || K == 8) pin(c.t);
+        if constexpr (K == 7 || K == 9 || K == 10) pin(c.q);
+        if constexpr (K == 0 || K == 7) pin(c.h);
+    }
+}
+
+template <bool M3>
+struct ChainShape {
+    static constexpr int NST = M3 ? 6 : 11;
+    static constexpr int HEAD = M3 ? 6 : 11;  // stages issued back to back while the broadcasts are in flight
+};
+
+template <bool M3, int K0, int K1>
+__device__ __forceinline__ void chain_run(PivotChain& c)
+{
+    if constexpr (K0 < K1) {
+        chain_stage<M3, K0>(c);
+        chain_run<M3, K0 + 1, K1>(c);
+    }
+}
+
+// Pivot rule for a diagonal value that is 0, negative or NaN (any mode but plain-sqrt): the replacement pivot
+// (sqrt(sub) and its reciprocal, or NaN = failure) is prepared once per launch and selected without a branch; the
+// column is only noted in a bit mask.  The log in global memory is written after the unrolled steps: a memory access on
+// a rare path inside them would make every step wait for the outstanding factor-column stores at the join.
+__device__ __forceinline__ void pivot_select(const FState& st, double d, int j, double& p, double& ip, unsigned& excmask)
+{
+    const bool bad = !(st.mode == 2 || d > 0.0);
+    p = bad ? st.p_exc : p;
+    ip = bad ? st.ip_exc : ip;
+    excmask |= bad ? (1u << j) : 0u;
+}
+
+// pairs P .. of step J: a(r, c) -= L(r, J) L(c, J) for the lane's slots, one chain stage per pair.  Slots whose column
+// is already final are dead registers in this routine: they are updated along with the others (no predicate).
+template <int J, int P>
+__device__ __forceinline__ void f_pairs(double (&a)[HB], double l, PivotChain& ch, const ColBcast& cb)
+{
+    constexpr int NST = ChainShape<false>::NST, HEAD = ChainShape<false>::HEAD;
+    constexpr int P0 = first_live_slot(J) / 2;
+    if constexpr (P < HB / 2) {
+        if constexpr (2 * P >= first_live_slot(J)) {
+            a[2 * P] = __builtin_fma(-l, cb.v[P].x, a[2 * P]);
+            pin(a[2 * P]);
+        }
+        if constexpr (2 * P + 1 >= first_live_slot(J)) {
+            a[2 * P + 1] = __builtin_fma(-l, cb.v[P].y, a[2 * P + 1]);
+            pin(a[2 * P + 1]);
+        }
+        if constexpr (P >= P0 && HEAD + (P - P0) < NST && J + 1 < SB) chain_stage<false, HEAD + (P - P0)>(ch);
+        __builtin_amdgcn_sched_barrier(0);
+        f_pairs<J, P + 1>(a, l, ch, cb);
+    }
+}
+
+// one elimination step; J is a compile-time constant so that every register index and lane select is static
+// (template recursion instead of `#pragma unroll`: the body is beyond clang's pragma-unroll budget)
+template <bool M3, int J>
+__device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double p, double ip, unsigned& excmask)
+{
+    constexpr int hJ = J / HB, kJ = J % HB;
+    // column J (owner half): col /= denom as reciprocal multiply + one residual correction
+    const double v = a[kJ];
+    double q = v * ip;
+    q = __builtin_fma(__builtin_fma(-q, p, v), ip, q);
+    if constexpr (M3) q = v;
+    // Padding rows / columns (block smaller than 128) are forced to stay the identity: 0 * inf = NaN would otherwise
+    // leak from an overflowing substituted factor into the log
+    const bool live = st.row_ok && J < st.ncols_ok;
+    const double l_own = (st.r > J && live) ? q : 0.0;
+    if (st.h == hJ) {
+        // the LDS image of column J: 1 / pivot on the diagonal, L below, zeros above
+        st.cptr[SB * J] = (st.r == J) ? ip : l_own;
+        if constexpr (!M3) {
+            if (st.r >= J && live) *st.gptr = (st.r == J) ? p : q;
+        }
+    }
+    if constexpr (!M3) st.gptr += st.lda;
+    const double l = bcast_half<hJ>(l_own);  // L(r, J) in both halves
+    ColBcast cb;
+    if constexpr (!M3) col_load<J, 0>(cb, st.bufh);
+    PivotChain ch;
+    if constexpr (J + 1 < SB) {
+        // the next diagonal value needs no broadcast: its lane multiplies by its own L(J + 1, J)
+        constexpr int hN = (J + 1) / HB, kN = (J + 1) % HB;
+        // (when that lane sits in the owner half it does not even wait for the exchange between the halves)
+        double dn = a[kN];
+        if constexpr (!M3) dn = (hN == hJ) ? __builtin_fma(-q, q, dn) : __builtin_fma(-l, l, dn);
+        ch.d = readlane_f64(dn, (J + 1) + SB * hN);  // next pivot candidate (uniform)
+        chain_run<M3, 0, ChainShape<M3>::HEAD>(ch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!M3) {
+        f_pairs<J, 0>(a, l, ch, cb);
+        if constexpr (J + 1 < SB) {
+            constexpr int done = ChainShape<false>::HEAD + (HB / 2 - first_live_slot(J) / 2);
+            chain_run<false, (done < ChainShape<false>::NST ? done : ChainShape<false>::NST), ChainShape<false>::NST>(ch);
+        }
+    }
+    if constexpr (J + 1 < SB) {
+        double pn = ch.q, ipn = ch.r;
+        if constexpr (!M3) pivot_select(st, ch.d, J + 1, pn, ipn, excmask);
+        f_step<M3, J + 1>(a, st, pn, ipn, excmask);
+    }
+}
+
+template <bool M3>
+__device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, double* __restrict__ A, int64_t lda, int n,
+                                                int64_t col0, int mode, double sub, int64_t* __restrict__ info)
+{
+    FState st;
+    st.lane = lane;
+    st.r = lane & (SB - 1);
+    st.h = lane >> 5;
+    double* image = lds + slot_of(b, b);
+    st.cptr = image + st.r;
+    st.bufh = image + HB * st.h;
+    st.gptr = A + (SB * b + st.r) + (int64_t)(SB * b) * lda;
+    st.row_ok = SB * b + st.r < n;
+    st.ncols_ok = n - SB * b;
+    st.lda = lda;
+    st.colbase = col0 + SB * b;
+    st.mode = mode;
+    st.p_exc = __builtin_nan("");
+    st.ip_exc = st.p_exc;
+    const bool substitute = (mode == 1 && sub > 0.0);
+    if (substitute) sqrt_rsqrt(sub, st.p_exc, st.ip_exc);
+    double a[HB];
+#pragma unroll
+    for (int k = 0; k < HB; ++k) a[k] = image[st.r + SB * (HB * st.h + k)];
+    // first pivot
+    unsigned excmask = 0;
+    const double d0 = readlane_f64(a[0], 0);
+    double p, ip;
+    if constexpr (M3) {
+        p = d0;
+        ip = 1.0 / d0;
+    } else {
+        sqrt_rsqrt(d0, p, ip);
+        pivot_select(st, d0, 0, p, ip, excmask);
+    }
+    f_step<M3, 0>(a, st, p, ip, excmask);
+    if (st.ncols_ok < SB) excmask &= (1u << (st.ncols_ok > 0 ? st.ncols_ok : 0)) - 1u;
+    if (excmask != 0 && lane == 0) {  // the log: substituted columns in order, or the first failing column
+        if (substitute) {
+            int64_t q = info[1];
+            for (int j = 0; j < SB; ++j)
+                if (excmask & (1u << j)) info[3 + q++] = st.colbase + j;
+            info[1] = q;
+        } else if (info[0] == 0) {
+            info[0] = 1 + st.colbase + (__builtin_ffs((int)excmask) - 1);
+        }
+    }
+}
+
+// ---- triangular solve against the LDS image of L_bb (one wave, 32 vectors of 32, split-row layout) -------------------
+// x <- solution of  L y = x  (forward substitution, right-looking):  y[J] = x[J] / L(J, J);  x[c] -= y[J] L(c, J), c > J.
+// Used for T (x = a row of A_ib: the row of L_ib is y) and for X_bb (x = e_c: y is column c of L_bb^-1).  Here the slots
+// of finished columns hold results, so a slot is updated only where 16 h + k > J (two multipliers per step).  The
+// broadcasts of column J + 1 are issued while column J is applied (the image is read-only in this phase).
+template <int J>
+__device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, int h, const ColBcast& cb, double ipj)
+{
+    constexpr int hJ = J / HB, kJ = J % HB;
+    ColBcast nx;
+    double ipn = 0.0;
+    if constexpr (J + 1 < SB) {
+        col_load<J + 1, 0>(nx, bufh);
+        ipn = bufh[(J + 1) + SB * (J + 1) - HB * h];  // image[(J+1) + 32 (J+1)], uniform
+    }
+    const double y_own = x[kJ] * ipj;
+    x[kJ] = (h == hJ) ? y_own : x[kJ];
+    pin(x[kJ]);
+    const double y = bcast_half<hJ>(y_own);
+    const double m_ge = (hJ == 0) ? y : ((h == 1) ? y : 0.0);  // halves h >= hJ
+    const double m_gt = (h == 1) ? y : 0.0;                    // halves h >  hJ (only when hJ == 0)
+#pragma unroll
+    for (int k = 0; k < HB; ++k) {
+        const double lv = (k & 1) ? cb.v[k >> 1].y : cb.v[k >> 1].x;
+        if (k > kJ) {
+            x[k] = __builtin_fma(-m_ge, lv, x[k]);
+            pin(x[k]);
+        } else if (hJ == 0) {
+            x[k] = __builtin_fma(-m_gt, lv, x[k]);
+            pin(x[k]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (J + 1 < SB) trsm_step<J + 1>(x, bufh, h, nx, ipn);
+}
+
+__device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, int h)
+{
+    const double* bufh = image + HB * h;
+    ColBcast cb;
+    col_load<0, 0>(cb, bufh);
+    const double ip0 = image[0];
+    trsm_step<0>(x, bufh, h, cb, ip0);
 }
 
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
-                                                   int64_t* __restrict__ info)
+                                                   int64_t* __restrict__ info, long long* ts)
 {
-    // Lc[x]      : L(x, j), the scaled column j (x > j)                          -- the row multiplier of the step
-    // Vc[c]      : L(c, j) for c > j (0 in mode 3: no factor update), Vc[PB + c] : X(j, c) for c < j (0 for c >= j)
-    // so that the update of element (i, c) is  a -= Lc[i] * Vc[c > j ? c : PB + c]  with no per-element predicate.
-    __shared__ double Lc[PB];
-    __shared__ double Vc[2 * PB];
-    __shared__ __attribute__((aligned(16))) double piv[2];  // {pivot, 1/pivot} of the current step
+    if (threadIdx.x == 0) ts[0] = __builtin_amdgcn_s_memtime();
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int t = threadIdx.x;
-    const int i = t & (PB - 1);
-    const int cg = t >> 7;  // 4 column groups of 128 threads (two waves): cg is wave-uniform
-    const bool row_ok = i < n;
-    const int wave_row0 = i & 64;  // first row held by this wave
+    const int lane = t & 63;
+    const int w = t >> 6;  // wave, uniform
+    const int r = lane & (SB - 1);
+    const int h = lane >> 5;
+    const int nblk = (n + SB - 1) / SB;
+    const bool want_inv = inv != nullptr;
+    const bool m3 = (mode == 3);
 
-    double a[PE];  // working element (i, cg + 4k): A, then (once column c is done) the inverse X
+    // ---- load the lower triangle into the LDS slots; rows / columns >= n are padded with the identity.  All 20 loads
+    //      of a thread are issued before the first LDS write (one memory round trip, not ten)
+    {
+        const int cg = t >> 5;  // 16 column groups, 2 columns each per slot
+        double v[2 * NSLOT];
 #pragma unroll
-    for (int k = 0; k < PE; ++k) {
-        const int c = cg + PG * k;
-        a[k] = (row_ok && c < n && i >= c) ? A[i + (int64_t)c * lda] : 0.0;
-    }
-    if (t == 0) {
-        double p0, ip0;
-        pivot_of(a[0], mode, sub, col0, info, p0, ip0);
-        piv[0] = p0;
-        piv[1] = ip0;
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int i = (sl >= 6) ? 3 : ((sl >= 3) ? 2 : ((sl >= 1) ? 1 : 0));
+            const int k = sl - i * (i + 1) / 2;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int gr = SB * i + r, gc = SB * k + cg * 2 + cc;
+                double x = (gr == gc) ? 1.0 : 0.0;
+                if (gr < n && gc < n && gr >= gc) x = A[gr + (int64_t)gc * lda];
+                if (gr < n && gc < n && gr < gc) x = 0.0;
+                v[2 * sl + cc] = x;
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int i = (sl >= 6) ? 3 : ((sl >= 3) ? 2 : ((sl >= 1) ? 1 : 0));
+            if (i < nblk) {
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) lds[sl * SBE + r + SB * (cg * 2 + cc)] = v[2 * sl + cc];
+            }
+        }
     }
     lds_barrier();
 
-    for (int j = 0; j < n; ++j) {
-        const int jcg = j & (PG - 1), jk = j / PG;
-        // ---- phase 1: owners of column j / row j scale and publish (sqrt and reciprocal were computed by ONE thread
-        //      at the end of the previous step)
-        const double p = piv[0], ip = piv[1];
-        if (cg == jcg && i >= j && row_ok) {  // the threads holding column j
+    // Wave 0 is the panel wave (the serial pivot chain), waves 1..7 are the update waves; both sides execute the same
+    // barriers per stage:  A (F done) | B (T, X solved) | C (X stored, U done) | D ((1) done) | E ((2) done) |
+    // F ((3) read) | G ((3) stored).
+    if (w == 0) {
+        if (lane == 0) ts[1] = __builtin_amdgcn_s_memtime();
+        for (int b = 0; b < nblk; ++b) {
+            if (m3)
+                factor_subblock<true>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+            else
+                factor_subblock<false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+            if (lane == 0) ts[2 + 2 * b] = __builtin_amdgcn_s_memtime();
 #pragma unroll
-            for (int k = 0; k < PE; ++k) {
-                if (k == jk) {  // uniform: exactly one of the 16 statically indexed bodies runs
-                    const double v = a[k];
-                    // col /= denom: quotient by reciprocal + one residual correction (== IEEE division except for rare
-                    // last-bit ties); the reciprocal is already on hand, a full division is ~35 dependent instructions
-                    double q = v * ip;
-                    q = __builtin_fma(__builtin_fma(-q, p, v), ip, q);
-                    q = (mode == 3) ? v : q;
-                    const bool diag = (i == j);
-                    const double lv = diag ? p : q;  // L(i, j)
-                    Lc[i] = lv;
-                    Vc[i] = (mode == 3) ? 0.0 : lv;
-                    if (mode != 3) A[i + (int64_t)j * lda] = lv;  // fire and forget: the barriers wait on LDS only
-                    a[k] = diag ? ip : -q * ip;  // X(i, j): 1/p on the diagonal, else 0 - L(i,j) X(j,j)
+            for (int k = 0; k < 7; ++k) lds_barrier();
+            if (lane == 0) ts[3 + 2 * b] = __builtin_amdgcn_s_memtime();
+        }
+    } else {
+        const int u = w - 1;  // update wave 0..6
+        for (int b = 0; b < nblk; ++b) {
+            lds_barrier();  // A
+            double* Lbb = lds + slot_of(b, b);  // image of L_bb (1 / pivot on the diagonal), later X_bb
+
+            // ---- ph1: T (waves 0..2): L_ib = A_ib L_bb^-T for i = b + 1 + u, a row per lane pair;
+            //           X_bb (wave 3): a column per lane pair
+            {
+                const int i = b + 1 + u;
+                const bool do_t = (u < 3) && !m3 && (i < nblk);
+                const bool do_x = (u == 3) && want_inv;
+                double x[HB];
+                double* Tib = lds + slot_of(do_t ? i : b, do_t ? b : 0);
+                if (do_t || do_x) {
+                    double one = 1.0;
+                    pin(one);  // not loop-invariant for the compiler: it would hoist e_c out of the stage loop and spill it
+#pragma unroll
+                    for (int k = 0; k < HB; ++k) x[k] = do_t ? Tib[r + SB * (HB * h + k)] : ((HB * h + k == r) ? one : 0.0);
+                    trsm_fwd(x, Lbb, h);
+                }
+                if (do_t) {
+                    const int gr = SB * i + r;
+#pragma unroll
+                    for (int k = 0; k < HB; ++k) {
+                        Tib[r + SB * (HB * h + k)] = x[k];
+                        const int gc = SB * b + HB * h + k;
+                        if (gr < n && gc < n) A[gr + (int64_t)gc * lda] = x[k];
+                    }
+                }
+                lds_barrier();  // B
+                // ---- ph2: X_bb replaces the image (lane (c, h) holds rows 16 h + k of column c: a strided,
+                //           bank-conflicting store, 16 of them)
+                if (do_x) {
+#pragma unroll
+                    for (int k = 0; k < HB; ++k) Lbb[(HB * h + k) + SB * r] = x[k];
                 }
             }
-        }
-        if (i == j) {  // the 4 threads holding row j: scale and publish X(j, c), c < j
+            //          U: A_ik -= L_ib L_kb^T (b < k <= i)
+            if (!m3) {
+                const int rem = nblk - b - 1;
+                const int nU = rem * (rem + 1) / 2;
+                for (int task = u; task < 4 * nU; task += 7) {
+                    const int pidx = task >> 2;
+                    const int c0 = ((task & 3) * 2 + h) * 4;
+                    // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b
+                    const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
+                    const int rk = pidx - ri * (ri - 1) / 2 + 1;
+                    const int i = b + ri, k = b + rk;
+                    double acc[4];
+                    prod_nt<4>(lds + slot_of(i, b) + r, lds + slot_of(k, b), c0, acc);
+                    double* C = lds + slot_of(i, k);
 #pragma unroll
-            for (int k = 0; k < PE; ++k) {
-                const int c = cg + PG * k;
-                const double sc = a[k] * ip;
-                const bool lt = c < j;
-                a[k] = lt ? sc : a[k];
-                Vc[PB + c] = lt ? sc : 0.0;  // zero for c >= j: the update of column j itself must be a no-op
-            }
-        }
-        const long long q1 = __builtin_amdgcn_s_memtime();
-        lds_barrier();
-        const long long q2 = __builtin_amdgcn_s_memtime();
-        // ---- phase 2: a(i, c) -= L(i, j) * (c > j ? L(c, j) : X(j, c)).  One LDS read + one FMA per element; waves whose
-        //      rows are all finished skip it (the block is VALU-throughput bound: 1024 threads x 16 elements per step)
-        if (wave_row0 + 63 > j) {
-            const bool act = (i > j) && row_ok;
-            const double lraw = Lc[i];
-            const double lij = act ? lraw : 0.0;
-            if (act && i == j + 1 && cg == ((j + 1) & (PG - 1))) {
-                // owner of the next diagonal element: take the next pivot now; the other waves overlap it with their
-                // 16 updates
-                const int nk = (j + 1) / PG;
-                double nd = 0.0;
-#pragma unroll
-                for (int k = 0; k < PE; ++k)
-                    if (k == nk) nd = a[k];
-                if (mode != 3) nd = nd - lij * lij;
-                double pn, ipn;
-                pivot_of(nd, mode, sub, col0 + j + 1, info, pn, ipn);
-                piv[0] = pn;
-                piv[1] = ipn;
-            }
-            // two batches of 16: all LDS reads of a batch first, then its FMAs (keeps the kernel under 128 VGPRs so that
-            // 8 waves fit next to one resident GEMM workgroup: 512 - 240 = 272 registers per SIMD lane)
-#pragma unroll
-            for (int k0 = 0; k0 < PE; k0 += 16) {
-                double vc[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int c = cg + PG * (k0 + k);
-                    vc[k] = Vc[c + ((c > j) ? 0 : PB)];
+                    for (int c = 0; c < 4; ++c) C[r + SB * (c0 + c)] -= acc[c];
                 }
+            }
+            lds_barrier();  // C
+
+            // ---- ph3: (1): W_bc = X_bb W_bc for c < b (in place, column-local to one task)
+            if (want_inv) {
+                for (int task = u; task < 4 * b; task += 7) {
+                    double* Wbc = lds + slot_of(b, task >> 2);
+                    const int c0 = ((task & 3) * 2 + h) * 4;
+                    double acc[4];
+                    prod_nn<4>(Lbb + r, Wbc, c0, acc);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) a[k0 + k] = __builtin_fma(-lij, vc[k], a[k0 + k]);
+                    for (int c = 0; c < 4; ++c) Wbc[r + SB * (c0 + c)] = acc[c];
+                }
+            }
+            lds_barrier();  // D
+
+            // ---- ph4: (2): W_ic -= L_ib W_bc (i > b, c < b)
+            if (want_inv) {
+                const int n2 = (nblk - b - 1) * b;
+                for (int task = u; task < 4 * n2; task += 7) {
+                    const int q = task >> 2;
+                    const int c0 = ((task & 3) * 2 + h) * 4;
+                    const int i = b + 1 + q / b, cb = q % b;
+                    double acc[4];
+                    prod_nn<4>(lds + slot_of(i, b) + r, lds + slot_of(b, cb), c0, acc);
+                    double* C = lds + slot_of(i, cb);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) C[r + SB * (c0 + c)] -= acc[c];
+                }
+            }
+            lds_barrier();  // E
+
+            // ---- ph5: (3): W_ib = -L_ib X_bb, in place over the now dead L_ib (all reads, a barrier, then the stores)
+            {
+                const int i = b + 1 + (u >> 1);
+                const bool act = want_inv && (u < 6) && i < nblk;
+                double* Wib = lds + slot_of(act ? i : b, act ? b : 0);
+                const int c0 = ((u & 1) * 2 + h) * 8;
+                double acc[8];
+                if (act) prod_nn<8>(Wib + r, Lbb, c0, acc);
+                lds_barrier();  // F
+                if (act) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) Wib[r + SB * (c0 + c)] = -acc[c];
+                }
+                lds_barrier();  // G
             }
         }
-        const long long q3 = __builtin_amdgcn_s_memtime();
-        lds_barrier();
-        const long long q4 = __builtin_amdgcn_s_memtime();
-        s1+=q1-q0; s2+=q2-q1; s3+=q3-q2; s4+=q4-q3;
     }
 
+    // ---- store the inverse (lower blocks from LDS, zeros above)
+    if (want_inv) {
+        const int cg = t >> 5;
+        for (int i = 0; i < nblk; ++i)
+            for (int k = 0; k < nblk; ++k) {
+                const double* s = lds + slot_of(i, k <= i ? k : 0);
 #pragma unroll
-    for (int k = 0; k < PE; ++k) {
-        const int c = cg + PG * k;
-        if (row_ok && c < n && i >= c) {
-            if (inv) inv[i + (int64_t)c * ldinv] = a[k];
-        } else if (row_ok && c < n && inv) {
-            inv[i + (int64_t)c * ldinv] = 0.0;
-        }
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int c = cg * 2 + cc;
+                    const int gr = SB * i + r, gc = SB * k + c;
+                    if (gr < n && gc < n) inv[gr + (int64_t)gc * ldinv] = (k <= i) ? s[r + SB * c] : 0.0;
+                }
+            }
     }
+    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();
 }
-
 }
 int main(){
   const int n=128; std::vector<double> h(n*n);
   for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
-  double *A,*inv; int64_t* info; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n));
-  for(int rep=0;rep<2;++rep){
+  double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*16);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
+  for(int rep=0;rep<3;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
-    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),0,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info); (void)hipDeviceSynchronize();
-    int64_t hi[80]; (void)hipMemcpy(hi,info,8*80,hipMemcpyDeviceToHost);
-    if (rep) for (int w=0; w<16; w+=3) printf("wave %2d: per-step ticks P1 %5.0f  bar1 %5.0f  P2 %5.0f  bar2 %5.0f\n",w,hi[8+4*w]/128.0,hi[9+4*w]/128.0,hi[10+4*w]/128.0,hi[11+4*w]/128.0);
+    hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,0);
+    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,0); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms,e0,e1);
+    long long t[16]; (void)hipMemcpy(t,ts,8*16,hipMemcpyDeviceToHost);
+    if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);
+      long long prev=t[1]; for(int b=0;b<4;++b){ printf(" | F%d %lld upd %lld", b, t[2+2*b]-prev, t[3+2*b]-t[2+2*b]); prev=t[3+2*b]; }
+      printf(" | store %lld | total %lld\n", t[10]-prev, t[10]-t[0]); }
   }
   return 0; }
