@@ -169,6 +169,14 @@ def main():
         total_flops = flops_fit(n, d) + flops_predict(n, m, d)
         syrk = prof["syrk"]
         achieved = syrk["flops"] / max(syrk["ms"], 1e-9) / 1e9  # TFLOP/s
+        # PMC counters cannot be read from inside the process: the figure is the committed rocprofv3 --pmc summary of the
+        # same workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction); null for any other size
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+        if os.path.exists(pmc_path) and (n, d, args.nb, world) == (32768, 16, 512, 1):
+            with open(pmc_path) as f:
+                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]
+            traffic_src = "profiles/r01/pmc_traffic.json"
         out = {
             "metric": "gp_fit_predict_gflops",
             "value": total_flops / (ms_per_step * 1e-3) / 1e9,
@@ -192,13 +200,15 @@ def main():
             "cholesky_tflops": (n ** 3 / 3.0) / (np.mean(fit_ms) * 1e-3) / 1e12,
             "n_substitutions": info["n_subst"],
             "roofline": {
-                "kernel": "gemm_f64_kernel<false,false> (trailing SYRK update, v_mfma_f64_16x16x4_f64)",
+                "kernel": "syrk_lower_f64_kernel (trailing SYRK update of the blocked Cholesky, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (L2 memory-side requests, Infinity-Cache hits included)",
+                "traffic_source": traffic_src,
                 "launches": syrk["launches"],
                 "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
                 "flops_per_launch": syrk["flops"] / max(syrk["launches"], 1),

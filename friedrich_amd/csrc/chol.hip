@@ -191,8 +191,9 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
         if (own_next) {
-            st = gemm(ctx, FR_PROF_SYRK, rest, kb2, kb, P, ld, false, P, ld, false, -1.0, 1.0, A + (k + kb) + (k + kb) * ld,
-                      ld);
+            // (profile class: panel -- the SYRK class times exactly the syrk_lower_f64_kernel launches)
+            st = gemm(ctx, FR_PROF_GEMM_PANEL, rest, kb2, kb, P, ld, false, P, ld, false, -1.0, 1.0,
+                      A + (k + kb) + (k + kb) * ld, ld);
             if (st != FR_OK) return fail(st);
         }
         if (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess)

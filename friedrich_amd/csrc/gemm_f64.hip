@@ -115,9 +115,8 @@ __device__ __forceinline__ void store_tile(double* __restrict__ S, int t, const 
 }
 
 template <bool A_KMAJ, bool B_KMAJ>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
+__device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
 {
-    __shared__ double lds[4 * TILE_ELEMS];  // [stage][A|B][TILE_ELEMS]
 
     // Tile assignment.  Block b runs on XCD b % 8 (observed dispatch rule; used for speed only).  Each XCD gets a
     // contiguous run of 64-tile "super-tiles" (8 x 8 tiles): an XCD keeps ~64 workgroups resident (32 CUs x 2), i.e. about
@@ -373,6 +372,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
     }
 }
 
+// Two kernel symbols over the same body: the lower-mode launch is the trailing SYRK update of the factorisation (the
+// dominant kernel of a fit); keeping it apart from the panel / solve GEMMs makes profiler per-kernel averages meaningful.
+template <bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
+{
+    __shared__ double lds[4 * TILE_ELEMS];  // [stage][A|B][TILE_ELEMS]
+    gemm_f64_body<A_KMAJ, B_KMAJ>(g, lds);
+}
+
+__global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g)
+{
+    __shared__ double lds[4 * TILE_ELEMS];
+    gemm_f64_body<false, false>(g, lds);
+}
+
 int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
 {
     if (d.M <= 0 || d.N <= 0) return FR_OK;
@@ -432,7 +446,9 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
     const double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
     ProfScope ps(ctx, d.prof_cls, flops, bytes);
     dim3 grid((unsigned)ntiles), block(256);
-    if (!d.a_kmajor && !d.b_kmajor)
+    if (d.lower && !d.a_kmajor && !d.b_kmajor)
+        hipLaunchKernelGGL(syrk_lower_f64_kernel, grid, block, 0, ctx->ls, g);
+    else if (!d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && d.b_kmajor)
         hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, ctx->ls, g);

@@ -7,7 +7,10 @@ kern = kern.replace("    if (w == 0) {\n        for (int b = 0; b < nblk; ++b) {
 kern = kern.replace("#pragma unroll\n            for (int k = 0; k < 7; ++k) lds_barrier();", "            if (lane == 0) ts[2 + 2 * b] = __builtin_amdgcn_s_memtime();\n#pragma unroll\n            for (int k = 0; k < 7; ++k) lds_barrier();\n            if (lane == 0) ts[3 + 2 * b] = __builtin_amdgcn_s_memtime();")
 i = kern.rindex("}")
 kern = kern[:i] + "    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n}\n"
-assert kern.count("ts[") == 5
+for tag, idx in (("A", 0), ("B", 1), ("C", 2), ("D", 3), ("E", 4), ("F", 5), ("G", 6)):
+    old = "lds_barrier();  // %s\n" % tag
+    assert kern.count(old) == 1, tag
+    kern = kern.replace(old, old + "            if (w == 1 && lane == 0) ts[16 + 8 * b + %d] = __builtin_amdgcn_s_memtime();\n" % idx)
 prog = '''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -19,17 +22,18 @@ namespace fr {
 int main(){
   const int n=128; std::vector<double> h(n*n);
   for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
-  double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*16);
+  double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*64);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
   for(int rep=0;rep<3;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
     hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,0);
     hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,0); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms,e0,e1);
-    long long t[16]; (void)hipMemcpy(t,ts,8*16,hipMemcpyDeviceToHost);
+    long long t[64]; (void)hipMemcpy(t,ts,8*64,hipMemcpyDeviceToHost);
     if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);
       long long prev=t[1]; for(int b=0;b<4;++b){ printf(" | F%d %lld upd %lld", b, t[2+2*b]-prev, t[3+2*b]-t[2+2*b]); prev=t[3+2*b]; }
-      printf(" | store %lld | total %lld\\n", t[10]-prev, t[10]-t[0]); }
+      printf(" | store %lld | total %lld\\n", t[10]-prev, t[10]-t[0]);
+      for(int b=0;b<4;++b){ printf("  stage %d (update wave 0): T/X %lld | Xstore+U %lld | (1) %lld | (2) %lld | (3)read %lld | (3)store %lld\\n", b, t[16+8*b+1]-t[16+8*b], t[16+8*b+2]-t[16+8*b+1], t[16+8*b+3]-t[16+8*b+2], t[16+8*b+4]-t[16+8*b+3], t[16+8*b+5]-t[16+8*b+4], t[16+8*b+6]-t[16+8*b+5]); } }
   }
   return 0; }
 '''

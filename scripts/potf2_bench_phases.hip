@@ -453,6 +453,7 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
         const int u = w - 1;  // update wave 0..6
         for (int b = 0; b < nblk; ++b) {
             lds_barrier();  // A
+            if (w == 1 && lane == 0) ts[16 + 8 * b + 0] = __builtin_amdgcn_s_memtime();
             double* Lbb = lds + slot_of(b, b);  // image of L_bb (1 / pivot on the diagonal), later X_bb
 
             // ---- ph1: T (waves 0..2): L_ib = A_ib L_bb^-T for i = b + 1 + u, a row per lane pair;
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
                     }
                 }
                 lds_barrier();  // B
+            if (w == 1 && lane == 0) ts[16 + 8 * b + 1] = __builtin_amdgcn_s_memtime();
                 // ---- ph2: X_bb replaces the image (lane (c, h) holds rows 16 h + k of column c: a strided,
                 //           bank-conflicting store, 16 of them)
                 if (do_x) {
@@ -506,6 +508,7 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
                 }
             }
             lds_barrier();  // C
+            if (w == 1 && lane == 0) ts[16 + 8 * b + 2] = __builtin_amdgcn_s_memtime();
 
             // ---- ph3: (1): W_bc = X_bb W_bc for c < b (in place, column-local to one task)
             if (want_inv) {
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
                 }
             }
             lds_barrier();  // D
+            if (w == 1 && lane == 0) ts[16 + 8 * b + 3] = __builtin_amdgcn_s_memtime();
 
             // ---- ph4: (2): W_ic -= L_ib W_bc (i > b, c < b)
             if (want_inv) {
@@ -535,6 +539,7 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
                 }
             }
             lds_barrier();  // E
+            if (w == 1 && lane == 0) ts[16 + 8 * b + 4] = __builtin_amdgcn_s_memtime();
 
             // ---- ph5: (3): W_ib = -L_ib X_bb, in place over the now dead L_ib (all reads, a barrier, then the stores)
             {
@@ -545,11 +550,13 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
                 double acc[8];
                 if (act) prod_nn<8>(Wib + r, Lbb, c0, acc);
                 lds_barrier();  // F
+            if (w == 1 && lane == 0) ts[16 + 8 * b + 5] = __builtin_amdgcn_s_memtime();
                 if (act) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) Wib[r + SB * (c0 + c)] = -acc[c];
                 }
                 lds_barrier();  // G
+            if (w == 1 && lane == 0) ts[16 + 8 * b + 6] = __builtin_amdgcn_s_memtime();
             }
         }
     }
@@ -574,16 +581,17 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
 int main(){
   const int n=128; std::vector<double> h(n*n);
   for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
-  double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*16);
+  double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*64);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
   for(int rep=0;rep<3;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
     hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,0);
     hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,0); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms,e0,e1);
-    long long t[16]; (void)hipMemcpy(t,ts,8*16,hipMemcpyDeviceToHost);
+    long long t[64]; (void)hipMemcpy(t,ts,8*64,hipMemcpyDeviceToHost);
     if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);
       long long prev=t[1]; for(int b=0;b<4;++b){ printf(" | F%d %lld upd %lld", b, t[2+2*b]-prev, t[3+2*b]-t[2+2*b]); prev=t[3+2*b]; }
-      printf(" | store %lld | total %lld\n", t[10]-prev, t[10]-t[0]); }
+      printf(" | store %lld | total %lld\n", t[10]-prev, t[10]-t[0]);
+      for(int b=0;b<4;++b){ printf("  stage %d (update wave 0): T/X %lld | Xstore+U %lld | (1) %lld | (2) %lld | (3)read %lld | (3)store %lld\n", b, t[16+8*b+1]-t[16+8*b], t[16+8*b+2]-t[16+8*b+1], t[16+8*b+3]-t[16+8*b+2], t[16+8*b+4]-t[16+8*b+3], t[16+8*b+5]-t[16+8*b+4], t[16+8*b+6]-t[16+8*b+5]); } }
   }
   return 0; }
