@@ -129,9 +129,10 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
     const int64_t xcd = b & 7;
     int64_t tm, tn;
     if (g.nsuper > 0) {
-        const int64_t tlin = xcd * (g.per_xcd * 64) + (b >> 3);
-        const int64_t sidx = tlin >> 6;
-        const int within = (int)(tlin & 63);
+        // super-tiles are dealt round-robin to the XCDs (the triangular enumeration of the lower mode has cheaper
+        // super-tiles on the diagonal: contiguous runs per XCD would leave a 6 % imbalance)
+        const int64_t sidx = ((b >> 3) >> 6) * 8 + xcd;
+        const int within = (int)((b >> 3) & 63);
         if (sidx >= g.nsuper) return;
         if (g.lower) {
             int64_t row = (int64_t)((sqrt(8.0 * (double)sidx + 1.0) - 1.0) * 0.5);

@@ -4,13 +4,19 @@ src = open('friedrich_amd/csrc/potf2.hip').read()
 kern = src[src.index("constexpr int PB = 128;"):src.index("int launch_potf2(")]
 kern = kern.replace("int64_t* __restrict__ info)\n{\n    extern __shared__", "int64_t* __restrict__ info, long long* ts)\n{\n    if (threadIdx.x == 0) ts[0] = __builtin_amdgcn_s_memtime();\n    extern __shared__")
 kern = kern.replace("    if (w == 0) {\n        for (int b = 0; b < nblk; ++b) {", "    if (w == 0) {\n        if (lane == 0) ts[1] = __builtin_amdgcn_s_memtime();\n        for (int b = 0; b < nblk; ++b) {")
-kern = kern.replace("#pragma unroll\n            for (int k = 0; k < 7; ++k) lds_barrier();", "            if (lane == 0) ts[2 + 2 * b] = __builtin_amdgcn_s_memtime();\n#pragma unroll\n            for (int k = 0; k < 7; ++k) lds_barrier();\n            if (lane == 0) ts[3 + 2 * b] = __builtin_amdgcn_s_memtime();")
+four = "            lds_barrier();\n            lds_barrier();\n            lds_barrier();\n"
+assert kern.count(four) == 1
+kern = kern.replace(four, "            if (lane == 0) ts[2 + 2 * b] = __builtin_amdgcn_s_memtime();\n" + four + "            if (lane == 0) ts[3 + 2 * b] = __builtin_amdgcn_s_memtime();\n")
+# update-wave stamps: after each of the 4 barriers of a stage (8-space indent inside the update branch)
+head, tail = kern.split("    const int u = w - 1;\n", 1)
+parts = tail.split("        lds_barrier();\n")
+assert len(parts) == 4, len(parts)
+tail = parts[0]
+for idx in range(3):
+    tail += "        lds_barrier();\n        if (w == 1 && lane == 0) ts[16 + 8 * b + %d] = __builtin_amdgcn_s_memtime();\n" % idx + parts[idx + 1]
+kern = head + "    const int u = w - 1;\n" + tail
 i = kern.rindex("}")
 kern = kern[:i] + "    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n}\n"
-for tag, idx in (("A", 0), ("B", 1), ("C", 2), ("D", 3), ("E", 4), ("F", 5), ("G", 6)):
-    old = "lds_barrier();  // %s\n" % tag
-    assert kern.count(old) == 1, tag
-    kern = kern.replace(old, old + "            if (w == 1 && lane == 0) ts[16 + 8 * b + %d] = __builtin_amdgcn_s_memtime();\n" % idx)
 prog = '''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -33,7 +39,7 @@ int main(){
     if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);
       long long prev=t[1]; for(int b=0;b<4;++b){ printf(" | F%d %lld upd %lld", b, t[2+2*b]-prev, t[3+2*b]-t[2+2*b]); prev=t[3+2*b]; }
       printf(" | store %lld | total %lld\\n", t[10]-prev, t[10]-t[0]);
-      for(int b=0;b<4;++b){ printf("  stage %d (update wave 0): T/X %lld | Xstore+U %lld | (1) %lld | (2) %lld | (3)read %lld | (3)store %lld\\n", b, t[16+8*b+1]-t[16+8*b], t[16+8*b+2]-t[16+8*b+1], t[16+8*b+3]-t[16+8*b+2], t[16+8*b+4]-t[16+8*b+3], t[16+8*b+5]-t[16+8*b+4], t[16+8*b+6]-t[16+8*b+5]); } }
+      for(int b=0;b<4;++b){ printf("  stage %d (update wave 0): P2 products %lld | P3 %lld\\n", b, t[16+8*b+1]-t[16+8*b], t[16+8*b+2]-t[16+8*b+1]); } }
   }
   return 0; }
 '''

@@ -10,7 +10,7 @@ constexpr int SB = 32;   // sub-block
 constexpr int SBE = SB * SB;
 constexpr int PT = 512;  // 8 waves; <= 128 VGPRs so that they fit beside ONE resident GEMM workgroup
 constexpr int NSLOT = 10;
-constexpr size_t POTF2_LDS = (size_t)NSLOT * SBE * sizeof(double);
+constexpr size_t POTF2_LDS = (size_t)NSLOT * SBE * sizeof(double) + 16;  // + the column counter of the panel wave
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every
 // outstanding factor-column store to be acknowledged by memory (microseconds under GEMM load).
@@ -104,6 +104,7 @@ __device__ __forceinline__ void prod_nn(const double* Arow, const double* B, int
 // whole column of broadcasts, so every LDS read of a step is in flight at once (a ~130-cycle latency paid once per
 // step, behind the pivot chain, instead of once per FMA).
 constexpr int HB = 16;  // slots per lane
+typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // value of the same row in half H, delivered to both halves (one v_permlane32_swap per dword)
 template <int H>
@@ -139,6 +140,8 @@ struct FState {
     double* gptr;       // &A[row r, current column]
     double* cptr;       // &image[r]: where the owner half writes its element of the current column
     const double* bufh; // &image[16 h]: base of this lane's broadcast reads
+    int* flag;          // LDS counter: number of factor columns published so far (all stages)
+    int flag_base;      // 32 b
     int64_t lda, colbase;  // colbase: global column index of the sub-block's first column
     double p_exc, ip_exc;  // replacement pivot of the exception rule (NaN = failure)
     int r, h, lane, mode, ncols_ok;  // ncols_ok: columns j < ncols_ok lie inside the matrix
@@ -263,6 +266,7 @@ __device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double p, do
     if (st.h == hJ) {
         // the LDS image of column J: 1 / pivot on the diagonal, L below, zeros above
         st.cptr[SB * J] = (st.r == J) ? ip : l_own;
+        *st.flag = st.flag_base + J + 1;  // after the column in this wave's LDS order: the solves of P1 may consume it
         if constexpr (!M3) {
             if (st.r >= J && live) *st.gptr = (st.r == J) ? p : q;
         }
@@ -301,6 +305,8 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, do
                                                 int64_t col0, int mode, double sub, int64_t* __restrict__ info)
 {
     FState st;
+    st.flag = reinterpret_cast<int*>(lds + NSLOT * SBE);
+    st.flag_base = SB * b;
     st.lane = lane;
     st.r = lane & (SB - 1);
     st.h = lane >> 5;
@@ -350,13 +356,22 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, do
 // Used for T (x = a row of A_ib: the row of L_ib is y) and for X_bb (x = e_c: y is column c of L_bb^-1).  Here the slots
 // of finished columns hold results, so a slot is updated only where 16 h + k > J (two multipliers per step).  The
 // broadcasts of column J + 1 are issued while column J is applied (the image is read-only in this phase).
+// The solves run CONCURRENTLY with F_b on other waves: they consume column J of the image as soon as the panel wave has
+// published it (LDS counter, polled), one step behind the pivot chain, and finish a step after it.
+__device__ __forceinline__ void wait_columns(const int* flag, int target)
+{
+    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(flag)) < target) __builtin_amdgcn_s_sleep(1);
+}
+
 template <int J>
-__device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, int h, const ColBcast& cb, double ipj)
+__device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, int h, const ColBcast& cb, double ipj,
+                                          const int* flag, int flag_base)
 {
     constexpr int hJ = J / HB, kJ = J % HB;
     ColBcast nx;
     double ipn = 0.0;
     if constexpr (J + 1 < SB) {
+        wait_columns(flag, flag_base + J + 2);
         col_load<J + 1, 0>(nx, bufh);
         ipn = bufh[(J + 1) + SB * (J + 1) - HB * h];  // image[(J+1) + 32 (J+1)], uniform
     }
@@ -378,16 +393,17 @@ __device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, i
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (J + 1 < SB) trsm_step<J + 1>(x, bufh, h, nx, ipn);
+    if constexpr (J + 1 < SB) trsm_step<J + 1>(x, bufh, h, nx, ipn, flag, flag_base);
 }
 
-__device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, int h)
+__device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, int h, const int* flag, int flag_base)
 {
     const double* bufh = image + HB * h;
     ColBcast cb;
+    wait_columns(flag, flag_base + 1);
     col_load<0, 0>(cb, bufh);
     const double ip0 = image[0];
-    trsm_step<0>(x, bufh, h, cb, ip0);
+    trsm_step<0>(x, bufh, h, cb, ip0, flag, flag_base);
 }
 
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
@@ -432,11 +448,21 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
             }
         }
     }
+    int* colflag = reinterpret_cast<int*>(lds + NSLOT * SBE);
+    if (t == 0) *colflag = 0;
     lds_barrier();
 
-    // Wave 0 is the panel wave (the serial pivot chain), waves 1..7 are the update waves; both sides execute the same
-    // barriers per stage:  A (F done) | B (T, X solved) | C (X stored, U done) | D ((1) done) | E ((2) done) |
-    // F ((3) read) | G ((3) stored).
+    // Per stage b (barriers between the phases):
+    //   P1  wave 0: F_b, the serial pivot chain; concurrently, one step behind it (column counter in LDS):
+    //       T: L_ib = A_ib L_bb^-T (one wave per sub-block below)  |  X_bb (one wave)  |  (1): W_bc = L_bb^-1 W_bc, c < b
+    //       -- all three are the same triangular solve against the image of L_bb, on rows of A_ib, on e_c, on columns of W_bc
+    //   P2  X_bb replaces the image  |  U: A_ik -= L_ib L_kb^T  |  (2): W_ic -= L_ib W_bc      (MFMA 16x16 tiles, all waves)
+    //   P3  (3): W_ib = -L_ib X_bb, in place over the now dead L_ib (one wave per sub-block)
+    // The inverse sub-blocks are kept TRANSPOSED in LDS (WT_ic[y + 32 x] = W_ic(x, y)): it makes every product an
+    // "N T" contraction whose two operand fragments and whose result tile are contiguous along the 16 lanes of an MFMA
+    // register, and it is the layout in which a lane pair of the solve naturally stores its column of X_bb.
+    // Wave 0 runs only F_b and the barriers (its own branch keeps the unrolled pivot chain free of the update phases'
+    // register pressure); waves 1..7 are the update waves.
     if (w == 0) {
         if (lane == 0) ts[1] = __builtin_amdgcn_s_memtime();
         for (int b = 0; b < nblk; ++b) {
@@ -445,123 +471,141 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
             else
                 factor_subblock<false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
             if (lane == 0) ts[2 + 2 * b] = __builtin_amdgcn_s_memtime();
-#pragma unroll
-            for (int k = 0; k < 7; ++k) lds_barrier();
+            lds_barrier();
+            lds_barrier();
+            lds_barrier();
             if (lane == 0) ts[3 + 2 * b] = __builtin_amdgcn_s_memtime();
         }
     } else {
-        const int u = w - 1;  // update wave 0..6
-        for (int b = 0; b < nblk; ++b) {
-            lds_barrier();  // A
-            if (w == 1 && lane == 0) ts[16 + 8 * b + 0] = __builtin_amdgcn_s_memtime();
-            double* Lbb = lds + slot_of(b, b);  // image of L_bb (1 / pivot on the diagonal), later X_bb
+    const int u = w - 1;
+    for (int b = 0; b < nblk; ++b) {
+        double* Lbb = lds + slot_of(b, b);  // image of L_bb (1 / pivot on the diagonal), later XT_bb
 
-            // ---- ph1: T (waves 0..2): L_ib = A_ib L_bb^-T for i = b + 1 + u, a row per lane pair;
-            //           X_bb (wave 3): a column per lane pair
-            {
-                const int i = b + 1 + u;
-                const bool do_t = (u < 3) && !m3 && (i < nblk);
-                const bool do_x = (u == 3) && want_inv;
-                double x[HB];
-                double* Tib = lds + slot_of(do_t ? i : b, do_t ? b : 0);
-                if (do_t || do_x) {
-                    double one = 1.0;
-                    pin(one);  // not loop-invariant for the compiler: it would hoist e_c out of the stage loop and spill it
+        // ---- P1
+        double xs[HB];
+        const bool do_x = (u == 3) && want_inv;
+        {
+            const int it = b + 1 + u;            // update waves 0..2: T on sub-block it
+            const int c1 = u - 4;                // update waves 4..6: (1) on W_b,c1
+            const bool do_t = (u < 3) && !m3 && (it < nblk);
+            const bool do_1 = (u >= 4) && want_inv && (c1 < b);
+            double* S = lds + (do_t ? slot_of(it, b) : (do_1 ? slot_of(b, c1) : 0));
+            if (do_t || do_x || do_1) {
+                double one = 1.0;
+                pin(one);  // not loop-invariant for the compiler: it would hoist e_c out of the stage loop and spill it
 #pragma unroll
-                    for (int k = 0; k < HB; ++k) x[k] = do_t ? Tib[r + SB * (HB * h + k)] : ((HB * h + k == r) ? one : 0.0);
-                    trsm_fwd(x, Lbb, h);
+                for (int k = 0; k < HB; ++k) {
+                    // T: row r of A_ib (normal layout);  (1): column r of W_bc (transposed layout: same addresses);  X: e_r
+                    const double v = S[r + SB * (HB * h + k)];
+                    xs[k] = do_x ? ((HB * h + k == r) ? one : 0.0) : v;
                 }
-                if (do_t) {
-                    const int gr = SB * i + r;
+                trsm_fwd(xs, Lbb, h, colflag, SB * b);
+            }
+            if (do_t || do_1) {
+                const int gr = SB * it + r;
 #pragma unroll
-                    for (int k = 0; k < HB; ++k) {
-                        Tib[r + SB * (HB * h + k)] = x[k];
-                        const int gc = SB * b + HB * h + k;
-                        if (gr < n && gc < n) A[gr + (int64_t)gc * lda] = x[k];
-                    }
-                }
-                lds_barrier();  // B
-            if (w == 1 && lane == 0) ts[16 + 8 * b + 1] = __builtin_amdgcn_s_memtime();
-                // ---- ph2: X_bb replaces the image (lane (c, h) holds rows 16 h + k of column c: a strided,
-                //           bank-conflicting store, 16 of them)
-                if (do_x) {
-#pragma unroll
-                    for (int k = 0; k < HB; ++k) Lbb[(HB * h + k) + SB * r] = x[k];
+                for (int k = 0; k < HB; ++k) {
+                    S[r + SB * (HB * h + k)] = xs[k];
+                    const int gc = SB * b + HB * h + k;
+                    if (do_t && gr < n && gc < n) A[gr + (int64_t)gc * lda] = xs[k];
                 }
             }
-            //          U: A_ik -= L_ib L_kb^T (b < k <= i)
-            if (!m3) {
-                const int rem = nblk - b - 1;
-                const int nU = rem * (rem + 1) / 2;
-                for (int task = u; task < 4 * nU; task += 7) {
-                    const int pidx = task >> 2;
-                    const int c0 = ((task & 3) * 2 + h) * 4;
+        }
+        lds_barrier();
+        if (w == 1 && lane == 0) ts[16 + 8 * b + 0] = __builtin_amdgcn_s_memtime();
+
+        // ---- P2
+        if (do_x) {
+            // lane pair (c, h) holds X(16 h + k, c): stored transposed, conflict-free
+#pragma unroll
+            for (int k = 0; k < HB; ++k) Lbb[r + SB * (HB * h + k)] = xs[k];
+        }
+        {
+            const int rem = nblk - b - 1;
+            const int nU = m3 ? 0 : rem * (rem + 1) / 2;
+            const int n2 = want_inv ? rem * b : 0;
+            const int l15 = lane & 15, lq = lane >> 4;
+            // update wave 3 joins after its store: the task list is dealt to the other waves first
+            for (int task = (u + 3) % 7; task < 4 * (nU + n2); task += 7) {
+                const int pidx = task >> 2;
+                const int tx = (task >> 1) & 1, ty = task & 1;
+                if (pidx < nU) {
                     // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b
                     const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
                     const int rk = pidx - ri * (ri - 1) / 2 + 1;
-                    const int i = b + ri, k = b + rk;
-                    double acc[4];
-                    prod_nt<4>(lds + slot_of(i, b) + r, lds + slot_of(k, b), c0, acc);
-                    double* C = lds + slot_of(i, k);
+                    const double* P = lds + slot_of(b + ri, b);
+                    const double* Q = lds + slot_of(b + rk, b);
+                    double* C = lds + slot_of(b + ri, b + rk);
+                    // result (x along the lanes): C[x + 32 y], x = 16 tx + l15, y = 16 ty + lq + 4 reg
+                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) C[r + SB * (c0 + c)] -= acc[c];
-                }
-            }
-            lds_barrier();  // C
-            if (w == 1 && lane == 0) ts[16 + 8 * b + 2] = __builtin_amdgcn_s_memtime();
-
-            // ---- ph3: (1): W_bc = X_bb W_bc for c < b (in place, column-local to one task)
-            if (want_inv) {
-                for (int task = u; task < 4 * b; task += 7) {
-                    double* Wbc = lds + slot_of(b, task >> 2);
-                    const int c0 = ((task & 3) * 2 + h) * 4;
-                    double acc[4];
-                    prod_nn<4>(Lbb + r, Wbc, c0, acc);
+                    for (int kk = 0; kk < SB / 4; ++kk) {
+                        const double pf = P[(HB * tx + l15) + SB * (4 * kk + lq)];
+                        const double qf = Q[(HB * ty + l15) + SB * (4 * kk + lq)];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qf, pf, acc, 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) Wbc[r + SB * (c0 + c)] = acc[c];
-                }
-            }
-            lds_barrier();  // D
-            if (w == 1 && lane == 0) ts[16 + 8 * b + 3] = __builtin_amdgcn_s_memtime();
-
-            // ---- ph4: (2): W_ic -= L_ib W_bc (i > b, c < b)
-            if (want_inv) {
-                const int n2 = (nblk - b - 1) * b;
-                for (int task = u; task < 4 * n2; task += 7) {
-                    const int q = task >> 2;
-                    const int c0 = ((task & 3) * 2 + h) * 4;
+                    for (int reg = 0; reg < 4; ++reg) C[(HB * tx + l15) + SB * (HB * ty + lq + 4 * reg)] -= acc[reg];
+                } else {
+                    const int q = pidx - nU;
                     const int i = b + 1 + q / b, cb = q % b;
-                    double acc[4];
-                    prod_nn<4>(lds + slot_of(i, b) + r, lds + slot_of(b, cb), c0, acc);
-                    double* C = lds + slot_of(i, cb);
+                    const double* P = lds + slot_of(i, b);    // L_ib, normal
+                    const double* Q = lds + slot_of(b, cb);   // WT_b,cb
+                    double* C = lds + slot_of(i, cb);         // WT_i,cb
+                    // result (y along the lanes): WT[y + 32 x], y = 16 ty + l15, x = 16 tx + lq + 4 reg
+                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) C[r + SB * (c0 + c)] -= acc[c];
-                }
-            }
-            lds_barrier();  // E
-            if (w == 1 && lane == 0) ts[16 + 8 * b + 4] = __builtin_amdgcn_s_memtime();
-
-            // ---- ph5: (3): W_ib = -L_ib X_bb, in place over the now dead L_ib (all reads, a barrier, then the stores)
-            {
-                const int i = b + 1 + (u >> 1);
-                const bool act = want_inv && (u < 6) && i < nblk;
-                double* Wib = lds + slot_of(act ? i : b, act ? b : 0);
-                const int c0 = ((u & 1) * 2 + h) * 8;
-                double acc[8];
-                if (act) prod_nn<8>(Wib + r, Lbb, c0, acc);
-                lds_barrier();  // F
-            if (w == 1 && lane == 0) ts[16 + 8 * b + 5] = __builtin_amdgcn_s_memtime();
-                if (act) {
+                    for (int kk = 0; kk < SB / 4; ++kk) {
+                        const double pf = P[(HB * tx + l15) + SB * (4 * kk + lq)];
+                        const double qf = Q[(HB * ty + l15) + SB * (4 * kk + lq)];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pf, qf, acc, 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) Wib[r + SB * (c0 + c)] = -acc[c];
+                    for (int reg = 0; reg < 4; ++reg) C[(HB * ty + l15) + SB * (HB * tx + lq + 4 * reg)] -= acc[reg];
                 }
-                lds_barrier();  // G
-            if (w == 1 && lane == 0) ts[16 + 8 * b + 6] = __builtin_amdgcn_s_memtime();
             }
         }
+        lds_barrier();
+        if (w == 1 && lane == 0) ts[16 + 8 * b + 1] = __builtin_amdgcn_s_memtime();
+
+        // ---- P3
+        if (want_inv && u < 3 && b + 1 + u < nblk) {
+            const int l15 = lane & 15, lq = lane >> 4;
+            double* Wib = lds + slot_of(b + 1 + u, b);  // L_ib (normal) in, WT_ib out
+            d4_t acc[2][2];
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty) acc[tx][ty] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < SB / 4; ++kk) {
+                double pf[2], qf[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    pf[tt] = Wib[(HB * tt + l15) + SB * (4 * kk + lq)];
+                    qf[tt] = Lbb[(HB * tt + l15) + SB * (4 * kk + lq)];  // XT_bb
+                }
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                    for (int ty = 0; ty < 2; ++ty)
+                        acc[tx][ty] = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[tx], qf[ty], acc[tx][ty], 0, 0, 0);
+            }
+            // every read of L_ib is behind us (one wave, program order): overwrite it with -(...) transposed
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        Wib[(HB * ty + l15) + SB * (HB * tx + lq + 4 * reg)] = -acc[tx][ty][reg];
+        }
+        lds_barrier();
+        if (w == 1 && lane == 0) ts[16 + 8 * b + 2] = __builtin_amdgcn_s_memtime();
+    }
     }
 
-    // ---- store the inverse (lower blocks from LDS, zeros above)
+    // ---- store the inverse: the LDS sub-blocks are transposed (zeros above the diagonal)
     if (want_inv) {
         const int cg = t >> 5;
         for (int i = 0; i < nblk; ++i)
@@ -571,7 +615,7 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
                 for (int cc = 0; cc < 2; ++cc) {
                     const int c = cg * 2 + cc;
                     const int gr = SB * i + r, gc = SB * k + c;
-                    if (gr < n && gc < n) inv[gr + (int64_t)gc * ldinv] = (k <= i) ? s[r + SB * c] : 0.0;
+                    if (gr < n && gc < n) inv[gr + (int64_t)gc * ldinv] = (k <= i) ? s[c + SB * r] : 0.0;
                 }
             }
     }
@@ -592,6 +636,6 @@ int main(){
     if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);
       long long prev=t[1]; for(int b=0;b<4;++b){ printf(" | F%d %lld upd %lld", b, t[2+2*b]-prev, t[3+2*b]-t[2+2*b]); prev=t[3+2*b]; }
       printf(" | store %lld | total %lld\n", t[10]-prev, t[10]-t[0]);
-      for(int b=0;b<4;++b){ printf("  stage %d (update wave 0): T/X %lld | Xstore+U %lld | (1) %lld | (2) %lld | (3)read %lld | (3)store %lld\n", b, t[16+8*b+1]-t[16+8*b], t[16+8*b+2]-t[16+8*b+1], t[16+8*b+3]-t[16+8*b+2], t[16+8*b+4]-t[16+8*b+3], t[16+8*b+5]-t[16+8*b+4], t[16+8*b+6]-t[16+8*b+5]); } }
+      for(int b=0;b<4;++b){ printf("  stage %d (update wave 0): P2 products %lld | P3 %lld\n", b, t[16+8*b+1]-t[16+8*b], t[16+8*b+2]-t[16+8*b+1]); } }
   }
   return 0; }
