@@ -178,29 +178,27 @@ struct FState {
     bool row_ok;
 };
 
-// The pivot of step J + 1 (sqrt and reciprocal of the next diagonal value) is a chain of ~13 dependent f64 operations.
-// It is cut into stages: the first ones run while the broadcast reads of the step are in flight, the others are
-// interleaved with the rank-1 updates (pinned with sched_barrier) so that the chain's latency hides behind them.
+// The reciprocal pivot of step J + 1 is a chain of dependent f64 operations on the critical path of the whole
+// factorisation (and every one of them queues behind the MFMAs of a co-resident GEMM wave), so it is kept minimal:
+// v_rsq_f64 seed + two Newton steps give r = 1 / sqrt(d) to about an ulp, and that IS what the next column is
+// multiplied by.  sqrt(d) itself (the stored diagonal) is derived off the chain.  The stages are interleaved with the
+// rest of the step (pinned with sched_barrier).
 struct PivotChain {
-    double d, r, h, q, t;
+    double d, r, h, t;
 };
 
 template <bool M3, int K>
 __device__ __forceinline__ void chain_stage(PivotChain& c)
 {
-    if constexpr (M3) {  // the block already holds the factor: p = d, ip = 1 / d (reciprocal seed + two Newton steps)
+    if constexpr (M3) {  // the block already holds the factor: 1 / d (reciprocal seed + two Newton steps)
         if constexpr (K == 0) c.r = __builtin_amdgcn_rcp(c.d);
         if constexpr (K == 1) c.t = __builtin_fma(-c.d, c.r, 1.0);
         if constexpr (K == 2) c.r = __builtin_fma(c.r, c.t, c.r);
         if constexpr (K == 3) c.t = __builtin_fma(-c.d, c.r, 1.0);
         if constexpr (K == 4) c.r = __builtin_fma(c.r, c.t, c.r);
-        if constexpr (K == 5) c.q = c.d;
         if constexpr (K == 0 || K == 2 || K == 4) pin(c.r);
         if constexpr (K == 1 || K == 3) pin(c.t);
     } else {
-        // v_rsq_f64 seed + two Newton steps give r = 1 / sqrt(d) to about an ulp: that IS the reciprocal pivot (the
-        // column scaling below corrects its quotient with one residual step against p, so r needs no further polish);
-        // p = sqrt(d) = d r with one Heron correction.  r is ready after stage 6, p after stage 9.
         if constexpr (K == 0) {
             c.r = __builtin_amdgcn_rsq(c.d);
             c.h = -0.5 * c.d;
@@ -211,58 +209,34 @@ __device__ __forceinline__ void chain_stage(PivotChain& c)
         if constexpr (K == 4) c.t = c.h * c.r;
         if constexpr (K == 5) c.t = __builtin_fma(c.t, c.r, 1.5);
         if constexpr (K == 6) c.r = c.r * c.t;
-        if constexpr (K == 7) {
-            c.q = c.d * c.r;
-            c.h = 0.5 * c.r;
-        }
-        if constexpr (K == 8) c.t = __builtin_fma(-c.q, c.q, c.d);
-        if constexpr (K == 9) c.q = __builtin_fma(c.h, c.t, c.q);
-        if constexpr (K == 10) {
-            const bool zero = (c.d == 0.0);  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
-            c.q = zero ? 0.0 : c.q;
-            c.r = zero ? __builtin_inf() : c.r;
-        }
-        if constexpr (K == 0 || K == 3 || K == 6 || K == 10) pin(c.r);
-        if constexpr (K == 1 || K == 2 || K == 4 || K == 5 || K == 8) pin(c.t);
-        if constexpr (K == 7 || K == 9 || K == 10) pin(c.q);
-        if constexpr (K == 0 || K == 7) pin(c.h);
+        if constexpr (K == 7) c.r = (c.d == 0.0) ? __builtin_inf() : c.r;  // plain-sqrt mode: the reference divides by 0
+        if constexpr (K == 0 || K == 3 || K == 6 || K == 7) pin(c.r);
+        if constexpr (K == 1 || K == 2 || K == 4 || K == 5) pin(c.t);
+        if constexpr (K == 0) pin(c.h);
     }
 }
 
 template <bool M3>
 struct ChainShape {
-    static constexpr int NST = M3 ? 6 : 11;
-    static constexpr int HEAD = M3 ? 6 : 11;  // stages issued back to back while the broadcasts are in flight
+    static constexpr int NST = M3 ? 5 : 8;
 };
-
-template <bool M3, int K0, int K1>
-__device__ __forceinline__ void chain_run(PivotChain& c)
-{
-    if constexpr (K0 < K1) {
-        chain_stage<M3, K0>(c);
-        chain_run<M3, K0 + 1, K1>(c);
-    }
-}
 
 // Pivot rule for a diagonal value that is 0, negative or NaN (any mode but plain-sqrt): the replacement pivot
 // (sqrt(sub) and its reciprocal, or NaN = failure) is prepared once per launch and selected without a branch; the
 // column is only noted in a bit mask.  The log in global memory is written after the unrolled steps: a memory access on
 // a rare path inside them would make every step wait for the outstanding factor-column stores at the join.
-__device__ __forceinline__ void pivot_select(const FState& st, double d, int j, double& p, double& ip, unsigned& excmask)
+__device__ __forceinline__ void pivot_select(const FState& st, double d, int j, double& ip, unsigned& excmask)
 {
     const bool bad = !(st.mode == 2 || d > 0.0);
-    p = bad ? st.p_exc : p;
     ip = bad ? st.ip_exc : ip;
     excmask |= bad ? (1u << j) : 0u;
 }
 
-// pairs P .. of step J: a(r, c) -= L(r, J) L(c, J) for the lane's slots, one chain stage per pair.  Slots whose column
-// is already final are dead registers in this routine: they are updated along with the others (no predicate).
+// pairs P .. of step J: a(r, c) -= L(r, J) L(c, J) for the lane's slots.  Slots whose column is already final are dead
+// registers in this routine: they are updated along with the others (no predicate).
 template <int J, int P>
-__device__ __forceinline__ void f_pairs(double (&a)[HB], double l, PivotChain& ch, const ColBcast& cb)
+__device__ __forceinline__ void f_pairs(double (&a)[HB], double l, const ColBcast& cb)
 {
-    constexpr int NST = ChainShape<false>::NST, HEAD = ChainShape<false>::HEAD;
-    constexpr int P0 = first_live_slot(J) / 2;
     if constexpr (P < HB / 2) {
         if constexpr (2 * P >= first_live_slot(J)) {
             a[2 * P] = __builtin_fma(-l, cb.v[P].x, a[2 * P]);
@@ -272,61 +246,80 @@ __device__ __forceinline__ void f_pairs(double (&a)[HB], double l, PivotChain& c
             a[2 * P + 1] = __builtin_fma(-l, cb.v[P].y, a[2 * P + 1]);
             pin(a[2 * P + 1]);
         }
-        if constexpr (P >= P0 && HEAD + (P - P0) < NST && J + 1 < SB) chain_stage<false, HEAD + (P - P0)>(ch);
-        __builtin_amdgcn_sched_barrier(0);
-        f_pairs<J, P + 1>(a, l, ch, cb);
+        f_pairs<J, P + 1>(a, l, cb);
     }
 }
 
 // one elimination step; J is a compile-time constant so that every register index and lane select is static
-// (template recursion instead of `#pragma unroll`: the body is beyond clang's pragma-unroll budget)
+// (template recursion instead of `#pragma unroll`: the body is beyond clang's pragma-unroll budget).
+// d = the diagonal value of column J, ip = its reciprocal pivot after the pivot rule.
 template <bool M3, int J>
-__device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double p, double ip, unsigned& excmask)
+__device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double d, double ip, unsigned& excmask)
 {
     constexpr int hJ = J / HB, kJ = J % HB;
-    // column J (owner half): col /= denom as reciprocal multiply + one residual correction
+    constexpr int hN = (J + 1) / HB, kN = (J + 1) % HB;
+    constexpr int NST = ChainShape<M3>::NST;
+    constexpr bool next = J + 1 < SB;
+    // ---- critical path first: column J scaled by the reciprocal pivot, the next diagonal value, the head of its chain.
+    // The next diagonal value needs no broadcast: its lane multiplies by its own L(J + 1, J).
     const double v = a[kJ];
-    double q = v * ip;
-    q = __builtin_fma(__builtin_fma(-q, p, v), ip, q);
-    if constexpr (M3) q = v;
-    // Padding rows / columns (block smaller than 128) are forced to stay the identity: 0 * inf = NaN would otherwise
-    // leak from an overflowing substituted factor into the log
-    const bool live = st.row_ok && J < st.ncols_ok;
-    const double l_own = (st.r > J && live) ? q : 0.0;
-    if (st.h == hJ) {
-        // the LDS image of column J: 1 / pivot on the diagonal, L below, zeros above
-        st.cptr[SB * J] = (st.r == J) ? ip : l_own;
-        *st.flag = st.flag_base + J + 1;  // after the column in this wave's LDS order: the solves of P1 may consume it
-        if constexpr (!M3) {
-            if (st.r >= J && live) *st.gptr = (st.r == J) ? p : q;
-        }
-    }
-    if constexpr (!M3) st.gptr += st.lda;
-    const double l = bcast_half<hJ>(l_own);  // L(r, J) in both halves
-    ColBcast cb;
-    if constexpr (!M3) col_load<J, 0>(cb, st.bufh);
+    const double q = M3 ? v : v * ip;
     PivotChain ch;
-    if constexpr (J + 1 < SB) {
-        // the next diagonal value needs no broadcast: its lane multiplies by its own L(J + 1, J)
-        constexpr int hN = (J + 1) / HB, kN = (J + 1) % HB;
-        // (when that lane sits in the owner half it does not even wait for the exchange between the halves)
+    if constexpr (next && hN == hJ) {
         double dn = a[kN];
-        if constexpr (!M3) dn = (hN == hJ) ? __builtin_fma(-q, q, dn) : __builtin_fma(-l, l, dn);
+        if constexpr (!M3) dn = __builtin_fma(-q, q, dn);
         ch.d = readlane_f64(dn, (J + 1) + SB * hN);  // next pivot candidate (uniform)
-        chain_run<M3, 0, ChainShape<M3>::HEAD>(ch);
+        chain_stage<M3, 0>(ch);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!M3) {
-        f_pairs<J, 0>(a, l, ch, cb);
-        if constexpr (J + 1 < SB) {
-            constexpr int done = ChainShape<false>::HEAD + (HB / 2 - first_live_slot(J) / 2);
-            chain_run<false, (done < ChainShape<false>::NST ? done : ChainShape<false>::NST), ChainShape<false>::NST>(ch);
-        }
+    // ---- L(r, J) in both halves.  Padding rows / columns (block smaller than 128) are forced to stay the identity:
+    // 0 * inf = NaN would otherwise leak from an overflowing substituted factor into the log
+    const bool live = st.row_ok && J < st.ncols_ok;
+    const double l_own = (st.r > J && live) ? q : 0.0;
+    const double l = bcast_half<hJ>(l_own);
+    if constexpr (next && hN != hJ) {  // the pivot lane sits in the other half (J = 15): it needs the exchange first
+        double dn = a[kN];
+        if constexpr (!M3) dn = __builtin_fma(-l, l, dn);
+        ch.d = readlane_f64(dn, (J + 1) + SB * hN);
+        chain_stage<M3, 0>(ch);
     }
-    if constexpr (J + 1 < SB) {
-        double pn = ch.q, ipn = ch.r;
-        if constexpr (!M3) pivot_select(st, ch.d, J + 1, pn, ipn, excmask);
-        f_step<M3, J + 1>(a, st, pn, ipn, excmask);
+    if constexpr (next && 1 < NST) chain_stage<M3, 1>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the LDS image of column J (owner half): 1 / pivot on the diagonal, L below, zeros above; then the counter
+    if (st.h == hJ) {
+        st.cptr[SB * J] = (st.r == J) ? ip : l_own;
+        *st.flag = st.flag_base + J + 1;  // after the column in this wave's LDS order: the solves of P1 may consume it
+    }
+    if constexpr (next && 2 < NST) chain_stage<M3, 2>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    ColBcast cb;
+    if constexpr (!M3) col_load<J, 0>(cb, st.bufh);
+    if constexpr (next && 3 < NST) chain_stage<M3, 3>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- off the chain: the diagonal entry sqrt(d) = d ip with one Heron correction, and the column to global memory
+    if constexpr (!M3) {
+        double pq = d * ip;
+        if constexpr (next && 4 < NST) chain_stage<M3, 4>(ch);
+        __builtin_amdgcn_sched_barrier(0);
+        const double pe = __builtin_fma(-pq, pq, d);
+        if constexpr (next && 5 < NST) chain_stage<M3, 5>(ch);
+        __builtin_amdgcn_sched_barrier(0);
+        pq = __builtin_fma(0.5 * ip, pe, pq);
+        pq = (d == 0.0) ? 0.0 : pq;                            // plain-sqrt mode, d == 0
+        pq = ((excmask >> J) & 1u) ? st.p_exc : pq;            // substituted / failed pivot
+        if (st.h == hJ && st.r >= J && live) *st.gptr = (st.r == J) ? pq : q;
+        st.gptr += st.lda;
+        if constexpr (next && 6 < NST) chain_stage<M3, 6>(ch);
+        if constexpr (next && 7 < NST) chain_stage<M3, 7>(ch);
+        __builtin_amdgcn_sched_barrier(0);
+        f_pairs<J, 0>(a, l, cb);
+    } else {
+        if constexpr (next && 4 < NST) chain_stage<M3, 4>(ch);
+    }
+    if constexpr (next) {
+        double ipn = ch.r;
+        if constexpr (!M3) pivot_select(st, ch.d, J + 1, ipn, excmask);
+        f_step<M3, J + 1>(a, st, ch.d, ipn, excmask);
     }
 }
 
@@ -359,15 +352,15 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, do
     // first pivot
     unsigned excmask = 0;
     const double d0 = readlane_f64(a[0], 0);
-    double p, ip;
+    double ip;
     if constexpr (M3) {
-        p = d0;
         ip = 1.0 / d0;
     } else {
+        double p;
         sqrt_rsqrt(d0, p, ip);
-        pivot_select(st, d0, 0, p, ip, excmask);
+        pivot_select(st, d0, 0, ip, excmask);
     }
-    f_step<M3, 0>(a, st, p, ip, excmask);
+    f_step<M3, 0>(a, st, d0, ip, excmask);
     if (st.ncols_ok < SB) excmask &= (1u << (st.ncols_ok > 0 ? st.ncols_ok : 0)) - 1u;
     if (excmask != 0 && lane == 0) {  // the log: substituted columns in order, or the first failing column
         if (substitute) {
@@ -493,6 +486,9 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
     // Wave 0 runs only F_b and the barriers (its own branch keeps the unrolled pivot chain free of the update phases'
     // register pressure); waves 1..7 are the update waves.
     if (w == 0) {
+        // the pivot chain is the critical path of the whole factorisation and shares its SIMD with a GEMM wave of the
+        // co-resident trailing update: take the issue slot whenever both are ready
+        __builtin_amdgcn_s_setprio(3);
         for (int b = 0; b < nblk; ++b) {
             if (m3)
                 factor_subblock<true>(lds, b, lane, A, lda, n, col0, mode, sub, info);
