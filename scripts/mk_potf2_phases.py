@@ -22,18 +22,27 @@ prog = '''#include <hip/hip_runtime.h>
 #include <cstdint>
 #include <vector>
 #include <cmath>
-#define FR_OK 0
+#include <unistd.h>
+#include "friedrich_amd.h"
 namespace fr {
 ''' + kern + '''}
-int main(){
+int main(int argc, char** argv){
+  const bool noise = argc > 1;
+  fr_ctx* ctx = nullptr; double *NA = nullptr, *NC = nullptr; const int64_t NM = 16384, NK = 512;
+  if (noise) {
+    if (fr_ctx_create(&ctx, 0) != FR_OK) { printf("ctx failed\\n"); return 1; }
+    (void)hipMalloc(&NA, NM*NK*8); (void)hipMalloc(&NC, NM*NM*8); (void)hipMemset(NA, 0, NM*NK*8); (void)hipMemset(NC, 0, NM*NM*8);
+  }
+  hipStream_t hs; int lo_p, hi_p; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p); (void)hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, hi_p);
   const int n=128; std::vector<double> h(n*n);
   for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
   double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*64);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
   for(int rep=0;rep<3;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
-    hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,0);
-    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,0); (void)hipDeviceSynchronize();
+    if (noise) { for (int g = 0; g < 6; ++g) fr_gemm(ctx, 0, 1, NM, NM, NK, -1.0, NA, NM, NA, NM, 1.0, NC, NM); usleep(6000); }
+    hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,hs);
+    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,hs); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms,e0,e1);
     long long t[64]; (void)hipMemcpy(t,ts,8*64,hipMemcpyDeviceToHost);
     if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);

@@ -3,7 +3,8 @@
 #include <cstdint>
 #include <vector>
 #include <cmath>
-#define FR_OK 0
+#include <unistd.h>
+#include "friedrich_amd.h"
 namespace fr {
 constexpr int PB = 128;  // largest block
 constexpr int SB = 32;   // sub-block
@@ -364,7 +365,7 @@ __device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, i
     ColBcast nx;
     double ipn = 0.0;
     if constexpr (J + 1 < SB) {
-        wait_columns(flag, flag_base + J + 2);
+        wait_columns(flag, flag_base + SB);
         col_load<J + 1, 0>(nx, bufh);
         ipn = bufh[(J + 1) + SB * (J + 1) - HB * h];  // image[(J+1) + 32 (J+1)], uniform
     }
@@ -393,7 +394,7 @@ __device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, i
 {
     const double* bufh = image + HB * h;
     ColBcast cb;
-    wait_columns(flag, flag_base + 1);
+    wait_columns(flag, flag_base + SB);
     col_load<0, 0>(cb, bufh);
     const double ip0 = image[0];
     trsm_step<0>(x, bufh, h, cb, ip0, flag, flag_base);
@@ -457,7 +458,9 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
     // Wave 0 runs only F_b and the barriers (its own branch keeps the unrolled pivot chain free of the update phases'
     // register pressure); waves 1..7 are the update waves.
     if (w == 0) {
-        if (lane == 0) ts[1] = __builtin_amdgcn_s_memtime();
+        // the pivot chain is the critical path of the whole factorisation and shares its SIMD with a GEMM wave of the
+        // co-resident trailing update: take the issue slot whenever both are ready
+        __builtin_amdgcn_s_setprio(3);
         for (int b = 0; b < nblk; ++b) {
             if (m3)
                 factor_subblock<true>(lds, b, lane, A, lda, n, col0, mode, sub, info);
@@ -615,15 +618,23 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
     if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();
 }
 }
-int main(){
+int main(int argc, char** argv){
+  const bool noise = argc > 1;
+  fr_ctx* ctx = nullptr; double *NA = nullptr, *NC = nullptr; const int64_t NM = 16384, NK = 512;
+  if (noise) {
+    if (fr_ctx_create(&ctx, 0) != FR_OK) { printf("ctx failed\n"); return 1; }
+    (void)hipMalloc(&NA, NM*NK*8); (void)hipMalloc(&NC, NM*NM*8); (void)hipMemset(NA, 0, NM*NK*8); (void)hipMemset(NC, 0, NM*NM*8);
+  }
+  hipStream_t hs; int lo_p, hi_p; (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p); (void)hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, hi_p);
   const int n=128; std::vector<double> h(n*n);
   for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
   double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*64);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
   for(int rep=0;rep<3;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
-    hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,0);
-    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,0,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,0); (void)hipDeviceSynchronize();
+    if (noise) { for (int g = 0; g < 6; ++g) fr_gemm(ctx, 0, 1, NM, NM, NK, -1.0, NA, NM, NA, NM, 1.0, NC, NM); usleep(6000); }
+    hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,hs);
+    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,hs); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms,e0,e1);
     long long t[64]; (void)hipMemcpy(t,ts,8*64,hipMemcpyDeviceToHost);
     if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);
