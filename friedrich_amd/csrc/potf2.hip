@@ -381,20 +381,25 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, do
 // broadcasts of column J + 1 are issued while column J is applied (the image is read-only in this phase).
 // The solves run CONCURRENTLY with F_b on other waves: they consume column J of the image as soon as the panel wave has
 // published it (LDS counter, polled), one step behind the pivot chain, and finish a step after it.
-__device__ __forceinline__ void wait_columns(const int* flag, int target)
+// `avail` caches the last value seen: a solve that has fallen behind the pivot chain does not touch the counter again
+// until it has caught up (next to a GEMM workgroup an LDS round trip costs ~900 cycles).
+__device__ __forceinline__ void wait_columns(const int* flag, int target, int& avail)
 {
-    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(flag)) < target) __builtin_amdgcn_s_sleep(1);
+    while (avail < target) {
+        avail = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(flag));
+        if (avail < target) __builtin_amdgcn_s_sleep(1);
+    }
 }
 
 template <int J>
 __device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, int h, const ColBcast& cb, double ipj,
-                                          const int* flag, int flag_base)
+                                          const int* flag, int flag_base, int& avail)
 {
     constexpr int hJ = J / HB, kJ = J % HB;
     ColBcast nx;
     double ipn = 0.0;
     if constexpr (J + 1 < SB) {
-        wait_columns(flag, flag_base + J + 2);
+        wait_columns(flag, flag_base + J + 2, avail);
         col_load<J + 1, 0>(nx, bufh);
         ipn = bufh[(J + 1) + SB * (J + 1) - HB * h];  // image[(J+1) + 32 (J+1)], uniform
     }
@@ -416,17 +421,18 @@ __device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, i
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (J + 1 < SB) trsm_step<J + 1>(x, bufh, h, nx, ipn, flag, flag_base);
+    if constexpr (J + 1 < SB) trsm_step<J + 1>(x, bufh, h, nx, ipn, flag, flag_base, avail);
 }
 
 __device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, int h, const int* flag, int flag_base)
 {
     const double* bufh = image + HB * h;
     ColBcast cb;
-    wait_columns(flag, flag_base + 1);
+    int avail = 0;
+    wait_columns(flag, flag_base + 1, avail);
     col_load<0, 0>(cb, bufh);
     const double ip0 = image[0];
-    trsm_step<0>(x, bufh, h, cb, ip0, flag, flag_base);
+    trsm_step<0>(x, bufh, h, cb, ip0, flag, flag_base, avail);
 }
 
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
@@ -546,43 +552,61 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
             const int nU = m3 ? 0 : rem * (rem + 1) / 2;
             const int n2 = want_inv ? rem * b : 0;
             const int l15 = lane & 15, lq = lane >> 4;
-            // update wave 3 joins after its store: the task list is dealt to the other waves first
-            for (int task = (u + 3) % 7; task < 4 * (nU + n2); task += 7) {
-                const int pidx = task >> 2;
-                const int tx = (task >> 1) & 1, ty = task & 1;
-                if (pidx < nU) {
-                    // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b
-                    const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
-                    const int rk = pidx - ri * (ri - 1) / 2 + 1;
-                    const double* P = lds + slot_of(b + ri, b);
-                    const double* Q = lds + slot_of(b + rk, b);
-                    double* C = lds + slot_of(b + ri, b + rk);
-                    // result (x along the lanes): C[x + 32 y], x = 16 tx + l15, y = 16 ty + lq + 4 reg
-                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            // Every wave takes its tile tasks four at a time (independent accumulator chains): next to a GEMM workgroup a
+            // wave gets the matrix core in turns, and a turn takes whatever is ready.  Update wave 3 joins after its
+            // store: the task list is dealt to the other waves first.
+            const int ntask = 4 * (nU + n2);
+            for (int task0 = (u + 3) % 7; task0 < ntask; task0 += 28) {
+                d4_t acc[4];
+                const double* Pp[4];
+                const double* Qp[4];
+                double* Cp[4];
+                bool tr[4], on[4];
 #pragma unroll
-                    for (int kk = 0; kk < SB / 4; ++kk) {
-                        const double pf = P[(HB * tx + l15) + SB * (4 * kk + lq)];
-                        const double qf = Q[(HB * ty + l15) + SB * (4 * kk + lq)];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qf, pf, acc, 0, 0, 0);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int task = task0 + 7 * s4;
+                    on[s4] = task < ntask;
+                    const int pidx = on[s4] ? (task >> 2) : 0;
+                    const int tx = (task >> 1) & 1, ty = task & 1;
+                    acc[s4] = d4_t{0.0, 0.0, 0.0, 0.0};
+                    if (pidx < nU) {
+                        // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b:  C[x + 32 y] (x along the lanes)
+                        const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
+                        const int rk = pidx - ri * (ri - 1) / 2 + 1;
+                        tr[s4] = false;
+                        Pp[s4] = lds + slot_of(b + ri, b) + HB * tx + l15 + SB * lq;
+                        Qp[s4] = lds + slot_of(b + rk, b) + HB * ty + l15 + SB * lq;
+                        Cp[s4] = lds + slot_of(b + ri, b + rk) + (HB * tx + l15) + SB * (HB * ty + lq);
+                    } else {
+                        // (2): WT_i,cb[y + 32 x] (y along the lanes) -= L_ib WT_b,cb
+                        const int q = pidx - nU;
+                        const int bb = b > 0 ? b : 1;
+                        const int i = b + 1 + q / bb, cb = q % bb;
+                        tr[s4] = true;
+                        Pp[s4] = lds + slot_of(i, b) + HB * tx + l15 + SB * lq;
+                        Qp[s4] = lds + slot_of(b, cb) + HB * ty + l15 + SB * lq;
+                        Cp[s4] = lds + slot_of(i, cb) + (HB * ty + l15) + SB * (HB * tx + lq);
                     }
+                }
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) C[(HB * tx + l15) + SB * (HB * ty + lq + 4 * reg)] -= acc[reg];
-                } else {
-                    const int q = pidx - nU;
-                    const int i = b + 1 + q / b, cb = q % b;
-                    const double* P = lds + slot_of(i, b);    // L_ib, normal
-                    const double* Q = lds + slot_of(b, cb);   // WT_b,cb
-                    double* C = lds + slot_of(i, cb);         // WT_i,cb
-                    // result (y along the lanes): WT[y + 32 x], y = 16 ty + l15, x = 16 tx + lq + 4 reg
-                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < SB / 4; ++kk) {
 #pragma unroll
-                    for (int kk = 0; kk < SB / 4; ++kk) {
-                        const double pf = P[(HB * tx + l15) + SB * (4 * kk + lq)];
-                        const double qf = Q[(HB * ty + l15) + SB * (4 * kk + lq)];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pf, qf, acc, 0, 0, 0);
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        if (on[s4]) {
+                            const double pf = Pp[s4][SB * 4 * kk];
+                            const double qf = Qp[s4][SB * 4 * kk];
+                            // result index of the FIRST operand runs over lq + 4 reg, of the SECOND over the lanes
+                            acc[s4] = tr[s4] ? __builtin_amdgcn_mfma_f64_16x16x4f64(pf, qf, acc[s4], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f64_16x16x4f64(qf, pf, acc[s4], 0, 0, 0);
+                        }
                     }
+                }
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) C[(HB * ty + l15) + SB * (HB * tx + lq + 4 * reg)] -= acc[reg];
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (on[s4]) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) Cp[s4][SB * 4 * reg] -= acc[s4][reg];
+                    }
                 }
             }
         }
