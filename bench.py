@@ -95,16 +95,23 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # FRIEDRICH_BENCH_FORCE_DIST=1 takes the multi-process set-up (process group, ncclUniqueId hand-over, communicator
+    # self-test) with a single rank too: the only way to exercise it on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("FRIEDRICH_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     ctx = Context(local_rank)
     ctx.set_option("nb", args.nb)
-    if world > 1:
+    if use_dist:
         ids = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(rank, world, ids[0])
+        ctx.comm_selftest()
 
     n, d, m = args.n, args.d, args.m
     cfg = 4
@@ -128,7 +135,7 @@ def main():
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     fit_ms, pred_ms = [], []
@@ -158,7 +165,7 @@ def main():
     prof = ctx.profile()
     ctx.profile_enable(False)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -220,7 +227,7 @@ def main():
 
     chol.free()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

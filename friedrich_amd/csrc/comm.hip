@@ -17,6 +17,7 @@
 #include <mutex>
 
 #include "fr_internal.hpp"
+#include <vector>
 
 namespace fr {
 
@@ -259,6 +260,53 @@ int fr_ctx_comm_init_local(fr_ctx* ctx, int group_id, int rank, int world_size)
     ctx->rank = rank;
     ctx->world = world_size;
     return FR_OK;
+}
+
+int fr_ctx_comm_selftest(fr_ctx* ctx)
+{
+    if (!ctx) return FR_INVALID_ARGUMENT;
+    if (!ctx->comm && !ctx->local) return FR_OK;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->world, R = ctx->rank;
+    const size_t cnt = 256;
+    std::vector<double> h(cnt * (size_t)(2 + W));
+    for (size_t i = 0; i < cnt; ++i) {
+        h[i] = 1000.0 * R + (double)i;        // broadcast buffer (rank 0's content must win)
+        h[cnt + i] = 2000.0 * R + (double)i;  // all-gather contribution
+    }
+    double* d = nullptr;
+    FR_HIP(ctx, hipMalloc(&d, sizeof(double) * h.size()));
+    int st = FR_OK;
+    hipStream_t saved = ctx->ls;
+    ctx->ls = ctx->stream2 ? ctx->stream2 : ctx->stream;  // the panel stream carries the broadcasts of the factorisation
+    do {
+        if (hipMemcpyAsync(d, h.data(), sizeof(double) * 2 * cnt, hipMemcpyHostToDevice, ctx->ls) != hipSuccess) {
+            st = set_err(ctx, FR_HIP_ERROR, "selftest: upload failed");
+            break;
+        }
+        const int world_saved = ctx->world;
+        if (W == 1 && ctx->comm) ctx->world = 2;  // a 1-rank RCCL communicator: still issue the real collectives
+        st = comm_bcast(ctx, d, cnt, 0);
+        if (st == FR_OK) st = comm_allgather(ctx, d + cnt, d + 2 * cnt, cnt);
+        ctx->world = world_saved;
+        if (st != FR_OK) break;
+        if (hipStreamSynchronize(ctx->ls) != hipSuccess ||
+            hipMemcpy(h.data(), d, sizeof(double) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+            st = set_err(ctx, FR_HIP_ERROR, "selftest: download failed");
+            break;
+        }
+        for (size_t i = 0; i < cnt && st == FR_OK; ++i)
+            if (h[i] != (double)i) st = set_err(ctx, FR_RCCL_ERROR, "selftest: broadcast payload mismatch at %zu", i);
+        for (int r = 0; r < W && st == FR_OK; ++r)
+            for (size_t i = 0; i < cnt; ++i)
+                if (h[(2 + (size_t)r) * cnt + i] != 2000.0 * r + (double)i) {
+                    st = set_err(ctx, FR_RCCL_ERROR, "selftest: all-gather payload mismatch (rank %d, %zu)", r, i);
+                    break;
+                }
+    } while (0);
+    ctx->ls = saved;
+    (void)hipFree(d);
+    return st;
 }
 
 int fr_ctx_comm_info(const fr_ctx* ctx, int* rank, int* world_size)

@@ -149,6 +149,10 @@ class Context:
         buf = ctypes.create_string_buffer(unique_id, C.FR_COMM_ID_BYTES) if unique_id is not None else None
         self.check(self.lib.fr_ctx_comm_init(self.h, int(rank), int(world_size), buf))
 
+    def comm_selftest(self):
+        """one broadcast + one all-gather through the attached communicator, verified (collective)"""
+        self.check(self.lib.fr_ctx_comm_selftest(self.h))
+
     def comm_init_local(self, group_id, rank, world_size):
         """in-process transport (ranks = threads sharing one GPU); see fr_ctx_comm_init_local"""
         self.check(self.lib.fr_ctx_comm_init_local(self.h, int(group_id), int(rank), int(world_size)))

@@ -119,6 +119,10 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
  * group_id form one communicator).  Lets the sharded path run on a 1-GPU box; not a performance path. */
 int fr_ctx_comm_init_local(fr_ctx* ctx, int group_id, int rank, int world_size);
 int fr_ctx_comm_info(const fr_ctx* ctx, int* rank, int* world_size);
+/* Collective self-test of the communicator the way the factorisation uses it (one broadcast from rank 0 and one
+ * all-gather of small device buffers on the panel stream, results verified on the host).  Every rank calls it.
+ * No reference counterpart (friedrich is single-process); FR_OK when no communicator is attached. */
+int fr_ctx_comm_selftest(fr_ctx* ctx);
 
 /* ---- src/algebra/mod.rs --------------------------------------------------------------------------- */
 /* make_covariance_matrix (algebra/mod.rs:41-54): out[r,c] = k(A.row(r), B.row(c)), out is n1 x n2. */

@@ -127,3 +127,33 @@ def test_sharded_fit_predict_queries_split():
 
     got = np.concatenate(run_ranks(world, fn))
     assert rel_err(got, want) < TOL
+
+
+def test_local_transport_selftest():
+    def fn(ctx, rank):
+        ctx.comm_selftest()
+        return True
+
+    assert all(run_ranks(3, fn))
+
+
+def test_rccl_single_rank_communicator():
+    """The real RCCL transport on the one GPU a test box has: a 1-rank communicator created from an ncclUniqueId,
+    driven through the collectives the factorisation issues (broadcast + all-gather on the panel stream).  Catches a
+    broken dlopen / symbol table / stream handling before the multi-GPU bench does."""
+    from friedrich_amd.device import Context
+
+    ctx = Context()
+    try:
+        uid = ctx.comm_unique_id()
+        ctx.comm_init(0, 1, uid)
+        ctx.comm_selftest()
+        # and a factorisation with the communicator attached (world size 1: no exchange, same results)
+        X = rand_inputs(300, 3, 5)
+        k = ("squared_exp", 0.7, 1.2)
+        chol = ctx.cholesky_from_inputs(k, X, 0.1)
+        _, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+        assert rel_err(np.tril(chol.l()), np.tril(L_o)) < TOL
+        chol.free()
+    finally:
+        ctx.close()
