@@ -323,6 +323,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->gemm_tile = value;
         return FR_OK;
     }
+    if (!strcmp(name, "predict_assoc")) {
+        if (value != 0 && value != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "predict_assoc must be 0 or 1");
+        ctx->predict_assoc = value;
+        return FR_OK;
+    }
     return set_err(ctx, FR_INVALID_ARGUMENT, "unknown option %s", name);
 }
 

@@ -15,7 +15,6 @@
 namespace fr {
 
 constexpr int64_t kAlign = 64;  // row padding (elements) of every internal column-major buffer
-constexpr int kDiagBlock = 64;  // K4 base block: one workgroup factors + inverts a 64x64 diagonal block
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
@@ -45,7 +44,8 @@ struct fr_ctx {
     std::vector<fr::DevBuf> pool;
     // options
     int64_t nb = 256;       // outer Cholesky block / dinv block
-    int64_t gemm_tile = 0;  // reserved
+    int64_t gemm_tile = 0;      // tile-order experiments (gemm_f64.hip)
+    int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
     // profiling
     bool prof = false;
     unsigned prof_mask = ~0u;
@@ -202,8 +202,9 @@ struct GemmDesc {
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 
-// K4: factor one diagonal block (nbk <= 64) in LDS, emit its inverse.
-//   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows)
+// K4: factor one diagonal block (nbk <= 128) and emit its explicit inverse (inv may be NULL).
+//   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows),
+//   mode 3: the block already holds a factor, only the inverse is produced
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub,
                  double* inv, int64_t ldinv, int64_t* info);
 

@@ -117,11 +117,23 @@ int fr_predict_mean(fr_chol* c, const fr_kprog* kernel, const double* y, const d
     Staged ys(ctx), mean(ctx);
     FR_TRY(stage_vec_in(ctx, ys, y, c->n));
     FR_TRY(stage_vec_out(ctx, mean, out_mean, m));
+    FR_TRY(init_with_prior(ctx, mean.dev, prior_q, m));
+    if (ctx->predict_assoc == 1) {
+        // same value associated the cheap way: prior + K*^T (K^-1 y) -- two n x 1 solves instead of two n x m ones
+        WsGuard w(ctx);
+        const int64_t lda = round_up(c->n > 0 ? c->n : 1, kAlign);
+        double* alpha = w.get(sizeof(double) * (size_t)lda);
+        if (!alpha) return FR_OUT_OF_MEMORY;
+        FR_TRY(launch_copy(ctx, ys.dev, lda, alpha, lda, c->n, 1));
+        FR_TRY(trsm_lower_fwd(ctx, c, c->n, alpha, 1, lda, FR_PROF_GEMM_SOLVE));
+        FR_TRY(trsm_lower_bwd(ctx, c, c->n, alpha, 1, lda, FR_PROF_GEMM_SOLVE));
+        FR_TRY(launch_gemv_t(ctx, q.K, c->n, m, q.ldk, alpha, 1.0, 1.0, mean.dev));
+        return mean.commit();
+    }
     // weights = K^-1 K*   (solve_mut, mod.rs:235)
     FR_TRY(trsm_lower_fwd(ctx, c, c->n, q.K, m, q.ldk, FR_PROF_GEMM_SOLVE));
     FR_TRY(trsm_lower_bwd(ctx, c, c->n, q.K, m, q.ldk, FR_PROF_GEMM_SOLVE));
     // prior.gemm_tr(1, weights, y, 1)   (mod.rs:238-241)
-    FR_TRY(init_with_prior(ctx, mean.dev, prior_q, m));
     FR_TRY(launch_gemv_t(ctx, q.K, c->n, m, q.ldk, ys.dev, 1.0, 1.0, mean.dev));
     return mean.commit();
 }

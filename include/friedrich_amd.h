@@ -91,7 +91,13 @@ void fr_ctx_destroy(fr_ctx* ctx);
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
-/* Tunables: "nb" (outer Cholesky block, multiple of 64), "gemm_tile" (0 = 128x128, 1 = 256x128). */
+/* Tunables:
+ *   "nb"            outer Cholesky block (multiple of 128 in [128, 4096], default 256)
+ *   "lookahead"     1 (default): factor the next panel on a second stream under the trailing update
+ *   "gemm_tile"     tile-order experiments of the GEMM (0 = default; see gemm_f64.hip)
+ *   "predict_assoc" 0 (default): predict as the reference associates it, prior + (K^-1 K*)^T y  (mod.rs:234-241,
+ *                   two n x m triangular solves);  1: prior + K*^T (K^-1 y), the same value up to rounding with two
+ *                   n x 1 solves instead */
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
 
 /* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline leg). */

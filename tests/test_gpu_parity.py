@@ -196,6 +196,12 @@ def test_predict_family_matches_oracle(ctx, kernel, n, m, d):
     yres = gp.y
     pq = prior.prior(Xq)
     assert rel_err(chol.predict_mean(kernel, yres, Xq, pq), gp.predict(Xq)) < TOL
+    # the other association of the same product, K*^T (K^-1 y): same values up to rounding
+    ctx.set_option("predict_assoc", 1)
+    try:
+        assert rel_err(chol.predict_mean(kernel, yres, Xq, pq), gp.predict(Xq)) < TOL
+    finally:
+        ctx.set_option("predict_assoc", 0)
     var = chol.predict_variance(kernel, Xq)
     assert np.max(np.abs(var - gp.predict_variance(Xq))) < TOL * np.max(np.abs(gp.predict_variance(Xq)) + 1.0)
     mean2, var2 = chol.predict_mean_variance(kernel, yres, Xq, pq)
