@@ -30,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_NB = 512  # block size of the run profiles/r01/pmc_traffic.json was collected with
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; scripts/mfma_f64_peak measures 77.0-77.6 on the box
 
 
@@ -73,7 +74,7 @@ def main():
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--d", type=int, default=16)
     ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--nb", type=int, default=512)
+    ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block; 0 = the library's choice (1024 on one GPU at this size, 512 sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=6144)
     args = ap.parse_args()
@@ -107,6 +108,7 @@ def main():
 
     ctx = Context(local_rank)
     ctx.set_option("nb", args.nb)
+    nb_eff = args.nb if args.nb > 0 else (1024 if (world == 1 and args.n >= 24576) else 512)
     if use_dist:
         ids = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -193,7 +195,7 @@ def main():
         # same workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction); null for any other size
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and (n, d, args.nb, world) == (32768, 16, 512, 1):
+        if os.path.exists(pmc_path) and (n, d, nb_eff, world) == (32768, 16, PMC_NB, 1):
             with open(pmc_path) as f:
                 traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]
             traffic_src = "profiles/r01/pmc_traffic.json"
@@ -212,7 +214,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"GP fit (Gram + Cholesky) + predict, N={n} d={d} RBF, m={m} queries, friedrich default hyper-parameters",
-                "n": n, "d": d, "m": m, "kernel": "squared_exp", "nb": args.nb,
+                "n": n, "d": d, "m": m, "kernel": "squared_exp", "nb": nb_eff,
                 "parallelism": "1 GPU" if world == 1 else f"block-cyclic column panels over {world} GPUs (RCCL broadcast), queries sharded",
             },
             "fit_ms": float(np.mean(fit_ms)),

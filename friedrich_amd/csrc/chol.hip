@@ -287,10 +287,21 @@ static void chol_release(fr_chol* c)
     c->info = nullptr;
 }
 
+// Outer block of the right-looking factorisation (= K of the trailing SYRK).  Measured in one process
+// (scripts/nb_ab.py): every nb in 256..1024 is within 2 % up to N = 16384; at N = 32768 the fit takes 218 / 200 / 194 ms
+// with 256 / 512 / 1024 (each pass over the trailing matrix costs a read and a write of C whatever its depth).  Sharded
+// runs keep 512: block columns are dealt round-robin, and 32 panels over 8 ranks would balance poorly.
+static int64_t pick_nb(const fr_ctx* ctx, int64_t n)
+{
+    if (ctx->nb > 0) return ctx->nb;
+    return (ctx->world <= 1 && n >= 24576) ? 1024 : 512;
+}
+
 static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t d)
 {
     c->capacity = imax(capacity, 1);
     c->ld_a = round_up(c->capacity, kAlign);
+    if (c->ld_a % 1024 == 0) c->ld_a += ctx->ld_pad;
     c->ld_x = c->ld_a;
     c->d = d;
     const int64_t nblk = (c->capacity + IB - 1) / IB;
@@ -313,7 +324,7 @@ int chol_alloc(fr_ctx* ctx, int64_t n, int64_t capacity, int64_t d, fr_chol** ou
     fr_chol* c = new fr_chol();
     c->ctx = ctx;
     c->n = n;
-    c->nb = ctx->nb;
+    c->nb = pick_nb(ctx, n);
     int st = chol_alloc_buffers(ctx, c, imax(capacity, n), d);
     if (st != FR_OK) {
         delete c;
@@ -390,7 +401,7 @@ int potrf_matrix_ws(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int mode, dou
     int64_t* info = (int64_t*)ig.get(sizeof(int64_t) * (size_t)(3 + n));
     if (!dinv_tmp || !info) return FR_OUT_OF_MEMORY;
     FR_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int64_t) * 3, ctx->stream));
-    FR_TRY(potrf_blocked(ctx, A, ld, n, 0, mode, sub, dinv_tmp, info, ctx->nb));
+    FR_TRY(potrf_blocked(ctx, A, ld, n, 0, mode, sub, dinv_tmp, info, pick_nb(ctx, n)));
     int64_t head = 0;
     FR_HIP(ctx, hipMemcpyAsync(&head, info, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -507,7 +518,7 @@ int fr_chol_refactor(fr_chol* c, const fr_kprog* kernel, double noise, int has_e
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));
     if (c->d == 0 && c->n > 0 && !c->X) return set_err(ctx, FR_INVALID_ARGUMENT, "factor holds no training inputs");
-    c->nb = ctx->nb;
+    c->nb = pick_nb(ctx, c->n);
     return assemble_and_factor(c, kernel, noise, has_eps, eps);
 }
 
@@ -550,7 +561,7 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     if (ldx < imax(n_all, 1)) return set_err(ctx, FR_SHAPE, "add_rows: bad leading dimension");
     if (nb_new == 0) return FR_OK;
     FR_TRY(chol_grow(c, n_all));
-    c->nb = ctx->nb;
+    c->nb = pick_nb(ctx, n_all);
     // new rows of the EMatrix mirror
     FR_TRY(upload_rows(ctx, Xall + n_old, ldx, c->X + n_old, c->ld_x, nb_new, d));
     const int64_t ld = c->ld_a;

@@ -310,8 +310,8 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return FR_INVALID_ARGUMENT;
     if (!strcmp(name, "nb")) {
-        if (value < 128 || value % 128 != 0 || value > 4096)
-            return set_err(ctx, FR_INVALID_ARGUMENT, "nb must be a multiple of 128 in [128, 4096]");
+        if (value != 0 && (value < 128 || value % 128 != 0 || value > 4096))
+            return set_err(ctx, FR_INVALID_ARGUMENT, "nb must be 0 (automatic) or a multiple of 128 in [128, 4096]");
         ctx->nb = value;
         return FR_OK;
     }
@@ -321,6 +321,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     }
     if (!strcmp(name, "gemm_tile")) {
         ctx->gemm_tile = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "ld_pad")) {
+        if (value < 0 || value % kAlign != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "ld_pad must be a multiple of 64");
+        ctx->ld_pad = value;
         return FR_OK;
     }
     if (!strcmp(name, "predict_assoc")) {

@@ -17,9 +17,9 @@ namespace fr {
 constexpr int64_t kAlign = 64;  // row padding (elements) of every internal column-major buffer
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
-// Leading dimensions stay plain multiples of kAlign.  Padding them away from powers of two was measured
-// (scripts/gemm_ld_probe.py, gram_ld_probe.py): an isolated GEMM at N = 16384 gains 10 % (59 -> 66 TF/s) and the Gram
-// assembly 15 %, but the whole fit at N = 32768 loses 5 % (SYRK 62.5 -> 58.7 TF/s), so it is not applied.
+// Leading dimensions stay plain multiples of kAlign.  Padding them away from powers of two was measured: an isolated
+// GEMM at N = 16384 gains 10 % (scripts/gemm_ld_probe.py) and the Gram assembly 15 % (gram_ld_probe.py), but the fit as
+// a whole is unchanged at every size tried (scripts/ld_ab.py, option "ld_pad", same process), so it is not applied.
 
 struct DevBuf {
     void* p = nullptr;
@@ -46,8 +46,9 @@ struct fr_ctx {
     // grow-only workspace pool (stream-ordered reuse inside one context)
     std::vector<fr::DevBuf> pool;
     // options
-    int64_t nb = 256;       // outer Cholesky block / dinv block
+    int64_t nb = 0;         // outer Cholesky block; 0 = chosen from the matrix size (pick_nb)
     int64_t gemm_tile = 0;      // tile-order experiments (gemm_f64.hip)
+    int64_t ld_pad = 0;         // probe: elements added to a factor's leading dimension when it is a multiple of 1024
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
     // profiling
     bool prof = false;

@@ -92,7 +92,7 @@ int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
 /* Tunables:
- *   "nb"            outer Cholesky block (multiple of 128 in [128, 4096], default 256)
+ *   "nb"            outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "lookahead"     1 (default): factor the next panel on a second stream under the trailing update
  *   "gemm_tile"     tile-order experiments of the GEMM (0 = default; see gemm_f64.hip)
  *   "predict_assoc" 0 (default): predict as the reference associates it, prior + (K^-1 K*)^T y  (mod.rs:234-241,

@@ -93,7 +93,24 @@ def test_cholesky_kernels_and_block_sizes(ctx, kernel):
         chol = ctx.cholesky_from_inputs(kernel, X, 0.05)
         assert rel_err(chol.l(), np.tril(L_o)) < TOL
         chol.free()
-    ctx.set_option("nb", 256)
+    ctx.set_option("nb", 0)
+
+
+def test_cholesky_large_outer_blocks(ctx):
+    # nb = 768 / 1024 (the automatic choice at N >= 24576) with look-ahead active (n > 2 nb), against the oracle
+    n = 2600
+    kernel = PD_KERNELS[0]
+    X = rand_inputs(n, 4, 17)
+    st, L_o, _ = O.make_cholesky_cov_matrix(kernel, X, 0.05)
+    assert st == 0
+    for nb in (768, 1024):
+        ctx.set_option("nb", nb)
+        chol = ctx.cholesky_from_inputs(kernel, X, 0.05)
+        assert rel_err(chol.l(), np.tril(L_o)) < TOL
+        B = np.asfortranarray(np.random.default_rng(5).standard_normal((n, 3)))
+        assert rel_err(chol.solve(B), O.chol_solve(L_o, B)) < 1e-8
+        chol.free()
+    ctx.set_option("nb", 0)
 
 
 def test_readme_dataset(ctx):
