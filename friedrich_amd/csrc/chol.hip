@@ -230,27 +230,102 @@ static inline int64_t split128(int64_t n)
     return (nbk / 2) * IB;
 }
 
-// B (n x m) <- L^-1 B
-static int trsm_fwd_rec(fr_ctx* ctx, const double* L, int64_t ld, const double* dinv, int64_t n, double* B, int64_t m,
-                        int64_t ldb, int cls)
+// ---- explicit inverses of the 512 x 512 diagonal blocks ----------------------------------------------------------------
+// A triangular solve is a chain of n / 128 dependent leaf products against the 128-block inverses, each a ~25 us launch
+// on 1/8 of the chip; with the updates of the two smallest recursion levels they made 20 % of a solve at N = 32768,
+// m = 4096.  The wide solves (predict / predict_variance / sample_at / solve) use 512-row leaves instead: W_q = inverse of
+// the q-th 512 x 512 diagonal block of L, assembled from the 128-block inverses by the 2 x 2 block formula
+// inv([[P, 0], [C, Q]]) = [[P^-1, 0], [-Q^-1 C P^-1, Q^-1]], twice, as six batched GEMM launches for ALL blocks
+// (~0.3 ms).  Built on first use after the factor changed; only blocks lying entirely inside the matrix.
+constexpr int64_t LB = 512;  // leaf rows of the wide solves
+
+static int batched_gemm(fr_ctx* ctx, int cls, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, bool a_kmajor,
+                        int64_t sa, const double* B, int64_t ldb, bool b_kmajor, int64_t sb, double alpha, double* D,
+                        int64_t ldd, int64_t sd, int64_t batch)
 {
-    if (n <= IB) return gemm(ctx, cls, n, m, n, dinv, IB, false, B, ldb, true, 1.0, 0.0, B, ldb);
-    const int64_t n1 = split128(n);
-    FR_TRY(trsm_fwd_rec(ctx, L, ld, dinv, n1, B, m, ldb, cls));
+    GemmDesc g;
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.a_kmajor = a_kmajor;
+    g.B = B; g.ldb = ldb; g.b_kmajor = b_kmajor;
+    g.Cin = D; g.ldcin = ldd; g.D = D; g.ldd = ldd;
+    g.alpha = alpha; g.beta = 0.0; g.lower = false; g.prof_cls = cls;
+    g.batch = batch; g.batch_a = sa; g.batch_b = sb; g.batch_c = sd; g.batch_d = sd;
+    return launch_gemm(ctx, g);
+}
+
+static int ensure_inv512(fr_ctx* ctx, const fr_chol* cc, int cls)
+{
+    fr_chol* c = const_cast<fr_chol*>(cc);  // a cache: logically const
+    const int64_t nq = c->n / LB;
+    if (nq <= 0 || c->inv512_rows >= nq * LB) return FR_OK;
+    if (c->inv512_cap < nq) {
+        if (c->inv512) (void)hipFree(c->inv512);
+        c->inv512 = nullptr;
+        c->inv512_cap = 0;
+        const int64_t cap = imax(nq, c->capacity / LB);
+        FR_HIP(ctx, hipMalloc(&c->inv512, sizeof(double) * (size_t)cap * LB * LB));
+        c->inv512_cap = cap;
+    }
+    const int64_t ld = c->ld_a;
+    WsGuard w(ctx);
+    double* T = w.get(sizeof(double) * (size_t)nq * 256 * 256);
+    if (!T) return FR_OUT_OF_MEMORY;
+    double* W = c->inv512;
+    FR_TRY(launch_blockdiag512(ctx, c->dinv, W, nq));
+    // level 256: for both 256-halves (par) of every block q, 128-blocks a (upper) and b = a + 1:  W_ba = -X_b (L_ba X_a)
+    for (int par = 0; par < 2; ++par) {
+        const int64_t off = 256 * par;  // first row of the half inside its 512-block
+        FR_TRY(batched_gemm(ctx, cls, IB, IB, IB, c->A + (off + IB) + off * ld, ld, false, LB + LB * ld,
+                            c->dinv + (2 * par) * INV_ELEMS, IB, true, 4 * INV_ELEMS, 1.0, T, IB, INV_ELEMS, nq));
+        FR_TRY(batched_gemm(ctx, cls, IB, IB, IB, c->dinv + (2 * par + 1) * INV_ELEMS, IB, false, 4 * INV_ELEMS, T, IB, true,
+                            INV_ELEMS, -1.0, W + (off + IB) + off * LB, LB, LB * LB, nq));
+    }
+    // level 512: halves P (rows 0..255) and Q (256..511) of every block:  W_QP = -W_QQ (L_QP W_PP)
+    FR_TRY(batched_gemm(ctx, cls, 256, 256, 256, c->A + 256, ld, false, LB + LB * ld, W, LB, true, LB * LB, 1.0, T, 256,
+                        256 * 256, nq));
+    FR_TRY(batched_gemm(ctx, cls, 256, 256, 256, W + 256 + 256 * LB, LB, false, LB * LB, T, 256, true, 256 * 256, -1.0,
+                        W + 256, LB, LB * LB, nq));
+    c->inv512_rows = nq * LB;
+    return FR_OK;
+}
+
+// one 512-row leaf: B (512 x m) <- W B  (forward) or W^T B (backward); not in place (four tile rows): through a copy
+static int leaf512(fr_ctx* ctx, const fr_chol* c, int64_t row0, double* B, int64_t m, int64_t ldb, int cls, bool fwd,
+                   double* tmp)
+{
+    const double* W = c->inv512 + (row0 / LB) * LB * LB;
+    FR_TRY(launch_copy(ctx, B, ldb, tmp, LB, LB, m));
+    return gemm(ctx, cls, LB, m, LB, W, LB, !fwd, tmp, LB, true, 1.0, 0.0, B, ldb);
+}
+
+// B (n x m) <- L^-1 B.  row0 = first row of this sub-problem in the factor; tmp != nullptr enables the 512-row leaves
+static int trsm_fwd_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* B, int64_t m, int64_t ldb, int cls,
+                        double* tmp)
+{
+    const double* L = c->A + row0 + row0 * c->ld_a;
+    const int64_t ld = c->ld_a;
+    if (tmp && n == LB && row0 % LB == 0 && row0 + LB <= c->inv512_rows) return leaf512(ctx, c, row0, B, m, ldb, cls, true, tmp);
+    if (n <= IB) return gemm(ctx, cls, n, m, n, c->dinv + (row0 / IB) * INV_ELEMS, IB, false, B, ldb, true, 1.0, 0.0, B, ldb);
+    // split at a multiple of 512 while the problem is larger than a leaf (so that the leaves line up with the blocks)
+    const int64_t n1 = (tmp && n > LB) ? (((n + LB - 1) / LB) / 2) * LB : split128(n);
+    FR_TRY(trsm_fwd_rec(ctx, c, row0, n1, B, m, ldb, cls, tmp));
     FR_TRY(gemm(ctx, cls, n - n1, m, n1, L + n1, ld, false, B, ldb, true, -1.0, 1.0, B + n1, ldb));
-    return trsm_fwd_rec(ctx, L + n1 + n1 * ld, ld, dinv + (n1 / IB) * INV_ELEMS, n - n1, B + n1, m, ldb, cls);
+    return trsm_fwd_rec(ctx, c, row0 + n1, n - n1, B + n1, m, ldb, cls, tmp);
 }
 
 // B (n x m) <- L^-T B
-static int trsm_bwd_rec(fr_ctx* ctx, const double* L, int64_t ld, const double* dinv, int64_t n, double* B, int64_t m,
-                        int64_t ldb, int cls)
+static int trsm_bwd_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* B, int64_t m, int64_t ldb, int cls,
+                        double* tmp)
 {
-    if (n <= IB) return gemm(ctx, cls, n, m, n, dinv, IB, true, B, ldb, true, 1.0, 0.0, B, ldb);
-    const int64_t n1 = split128(n);
-    FR_TRY(trsm_bwd_rec(ctx, L + n1 + n1 * ld, ld, dinv + (n1 / IB) * INV_ELEMS, n - n1, B + n1, m, ldb, cls));
+    const double* L = c->A + row0 + row0 * c->ld_a;
+    const int64_t ld = c->ld_a;
+    if (tmp && n == LB && row0 % LB == 0 && row0 + LB <= c->inv512_rows) return leaf512(ctx, c, row0, B, m, ldb, cls, false, tmp);
+    if (n <= IB) return gemm(ctx, cls, n, m, n, c->dinv + (row0 / IB) * INV_ELEMS, IB, true, B, ldb, true, 1.0, 0.0, B, ldb);
+    const int64_t n1 = (tmp && n > LB) ? (((n + LB - 1) / LB) / 2) * LB : split128(n);
+    FR_TRY(trsm_bwd_rec(ctx, c, row0 + n1, n - n1, B + n1, m, ldb, cls, tmp));
     // B1 -= L21^T * B2    (op(A)[m][k] = L21[k][m]: k-major)
     FR_TRY(gemm(ctx, cls, n1, m, n - n1, L + n1, ld, true, B + n1, ldb, true, -1.0, 1.0, B, ldb));
-    return trsm_bwd_rec(ctx, L, ld, dinv, n1, B, m, ldb, cls);
+    return trsm_bwd_rec(ctx, c, row0, n1, B, m, ldb, cls, tmp);
 }
 
 // X (k x n) <- X L^-T
@@ -265,16 +340,36 @@ static int trsm_right_rec(fr_ctx* ctx, const double* L, int64_t ld, const double
     return trsm_right_rec(ctx, L + n1 + n1 * ld, ld, dinv + (n1 / IB) * INV_ELEMS, n - n1, X + n1 * ldx, k, ldx, cls);
 }
 
+// 512-row leaves pay once the right-hand side is wide enough for the leaf product to fill the chip
+static bool wide_solve(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m)
+{
+    return ctx->leaf512 != 0 && n == c->n && n >= 2 * LB && m >= 256;
+}
+
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
-    return trsm_fwd_rec(ctx, c->A, c->ld_a, c->dinv, n, B, m, ldb, cls);
+    WsGuard w(ctx);
+    double* tmp = nullptr;
+    if (wide_solve(ctx, c, n, m)) {
+        FR_TRY(ensure_inv512(ctx, c, cls));
+        tmp = w.get(sizeof(double) * (size_t)LB * (size_t)m);
+        if (!tmp) return FR_OUT_OF_MEMORY;
+    }
+    return trsm_fwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
 }
 
 int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
-    return trsm_bwd_rec(ctx, c->A, c->ld_a, c->dinv, n, B, m, ldb, cls);
+    WsGuard w(ctx);
+    double* tmp = nullptr;
+    if (wide_solve(ctx, c, n, m)) {
+        FR_TRY(ensure_inv512(ctx, c, cls));
+        tmp = w.get(sizeof(double) * (size_t)LB * (size_t)m);
+        if (!tmp) return FR_OUT_OF_MEMORY;
+    }
+    return trsm_bwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
 }
 
 static void chol_release(fr_chol* c)
@@ -283,8 +378,10 @@ static void chol_release(fr_chol* c)
     if (c->X) (void)hipFree(c->X);
     if (c->dinv) (void)hipFree(c->dinv);
     if (c->info) (void)hipFree(c->info);
-    c->A = c->X = c->dinv = nullptr;
+    if (c->inv512) (void)hipFree(c->inv512);
+    c->A = c->X = c->dinv = c->inv512 = nullptr;
     c->info = nullptr;
+    c->inv512_cap = c->inv512_rows = 0;
 }
 
 // Outer block of the right-looking factorisation (= K of the trailing SYRK).  Measured in one process
@@ -386,6 +483,7 @@ static int merge_info(fr_chol* c)
 
 int potrf_device(fr_ctx* ctx, fr_chol* c, int64_t j0, int64_t n, int mode, double sub)
 {
+    c->inv512_rows = 0;
     return potrf_blocked(ctx, c->A + j0 + j0 * c->ld_a, c->ld_a, n, j0, mode, sub, c->dinv + (j0 / IB) * INV_ELEMS, c->info,
                          c->nb);
 }
@@ -413,6 +511,7 @@ int potrf_matrix_ws(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int mode, dou
 static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise, int has_eps, double eps)
 {
     fr_ctx* ctx = c->ctx;
+    c->inv512_rows = 0;
     FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
     FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank,
                            c->nb));
@@ -560,6 +659,7 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     if (d != c->d) return set_err(ctx, FR_SHAPE, "add_rows: feature count %lld != %lld", (long long)d, (long long)c->d);
     if (ldx < imax(n_all, 1)) return set_err(ctx, FR_SHAPE, "add_rows: bad leading dimension");
     if (nb_new == 0) return FR_OK;
+    c->inv512_rows = 0;  // the factor grows: the cached 512-block inverses are rebuilt on the next wide solve
     FR_TRY(chol_grow(c, n_all));
     c->nb = pick_nb(ctx, n_all);
     // new rows of the EMatrix mirror

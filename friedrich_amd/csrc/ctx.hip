@@ -323,6 +323,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->gemm_tile = value;
         return FR_OK;
     }
+    if (!strcmp(name, "leaf512")) {
+        ctx->leaf512 = value != 0;
+        return FR_OK;
+    }
     if (!strcmp(name, "ld_pad")) {
         if (value < 0 || value % kAlign != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "ld_pad must be a multiple of 64");
         ctx->ld_pad = value;

@@ -49,6 +49,7 @@ struct fr_ctx {
     int64_t nb = 0;         // outer Cholesky block; 0 = chosen from the matrix size (pick_nb)
     int64_t gemm_tile = 0;      // tile-order experiments (gemm_f64.hip)
     int64_t ld_pad = 0;         // probe: elements added to a factor's leading dimension when it is a multiple of 1024
+    int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
     // profiling
     bool prof = false;
@@ -79,7 +80,12 @@ struct fr_chol {
     int64_t nb = 256;
     double* A = nullptr;
     double* X = nullptr;     // capacity x d training inputs (EMatrix mirror)
-    double* dinv = nullptr;  // ceil(capacity/nb) blocks of nb x nb
+    double* dinv = nullptr;  // ceil(capacity/128) explicit inverses of the 128 x 128 diagonal blocks
+    // explicit inverses of the 512 x 512 diagonal blocks (leaves of the wide triangular solves), built on demand from
+    // dinv; inv512_rows = rows covered by valid blocks (0 after every change of the factor)
+    double* inv512 = nullptr;
+    int64_t inv512_cap = 0;  // blocks allocated
+    int64_t inv512_rows = 0;
     int64_t* info = nullptr;  // device: [0] = 1 + first failing column (0: none), [1] = n_subst,
                               //         [2] = 1 if a zero diagonal was seen, [3..] substituted columns
     int64_t info_cap = 0;
@@ -203,6 +209,8 @@ struct GemmDesc {
     // multi-GPU column-ownership filter (see gemm_f64.hip); defaults: disabled
     int own_world = 1, own_rank = 0;
     int64_t own_nb = 1, own_col0 = 0;
+    // batched launch: `batch` independent problems of the same shape, operands `batch_*` elements apart
+    int64_t batch = 1, batch_a = 0, batch_b = 0, batch_c = 0, batch_d = 0;
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 
@@ -214,6 +222,7 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
 
 // small helpers (elementwise / reductions)
 int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v);
+int launch_blockdiag512(fr_ctx* ctx, const double* dinv128, double* w, int64_t nblocks);
 int launch_copy(fr_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);
 int launch_set_identity(fr_ctx* ctx, double* p, int64_t n, int64_t ld);
 int launch_tri_fill(fr_ctx* ctx, double* p, int64_t n, int64_t ld, double v);            // strict upper := v

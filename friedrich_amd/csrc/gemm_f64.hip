@@ -50,6 +50,8 @@ struct GemmArgs {
     // ((own_col0 + n0) / own_nb) % own_world == own_rank; own_world <= 1 disables the filter
     int own_world, own_rank;
     int64_t own_nb, own_col0;
+    // batch: blockIdx.y selects a problem; operands advance by these strides (elements)
+    int64_t batch_a, batch_b, batch_c, batch_d;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile
@@ -376,9 +378,15 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
 // Two kernel symbols over the same body: the lower-mode launch is the trailing SYRK update of the factorisation (the
 // dominant kernel of a fit); keeping it apart from the panel / solve GEMMs makes profiler per-kernel averages meaningful.
 template <bool A_KMAJ, bool B_KMAJ>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g)
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g0)
 {
     __shared__ double lds[4 * TILE_ELEMS];  // [stage][A|B][TILE_ELEMS]
+    GemmArgs g = g0;
+    const int64_t bz = blockIdx.y;  // batch member (0 for a plain launch)
+    g.A += bz * g.batch_a;
+    g.B += bz * g.batch_b;
+    g.Cin += bz * g.batch_c;
+    g.D += bz * g.batch_d;
     gemm_f64_body<A_KMAJ, B_KMAJ>(g, lds);
 }
 
@@ -446,7 +454,12 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
     const double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
     ProfScope ps(ctx, d.prof_cls, flops, bytes);
-    dim3 grid((unsigned)ntiles), block(256);
+    g.batch_a = d.batch_a;
+    g.batch_b = d.batch_b;
+    g.batch_c = d.batch_c;
+    g.batch_d = d.batch_d;
+    if (d.batch > 1 && d.lower) return set_err(ctx, FR_INVALID_ARGUMENT, "batched GEMM is full-mode only");
+    dim3 grid((unsigned)ntiles, (unsigned)(d.batch > 1 ? d.batch : 1)), block(256);
     if (d.lower && !d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL(syrk_lower_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && !d.b_kmajor)

@@ -19,6 +19,19 @@ __global__ void copy_kernel(const double* src, int64_t lds, double* dst, int64_t
         if (r < rows) dst[r + c * ldd] = src[r + c * lds];
 }
 
+// 512-block inverses, step 0: block q (512 x 512, contiguous) gets the four 128 x 128 inverses 4q .. 4q+3 on its
+// diagonal and zeros everywhere else.  grid = (2, 512, blocks): thread -> row, blockIdx.y -> column
+__global__ void blockdiag512_kernel(const double* __restrict__ dinv128, double* __restrict__ w, int64_t nblocks)
+{
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);  // 0..511
+    const int c = (int)blockIdx.y;
+    const int64_t q = blockIdx.z;
+    if (q >= nblocks) return;
+    double v = 0.0;
+    if ((r >> 7) == (c >> 7)) v = dinv128[(4 * q + (r >> 7)) * (128 * 128) + (r & 127) + (int64_t)(c & 127) * 128];
+    w[q * (512 * 512) + r + (int64_t)c * 512] = v;
+}
+
 __global__ void identity_kernel(double* p, int64_t n, int64_t ld)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,6 +144,14 @@ int launch_copy(fr_ctx* ctx, const double* src, int64_t lds, double* dst, int64_
     if (rows <= 0 || cols <= 0) return FR_OK;
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((rows + 255) / 256), ydim(cols)), dim3(256), 0, ctx->ls, src,
                        lds, dst, ldd, rows, cols);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_blockdiag512(fr_ctx* ctx, const double* dinv128, double* w, int64_t nblocks)
+{
+    if (nblocks <= 0) return FR_OK;
+    hipLaunchKernelGGL(blockdiag512_kernel, dim3(2, 512, (unsigned)nblocks), dim3(256), 0, ctx->ls, dinv128, w, nblocks);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

@@ -113,6 +113,27 @@ def test_cholesky_large_outer_blocks(ctx):
     ctx.set_option("nb", 0)
 
 
+def test_wide_solves_with_512_row_leaves(ctx):
+    # >= 256 right-hand sides: the solves end in 512-row leaves (explicit 512-block inverses built on demand); n is not
+    # a multiple of 512, so the last rows still take the 128-row path.  Also after add_rows (cache invalidated).
+    n0, n, m = 1300, 1700, 300
+    kernel = PD_KERNELS[1]
+    X = rand_inputs(n, 5, 23)
+    B = np.asfortranarray(np.random.default_rng(6).standard_normal((n, m)))
+    chol = ctx.cholesky_from_inputs(kernel, X[:n0], 0.08, capacity_hint=n)
+    _, L0, _ = O.make_cholesky_cov_matrix(kernel, X[:n0], 0.08)
+    for leaf in (1, 0):
+        ctx.set_option("leaf512", leaf)
+        assert rel_err(chol.solve(B[:n0]), O.chol_solve(L0, B[:n0])) < 1e-8
+        assert rel_err(chol.solve_lower(B[:n0]), O.solve_lower(L0, B[:n0])[1]) < 1e-9
+    ctx.set_option("leaf512", 1)
+    chol.add_rows(kernel, X, n - n0, 0.08)
+    _, L1, _ = O.make_cholesky_cov_matrix(kernel, X, 0.08)
+    assert rel_err(chol.solve(B), O.chol_solve(L1, B)) < 1e-8
+    assert rel_err(chol.solve_lower(B), O.solve_lower(L1, B)[1]) < 1e-9
+    chol.free()
+
+
 def test_readme_dataset(ctx):
     # the reference's only dataset (src/main.rs:16-17)
     X = np.array([[0.8], [1.2], [3.8], [4.2]])
