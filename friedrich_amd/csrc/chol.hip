@@ -593,6 +593,7 @@ int fr_chol_from_inputs(fr_ctx* ctx, const fr_kprog* kernel, const double* X, in
                         double noise, int has_eps, double eps, int64_t capacity_hint, fr_chol** out)
 {
     if (!ctx || !out) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     *out = nullptr;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));
@@ -613,6 +614,7 @@ int fr_chol_from_inputs(fr_ctx* ctx, const fr_kprog* kernel, const double* X, in
 int fr_chol_refactor(fr_chol* c, const fr_kprog* kernel, double noise, int has_eps, double eps)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));
@@ -624,6 +626,7 @@ int fr_chol_refactor(fr_chol* c, const fr_kprog* kernel, double noise, int has_e
 int fr_chol_from_matrix(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int has_eps, double eps, fr_chol** out)
 {
     if (!ctx || !out) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     *out = nullptr;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     if (n < 0 || lda < imax(n, 1)) return set_err(ctx, FR_SHAPE, "bad matrix shape");
@@ -650,6 +653,7 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
                      int64_t nb_new, double noise)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));
@@ -718,6 +722,7 @@ int fr_chol_substitutions(const fr_chol* c, int64_t* idx, int64_t max_idx)
 int fr_chol_solve(fr_chol* c, double* B, int64_t m, int64_t ldb)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     Staged b(ctx);
@@ -742,6 +747,7 @@ static int check_zero_diag(fr_chol* c, const char* what)
 int fr_chol_solve_lower(fr_chol* c, double* B, int64_t m, int64_t ldb)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(check_zero_diag(c, "solve_lower_triangular"));
@@ -754,6 +760,7 @@ int fr_chol_solve_lower(fr_chol* c, double* B, int64_t m, int64_t ldb)
 int fr_chol_inverse(fr_chol* c, double* out, int64_t ldo)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     Staged o(ctx);
@@ -767,6 +774,7 @@ int fr_chol_inverse(fr_chol* c, double* out, int64_t ldo)
 int fr_chol_download_l(fr_chol* c, double* out, int64_t ldo, int upper_fill)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     Staged o(ctx);
@@ -780,6 +788,7 @@ int fr_chol_upload_l(fr_ctx* ctx, const double* L, int64_t n, int64_t ldl, const
                      int64_t capacity_hint, fr_chol** out)
 {
     if (!ctx || !out) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     *out = nullptr;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     if (n < 0 || d < 0 || ldl < imax(n, 1) || (d > 0 && ldx < imax(n, 1))) return set_err(ctx, FR_SHAPE, "bad shape");
@@ -813,10 +822,13 @@ void fr_chol_free(fr_chol* c)
 {
     if (!c) return;
     if (c->ctx) {
+        FR_LOCK(c->ctx);
         (void)hipSetDevice(c->ctx->device);
         (void)hipStreamSynchronize(c->ctx->stream);
+        chol_release(c);
+    } else {
+        chol_release(c);
     }
-    chol_release(c);
     delete c;
 }
 

@@ -222,6 +222,7 @@ int fr_comm_unique_id(void* out_id)
 int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_id)
 {
     if (!ctx || world_size < 1 || rank < 0 || rank >= world_size) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     FR_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->comm || ctx->local) return set_err(ctx, FR_INVALID_ARGUMENT, "communicator already initialised");
     if (world_size == 1 && !unique_id) {
@@ -244,6 +245,7 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
 int fr_ctx_comm_init_local(fr_ctx* ctx, int group_id, int rank, int world_size)
 {
     if (!ctx || world_size < 1 || world_size > 64 || rank < 0 || rank >= world_size) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     if (ctx->comm || ctx->local) return set_err(ctx, FR_INVALID_ARGUMENT, "communicator already initialised");
     std::lock_guard<std::mutex> lk(g_local_mutex);
     LocalGroup*& g = g_local_groups[group_id];
@@ -265,6 +267,7 @@ int fr_ctx_comm_init_local(fr_ctx* ctx, int group_id, int rank, int world_size)
 int fr_ctx_comm_selftest(fr_ctx* ctx)
 {
     if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     if (!ctx->comm && !ctx->local) return FR_OK;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     const int W = ctx->world, R = ctx->rank;

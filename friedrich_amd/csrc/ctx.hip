@@ -289,6 +289,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
@@ -300,6 +301,7 @@ int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream)
 int fr_ctx_synchronize(fr_ctx* ctx)
 {
     if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FR_OK;
 }
@@ -309,6 +311,7 @@ const char* fr_last_error(const fr_ctx* ctx) { return ctx ? ctx->err.c_str() : "
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     if (!strcmp(name, "nb")) {
         if (value != 0 && (value < 128 || value % 128 != 0 || value > 4096))
             return set_err(ctx, FR_INVALID_ARGUMENT, "nb must be 0 (automatic) or a multiple of 128 in [128, 4096]");
@@ -343,6 +346,7 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
 int fr_ctx_profile_enable(fr_ctx* ctx, int enable)
 {
     if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     prof_collect(ctx);
     ctx->prof = enable != 0;
     // enable == 1: every class; otherwise bit (cls + 1) selects class cls (bench.py times only the SYRK class so
@@ -354,6 +358,7 @@ int fr_ctx_profile_enable(fr_ctx* ctx, int enable)
 int fr_ctx_profile_reset(fr_ctx* ctx)
 {
     if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     prof_collect(ctx);
     for (int i = 0; i < FR_PROF_COUNT; ++i) {
         ctx->prof_ms[i] = 0;
@@ -367,6 +372,7 @@ int fr_ctx_profile_reset(fr_ctx* ctx)
 int fr_ctx_profile_get(fr_ctx* ctx, int cls, double* ms, int64_t* launches, double* flops, double* bytes)
 {
     if (!ctx || cls < 0 || cls >= FR_PROF_COUNT) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     prof_collect(ctx);
     if (ms) *ms = ctx->prof_ms[cls];
     if (launches) *launches = ctx->prof_launches[cls];

@@ -11,6 +11,9 @@
 #include <vector>
 
 #include "friedrich_amd.h"
+#include <mutex>
+
+#define FR_LOCK(ctxptr) std::lock_guard<std::recursive_mutex> fr_lock_guard__((ctxptr)->mu)
 
 namespace fr {
 
@@ -35,6 +38,10 @@ struct ProfRec {
 }  // namespace fr
 
 struct fr_ctx {
+    // Serialises the entry points of one context: friedrich's GaussianProcess is Send + Sync, so concurrent &self calls
+    // (several threads predicting from one model) are legal and must stay correct; they share this context's streams
+    // and workspaces, so they take turns.  Recursive: entry points call each other.
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;   // main stream (memcpys, host synchronisation)
     bool own_stream = true;

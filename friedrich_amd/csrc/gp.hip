@@ -74,6 +74,7 @@ extern "C" {
 int fr_likelihood(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, double* out)
 {
     if (!c || !out) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));
@@ -111,6 +112,7 @@ int fr_predict_mean(fr_chol* c, const fr_kprog* kernel, const double* y, const d
                     const double* prior_q, double* out_mean)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     QueryCtx q(c);
     FR_TRY(q.init(kernel, Xq, m, ldq));
@@ -141,6 +143,7 @@ int fr_predict_mean(fr_chol* c, const fr_kprog* kernel, const double* y, const d
 int fr_predict_variance(fr_chol* c, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq, double* out_var)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     QueryCtx q(c);
     FR_TRY(q.init(kernel, Xq, m, ldq));
@@ -162,6 +165,7 @@ int fr_predict_mean_variance(fr_chol* c, const fr_kprog* kernel, const double* y
                              int64_t ldq, const double* prior_q, double* out_mean, double* out_var)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     QueryCtx q(c);
     FR_TRY(q.init(kernel, Xq, m, ldq));
@@ -191,6 +195,7 @@ int fr_predict_covariance(fr_chol* c, const fr_kprog* kernel, const double* Xq, 
                           int64_t ldc)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     QueryCtx q(c);
     FR_TRY(q.init(kernel, Xq, m, ldq));
@@ -214,6 +219,7 @@ int fr_posterior(fr_chol* c, const fr_kprog* kernel, const double* y, const doub
                  const double* prior_q, double* out_mean, double* out_cov, int64_t ldc, double* out_cov_l, int64_t ldl)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     QueryCtx q(c);
     FR_TRY(q.init(kernel, Xq, m, ldq));
@@ -261,6 +267,7 @@ int fr_gemm(fr_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t
             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc)
 {
     if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     FR_HIP(ctx, hipSetDevice(ctx->device));
     if (M < 0 || N < 0 || K < 0) return set_err(ctx, FR_SHAPE, "negative GEMM dimension");
     Staged a(ctx), b(ctx), c(ctx);

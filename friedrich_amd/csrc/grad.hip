@@ -261,6 +261,7 @@ extern "C" int fr_grad_terms(fr_chol* c, const fr_kprog* kernel, const double* y
                              double* out_grad, double* out_scale)
 {
     if (!c || !out_grad) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));

@@ -348,6 +348,7 @@ int fr_gram(fr_ctx* ctx, const fr_kprog* kernel, const double* A, int64_t n1, in
             int64_t ldb, int64_t d, double* out, int64_t ldo)
 {
     if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));
     if (d < 0) return set_err(ctx, FR_SHAPE, "negative feature count");
@@ -362,6 +363,7 @@ int fr_gram(fr_ctx* ctx, const fr_kprog* kernel, const double* A, int64_t n1, in
 int fr_mean_pairwise_distance(fr_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t d, double* out)
 {
     if (!ctx || !out) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
     FR_HIP(ctx, hipSetDevice(ctx->device));
     if (n < 2) {  // 0/0 in the reference (kernel.rs:112)
         *out = std::nan("");

@@ -404,3 +404,36 @@ def test_grad_terms_match_oracle(ctx, kernel):
     assert np.array_equal(np.isfinite(gs), fin)
     assert np.max(np.abs(gs[fin] - gs_o[fin])) < 1e-8 * (np.max(np.abs(gs_o[fin])) + 1.0)
     chol.free()
+
+
+def test_concurrent_predict_from_threads(ctx):
+    # GaussianProcess is Send + Sync in the reference: several threads may call &self methods of one model at once.
+    # The entry points of a context take turns (per-context lock); results must equal the sequential ones.
+    import threading
+
+    n, m, d = 900, 400, 4
+    kernel = PD_KERNELS[0]
+    X = rand_inputs(n, d, 41)
+    y = np.cos(X.sum(axis=1))
+    chol = ctx.cholesky_from_inputs(kernel, X, 0.1)
+    queries = [rand_inputs(m, d, 500 + i) for i in range(4)]
+    expect = [(chol.predict_mean(kernel, y, q, None), chol.predict_variance(kernel, q)) for q in queries]
+    got = [None] * len(queries)
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                got[i] = (chol.predict_mean(kernel, y, queries[i], None), chol.predict_variance(kernel, queries[i]))
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(queries))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    for (m0, v0), (m1, v1) in zip(expect, got):
+        assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+    chol.free()
