@@ -7,6 +7,7 @@ from friedrich_amd import synth
 from friedrich_amd.device import Context
 
 ctx = Context()
+NBS = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [256, 384, 512, 640, 768, 1024]
 for n in [int(a) for a in sys.argv[1].split(",")]:
     X, y, Xq = synth.make_problem(n, 16, cfg=4, m=1024)
     ls = ctx.mean_pairwise_distance(X)
@@ -14,7 +15,7 @@ for n in [int(a) for a in sys.argv[1].split(",")]:
     k = ("squared_exp", hp["ls"], hp["ampl"])
     chol = ctx.cholesky_from_inputs(k, X, hp["noise"], capacity_hint=n)
     for rnd in range(2):
-        for nb in (256, 384, 512, 640, 768, 1024):
+        for nb in NBS:
             ctx.set_option("nb", nb)
             ts = []
             for rep in range(3):
