@@ -240,6 +240,9 @@ int launch_col_dot(fr_ctx* ctx, const double* U, int64_t ldu, const double* V, i
 // out[j] = alpha * dot(V[:,j], y) + beta * out[j]
 int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ldv, const double* y, double alpha,
                   double beta, double* out);
+// y = alpha * A x + beta * y  (A rows x cols, column-major)
+int launch_gemv_n(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int64_t lda, const double* x, double alpha,
+                  double beta, double* y);
 int launch_axpby_vec(fr_ctx* ctx, int64_t n, double a, const double* x, double b, double* y);  // y = a*x + b*y
 int launch_diag_check_zero(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t* flag);
 int launch_sum_log_abs(fr_ctx* ctx, const double* v, int64_t n, double* out);

@@ -104,6 +104,33 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const double* V, int64_t n,
     if (threadIdx.x == 0) out[j] = alpha * tot + (beta != 0.0 ? beta * out[j] : 0.0);
 }
 
+// y[i] = alpha * sum_j A[i + j lda] x[j] + beta * y[i]   (single right-hand side of the triangular solves: HBM-bound,
+// A is read once).  64 rows per workgroup, four column groups per row, partials combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, int64_t rows, int64_t cols, int64_t lda,
+                                                     const double* __restrict__ x, double alpha, double beta,
+                                                     double* __restrict__ y)
+{
+    __shared__ double part[4][64];
+    const int r = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + r;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (i < rows) {
+        const double* a = A + i;
+        int64_t j = g;
+        for (; j + 4 < cols; j += 8) {
+            acc0 += a[j * lda] * x[j];
+            acc1 += a[(j + 4) * lda] * x[j + 4];
+        }
+        if (j < cols) acc0 += a[j * lda] * x[j];
+    }
+    part[g][r] = acc0 + acc1;
+    __syncthreads();
+    if (g == 0 && i < rows) {
+        const double tot = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+        y[i] = alpha * tot + (beta != 0.0 ? beta * y[i] : 0.0);
+    }
+}
+
 __global__ void axpby_kernel(int64_t n, double a, const double* x, double b, double* y)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,6 +231,17 @@ int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ld
     if (m <= 0) return FR_OK;
     ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)n * m, 8.0 * (double)n * m);
     hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)m), dim3(256), 0, ctx->ls, V, n, ldv, y, alpha, beta, out);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_gemv_n(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int64_t lda, const double* x, double alpha,
+                  double beta, double* y)
+{
+    if (rows <= 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)rows * cols, 8.0 * (double)rows * cols);
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, ctx->ls, A, rows, cols, lda, x,
+                       alpha, beta, y);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
