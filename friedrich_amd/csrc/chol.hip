@@ -708,7 +708,7 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     if (d != c->d) return set_err(ctx, FR_SHAPE, "add_rows: feature count %lld != %lld", (long long)d, (long long)c->d);
     if (ldx < imax(n_all, 1)) return set_err(ctx, FR_SHAPE, "add_rows: bad leading dimension");
     if (nb_new == 0) return FR_OK;
-    c->inv512_rows = 0;  // the factor grows: the cached 512-block inverses are rebuilt on the next wide solve
+    // (the cached 512-block inverses stay valid: rows below n_old are appended, blocks inside the old factor do not change)
     FR_TRY(chol_grow(c, n_all));
     c->nb = pick_nb(ctx, n_all);
     // new rows of the EMatrix mirror
@@ -717,12 +717,26 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     double* A21 = c->A + n_old;               // nb_new x n_old
     double* A22 = c->A + n_old + n_old * ld;  // nb_new x nb_new
     // K21 = k(new, old), K22 = lower(k(new, new)) + noise^2 I       (algebra/mod.rs:115-121)
-    FR_TRY(launch_gram_cross(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, c->X, n_old, c->ld_x, d, A21, ld));
     FR_TRY(launch_gram_sym(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, d, noise * noise, A22, ld));
     // L21 = K21 L11^-T ; K22 -= L21 L21^T ; L22 = chol(K22) with insert_column's plain sqrt (mode 2)
-    if (n_old > 0) {
-        FR_TRY(trsm_right_rec(ctx, c->A, ld, c->dinv, n_old, A21, nb_new, ld, FR_PROF_GEMM_PANEL));
+    if (n_old >= 4 * IB && nb_new >= IB) {
+        // a short, wide block: solving from the right would be GEMMs of nb_new rows (four tile rows, ~120 launches); the
+        // transposed problem  L21^T = L11^-1 K12  is a forward solve with nb_new right-hand sides (tall GEMMs, 512-row
+        // leaves), then one transposition into place
+        WsGuard wg(ctx);
+        const int64_t ldw = round_up(n_old, kAlign);
+        double* W = wg.get(sizeof(double) * (size_t)ldw * (size_t)nb_new);
+        if (!W) return FR_OUT_OF_MEMORY;
+        FR_TRY(launch_gram_cross(ctx, *kernel, c->X, n_old, c->ld_x, c->X + n_old, nb_new, c->ld_x, d, W, ldw));
+        FR_TRY(trsm_lower_fwd(ctx, c, n_old, W, nb_new, ldw, FR_PROF_GEMM_PANEL));
+        FR_TRY(launch_transpose(ctx, W, n_old, nb_new, ldw, A21, ld));
         FR_TRY(gemm(ctx, FR_PROF_SYRK, nb_new, nb_new, n_old, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
+    } else {
+        FR_TRY(launch_gram_cross(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, c->X, n_old, c->ld_x, d, A21, ld));
+        if (n_old > 0) {
+            FR_TRY(trsm_right_rec(ctx, c->A, ld, c->dinv, n_old, A21, nb_new, ld, FR_PROF_GEMM_PANEL));
+            FR_TRY(gemm(ctx, FR_PROF_SYRK, nb_new, nb_new, n_old, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
+        }
     }
     {
         WsGuard tmp(ctx);

@@ -326,6 +326,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->gemm_tile = value;
         return FR_OK;
     }
+    if (!strcmp(name, "splitk")) {
+        ctx->splitk = value != 0;
+        return FR_OK;
+    }
     if (!strcmp(name, "leaf512")) {
         ctx->leaf512 = value != 0;
         return FR_OK;

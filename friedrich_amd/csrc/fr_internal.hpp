@@ -56,6 +56,7 @@ struct fr_ctx {
     int64_t nb = 0;         // outer Cholesky block; 0 = chosen from the matrix size (pick_nb)
     int64_t gemm_tile = 0;      // tile-order experiments (gemm_f64.hip)
     int64_t ld_pad = 0;         // probe: elements added to a factor's leading dimension when it is a multiple of 1024
+    int64_t splitk = 1;         // GEMMs with few result tiles and a deep contraction are cut along K (gemm_f64.hip)
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
     // profiling
@@ -240,6 +241,8 @@ int launch_col_dot(fr_ctx* ctx, const double* U, int64_t ldu, const double* V, i
 // out[j] = alpha * dot(V[:,j], y) + beta * out[j]
 int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ldv, const double* y, double alpha,
                   double beta, double* out);
+// out (cols x rows, ldo) = in (rows x cols, ldi)^T
+int launch_transpose(fr_ctx* ctx, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out, int64_t ldo);
 // y = alpha * A x + beta * y  (A rows x cols, column-major)
 int launch_gemv_n(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int64_t lda, const double* x, double alpha,
                   double beta, double* y);

@@ -396,7 +396,64 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g
     gemm_f64_body<false, false>(g, lds);
 }
 
+// D = beta * Cin + sum over slices of the partial products (split-K), slices M x N with leading dimension M
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __restrict__ part, int64_t M, int64_t N, int slices,
+                                                            const double* __restrict__ cin, int64_t ldcin, double beta,
+                                                            double* __restrict__ out, int64_t ldd, int lower)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = blockIdx.y;
+    if (i >= M || j >= N) return;
+    if (lower && (i >> 7) < (j >> 7)) return;  // tiles strictly above the diagonal are not part of a lower-mode result
+    double acc = 0.0;
+    const double* p = part + i + j * M;
+    for (int s = 0; s < slices; ++s) acc += p[(int64_t)s * M * N];
+    out[i + j * ldd] = (beta != 0.0 ? beta * cin[i + j * ldcin] : 0.0) + acc;
+}
+
+static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d);
+
+// Few result tiles and a deep contraction (a 512-row block against 8192 columns: add_rows, narrow predicts): one tile's
+// K-loop is then the whole run time while most CUs idle.  The contraction is cut into slices computed as one batched
+// launch into a workspace, and a second small kernel adds them up (fixed order).  Main stream only (the workspace pool
+// relies on stream order), single GPU ownership only.
 int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
+{
+    if (d.M <= 0 || d.N <= 0) return FR_OK;
+    const int64_t tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    if (d.batch <= 1 && d.own_world <= 1 && ctx->ls == ctx->stream && ctx->splitk != 0 && tiles <= 192 && d.K >= 2048 &&
+        d.M <= 65535 * 256) {
+        int64_t S = (384 + tiles - 1) / tiles;
+        if (S > d.K / 256) S = d.K / 256;
+        if (S > 32) S = 32;
+        while (S > 1 && (d.K % S != 0 || (d.K / S) % BK != 0)) --S;
+        if (S > 1) {
+            WsGuard w(ctx);
+            double* part = w.get(sizeof(double) * (size_t)S * (size_t)d.M * (size_t)d.N);
+            if (!part) return FR_OUT_OF_MEMORY;
+            const int64_t ks = d.K / S;
+            GemmDesc p = d;
+            p.K = ks;
+            p.lower = false;
+            p.Cin = part; p.ldcin = d.M; p.D = part; p.ldd = d.M;
+            p.beta = 0.0;
+            p.batch = S;
+            p.batch_a = d.a_kmajor ? ks : ks * d.lda;
+            p.batch_b = d.b_kmajor ? ks : ks * d.ldb;
+            p.batch_c = p.batch_d = d.M * d.N;
+            FR_TRY(launch_gemm_plain(ctx, p));
+            const double* cin = d.Cin ? d.Cin : d.D;
+            const int64_t ldcin = d.Cin ? d.ldcin : d.ldd;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((d.M + 255) / 256), (unsigned)d.N), dim3(256), 0, ctx->ls,
+                               part, d.M, d.N, (int)S, cin, ldcin, d.beta, d.D, d.ldd, d.lower ? 1 : 0);
+            FR_HIP(ctx, hipGetLastError());
+            return FR_OK;
+        }
+    }
+    return launch_gemm_plain(ctx, d);
+}
+
+static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
 {
     if (d.M <= 0 || d.N <= 0) return FR_OK;
     GemmArgs g;
@@ -453,7 +510,8 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
         g.nsuper = 0;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
     const double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
-    ProfScope ps(ctx, d.prof_cls, flops, bytes);
+    const double nbatch = d.batch > 1 ? (double)d.batch : 1.0;
+    ProfScope ps(ctx, d.prof_cls, flops * nbatch, bytes * nbatch);
     g.batch_a = d.batch_a;
     g.batch_b = d.batch_b;
     g.batch_c = d.batch_c;

@@ -46,6 +46,24 @@ __global__ void tri_fill_kernel(double* p, int64_t n, int64_t ld, double v)
         if (r < n && r < c) p[r + c * ld] = v;
 }
 
+// out (cols x rows) = in (rows x cols)^T through a 64x64 LDS tile (coalesced on both sides)
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, int64_t rows, int64_t cols, int64_t ldi,
+                                                        double* __restrict__ out, int64_t ldo)
+{
+    __shared__ double tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {
+        const int64_t r = r0 + tx, c = c0 + k;
+        tile[k][tx] = (r < rows && c < cols) ? in[r + c * ldi] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const int64_t c = c0 + tx, r = r0 + k;  // out(c, r) = in(r, c)
+        if (r < rows && c < cols) out[c + r * ldo] = tile[tx][k];
+    }
+}
+
 // upper := lower^T through a 64x64 LDS tile (coalesced on both sides)
 __global__ __launch_bounds__(256) void symmetrize_kernel(double* p, int64_t n, int64_t ld)
 {
@@ -231,6 +249,15 @@ int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ld
     if (m <= 0) return FR_OK;
     ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)n * m, 8.0 * (double)n * m);
     hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)m), dim3(256), 0, ctx->ls, V, n, ldv, y, alpha, beta, out);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_transpose(fr_ctx* ctx, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out, int64_t ldo)
+{
+    if (rows <= 0 || cols <= 0) return FR_OK;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64)), dim3(256), 0,
+                       ctx->ls, in, rows, cols, ldi, out, ldo);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

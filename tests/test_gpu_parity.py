@@ -113,6 +113,25 @@ def test_cholesky_large_outer_blocks(ctx):
     ctx.set_option("nb", 0)
 
 
+def test_gemm_split_k_and_batched_paths(ctx):
+    # few result tiles + deep contraction: the product is cut along K (batched partial products + ordered reduction)
+    rng = np.random.default_rng(12)
+    for (M, N, K, ta, tb) in [(300, 200, 4096, False, False), (512, 512, 6144, False, True), (130, 700, 2048, True, False)]:
+        A = rng.standard_normal((K, M) if ta else (M, K))
+        B = rng.standard_normal((N, K) if tb else (K, N))
+        C0 = rng.standard_normal((M, N))
+        ref = 0.5 * (A.T if ta else A) @ (B.T if tb else B) - 2.0 * C0
+        outs = []
+        for sk in (1, 0):
+            ctx.set_option("splitk", sk)
+            C = np.asfortranarray(C0.copy())
+            ctx.gemm(A, B, C=C, trans_a=ta, trans_b=tb, alpha=0.5, beta=-2.0)
+            assert rel_err(C, ref) < 1e-12
+            outs.append(C)
+        ctx.set_option("splitk", 1)
+        assert rel_err(outs[0], outs[1]) < 1e-13
+
+
 def test_wide_solves_with_512_row_leaves(ctx):
     # >= 256 right-hand sides: the solves end in 512-row leaves (explicit 512-block inverses built on demand); n is not
     # a multiple of 512, so the last rows still take the 128-row path.  Also after add_rows (cache invalidated).
