@@ -383,10 +383,11 @@ static int single_rhs_solve(fr_ctx* ctx, const fr_chol* c, int64_t n, double* b,
     return fwd ? trsv_fwd_rec(ctx, c, 0, n, b, tmp) : trsv_bwd_rec(ctx, c, 0, n, b, tmp);
 }
 
-// 512-row leaves pay once the right-hand side is wide enough for the leaf product to fill the chip
+// 512-row leaves: fewer, larger links in the chain of dependent launches (measured down to 16 right-hand sides:
+// scripts/narrow_predict_ab.py); a single right-hand side takes the matrix-vector path above
 static bool wide_solve(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m)
 {
-    return ctx->leaf512 != 0 && n == c->n && n >= 2 * LB && m >= 256;
+    return ctx->leaf512 != 0 && n == c->n && n >= 2 * LB && m >= 2;
 }
 
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
