@@ -340,47 +340,60 @@ static int trsm_right_rec(fr_ctx* ctx, const double* L, int64_t ld, const double
     return trsm_right_rec(ctx, L + n1 + n1 * ld, ld, dinv + (n1 / IB) * INV_ELEMS, n - n1, X + n1 * ldx, k, ldx, cls);
 }
 
-// ---- single right-hand side (likelihood, K^-1 y, the m = 1 predict): matrix-vector kernels, L is read once --------------
-// Same recursion; leaves against the 512-block inverses (out of place: through `tmp`, 512 doubles).
-static int trsv_fwd_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* b, double* tmp)
+// ---- a few right-hand sides (likelihood, K^-1 y, predicting a handful of points) -----------------------------------------
+// Same recursion on memory-bound kernels that read L once per 16 columns (a matrix-vector kernel for one column): the GEMM's
+// 128-wide tiles would be mostly padding.  Leaves against the 512-block inverses, out of place through `tmp` (512 x m).
+static int narrow_fwd_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* b, int64_t m, int64_t ldb,
+                          double* tmp)
 {
     const int64_t ld = c->ld_a;
     const double* L = c->A + row0 + row0 * ld;
     const bool leaf512_ok = n == LB && row0 % LB == 0 && row0 + LB <= c->inv512_rows;
     if (leaf512_ok || n <= IB) {
         const double* W = leaf512_ok ? c->inv512 + (row0 / LB) * LB * LB : c->dinv + (row0 / IB) * INV_ELEMS;
-        FR_TRY(launch_copy(ctx, b, n, tmp, n, n, 1));
-        return launch_gemv_n(ctx, W, n, n, leaf512_ok ? LB : IB, tmp, 1.0, 0.0, b);
+        const int64_t ldw = leaf512_ok ? LB : IB;
+        FR_TRY(launch_copy(ctx, b, ldb, tmp, LB, n, m));
+        if (m == 1) return launch_gemv_n(ctx, W, n, n, ldw, tmp, 1.0, 0.0, b);
+        return launch_skinny_n(ctx, W, n, n, ldw, tmp, LB, m, 1.0, 0.0, b, ldb);
     }
     const int64_t n1 = (n > LB) ? (((n + LB - 1) / LB) / 2) * LB : split128(n);
-    FR_TRY(trsv_fwd_rec(ctx, c, row0, n1, b, tmp));
-    FR_TRY(launch_gemv_n(ctx, L + n1, n - n1, n1, ld, b, -1.0, 1.0, b + n1));
-    return trsv_fwd_rec(ctx, c, row0 + n1, n - n1, b + n1, tmp);
+    FR_TRY(narrow_fwd_rec(ctx, c, row0, n1, b, m, ldb, tmp));
+    if (m == 1)
+        FR_TRY(launch_gemv_n(ctx, L + n1, n - n1, n1, ld, b, -1.0, 1.0, b + n1));
+    else
+        FR_TRY(launch_skinny_n(ctx, L + n1, n - n1, n1, ld, b, ldb, m, -1.0, 1.0, b + n1, ldb));
+    return narrow_fwd_rec(ctx, c, row0 + n1, n - n1, b + n1, m, ldb, tmp);
 }
 
-static int trsv_bwd_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* b, double* tmp)
+static int narrow_bwd_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* b, int64_t m, int64_t ldb,
+                          double* tmp)
 {
     const int64_t ld = c->ld_a;
     const double* L = c->A + row0 + row0 * ld;
     const bool leaf512_ok = n == LB && row0 % LB == 0 && row0 + LB <= c->inv512_rows;
     if (leaf512_ok || n <= IB) {
         const double* W = leaf512_ok ? c->inv512 + (row0 / LB) * LB * LB : c->dinv + (row0 / IB) * INV_ELEMS;
-        FR_TRY(launch_copy(ctx, b, n, tmp, n, n, 1));
-        return launch_gemv_t(ctx, W, n, n, leaf512_ok ? LB : IB, tmp, 1.0, 0.0, b);  // b = W^T tmp
+        const int64_t ldw = leaf512_ok ? LB : IB;
+        FR_TRY(launch_copy(ctx, b, ldb, tmp, LB, n, m));
+        if (m == 1) return launch_gemv_t(ctx, W, n, n, ldw, tmp, 1.0, 0.0, b);  // b = W^T tmp
+        return launch_skinny_t(ctx, W, n, n, ldw, tmp, LB, m, 1.0, 0.0, b, ldb);
     }
     const int64_t n1 = (n > LB) ? (((n + LB - 1) / LB) / 2) * LB : split128(n);
-    FR_TRY(trsv_bwd_rec(ctx, c, row0 + n1, n - n1, b + n1, tmp));
-    FR_TRY(launch_gemv_t(ctx, L + n1, n - n1, n1, ld, b + n1, -1.0, 1.0, b));  // b1 -= L21^T b2
-    return trsv_bwd_rec(ctx, c, row0, n1, b, tmp);
+    FR_TRY(narrow_bwd_rec(ctx, c, row0 + n1, n - n1, b + n1, m, ldb, tmp));
+    if (m == 1)
+        FR_TRY(launch_gemv_t(ctx, L + n1, n - n1, n1, ld, b + n1, -1.0, 1.0, b));  // b1 -= L21^T b2
+    else
+        FR_TRY(launch_skinny_t(ctx, L + n1, n - n1, n1, ld, b + n1, ldb, m, -1.0, 1.0, b, ldb));
+    return narrow_bwd_rec(ctx, c, row0, n1, b, m, ldb, tmp);
 }
 
-static int single_rhs_solve(fr_ctx* ctx, const fr_chol* c, int64_t n, double* b, int cls, bool fwd)
+static int narrow_solve(fr_ctx* ctx, const fr_chol* c, int64_t n, double* b, int64_t m, int64_t ldb, int cls, bool fwd)
 {
     WsGuard w(ctx);
-    double* tmp = w.get(sizeof(double) * (size_t)LB);
+    double* tmp = w.get(sizeof(double) * (size_t)LB * (size_t)m);
     if (!tmp) return FR_OUT_OF_MEMORY;
     if (n >= 2 * LB) FR_TRY(ensure_inv512(ctx, c, cls));
-    return fwd ? trsv_fwd_rec(ctx, c, 0, n, b, tmp) : trsv_bwd_rec(ctx, c, 0, n, b, tmp);
+    return fwd ? narrow_fwd_rec(ctx, c, 0, n, b, m, ldb, tmp) : narrow_bwd_rec(ctx, c, 0, n, b, m, ldb, tmp);
 }
 
 // 512-row leaves: fewer, larger links in the chain of dependent launches (measured down to 16 right-hand sides:
@@ -393,7 +406,7 @@ static bool wide_solve(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
-    if (m == 1 && n == c->n && n >= 4 * IB) return single_rhs_solve(ctx, c, n, B, cls, true);
+    if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, true);
     WsGuard w(ctx);
     double* tmp = nullptr;
     if (wide_solve(ctx, c, n, m)) {
@@ -407,7 +420,7 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
 int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
-    if (m == 1 && n == c->n && n >= 4 * IB) return single_rhs_solve(ctx, c, n, B, cls, false);
+    if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, false);
     WsGuard w(ctx);
     double* tmp = nullptr;
     if (wide_solve(ctx, c, n, m)) {

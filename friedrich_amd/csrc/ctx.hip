@@ -326,6 +326,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->gemm_tile = value;
         return FR_OK;
     }
+    if (!strcmp(name, "narrow_max")) {
+        if (value < 0 || value > 4096) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow_max must be in [0, 4096]");
+        ctx->narrow_max = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "splitk")) {
         ctx->splitk = value != 0;
         return FR_OK;

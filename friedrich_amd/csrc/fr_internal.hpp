@@ -57,6 +57,7 @@ struct fr_ctx {
     int64_t gemm_tile = 0;      // tile-order experiments (gemm_f64.hip)
     int64_t ld_pad = 0;         // probe: elements added to a factor's leading dimension when it is a multiple of 1024
     int64_t splitk = 1;         // GEMMs with few result tiles and a deep contraction are cut along K (gemm_f64.hip)
+    int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
     // profiling
@@ -243,6 +244,11 @@ int launch_gemv_t(fr_ctx* ctx, const double* V, int64_t n, int64_t m, int64_t ld
                   double beta, double* out);
 // out (cols x rows, ldo) = in (rows x cols, ldi)^T
 int launch_transpose(fr_ctx* ctx, const double* in, int64_t rows, int64_t cols, int64_t ldi, double* out, int64_t ldo);
+// a handful of right-hand sides (m <= ~32): A streamed once, the small operand in scalar registers
+int launch_skinny_n(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int64_t lda, const double* X, int64_t ldx,
+                    int64_t m, double alpha, double beta, double* Y, int64_t ldy);
+int launch_skinny_t(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int64_t lda, const double* Y, int64_t ldy,
+                    int64_t m, double alpha, double beta, double* OUT, int64_t ldo);
 // y = alpha * A x + beta * y  (A rows x cols, column-major)
 int launch_gemv_n(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int64_t lda, const double* x, double alpha,
                   double beta, double* y);

@@ -149,6 +149,147 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ 
     }
 }
 
+// ---- "skinny" products: a handful of right-hand sides (2 .. 32 query rows) --------------------------------------------
+// The FP64 GEMM works in 128-wide tiles: with 16 right-hand sides 7/8 of every tile is padding and the solve costs as much
+// as with 128.  These two kernels stream A once from HBM against up to SKC columns of the small operand staged in LDS.
+constexpr int SKC = 16;  // right-hand-side columns per pass
+
+// Y[i, c] = alpha * sum_j A[i + j lda] X[j + c ldx] + beta * Y[i, c],  c < mc <= SKC.  64 rows per workgroup; A is consumed
+// in chunks of 64 columns whose X rows are staged in LDS; the columns of a chunk are dealt to the four waves (16 loads of A
+// in flight per thread), partial sums combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void skinny_n_kernel(const double* __restrict__ A, int64_t rows, int64_t cols, int64_t lda,
+                                                       const double* __restrict__ X, int64_t ldx, int mc, double alpha,
+                                                       double beta, double* __restrict__ Y, int64_t ldy)
+{
+    __shared__ __attribute__((aligned(16))) double xs[64][SKC];  // [j in chunk][c]
+    __shared__ double part[3][SKC][64];
+    const int t = threadIdx.x;
+    const int r = t & 63;
+    const int g = t >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + r;
+    const bool row_ok = i < rows;
+    const double* a = A + (row_ok ? i : 0);
+    double acc[SKC];
+#pragma unroll
+    for (int c = 0; c < SKC; ++c) acc[c] = 0.0;
+    for (int64_t j0 = 0; j0 < cols; j0 += 64) {
+        // stage X[j0 .. j0+63, 0 .. mc): thread (jj = t & 63, cq = t >> 6) loads columns cq, cq + 4, ...
+#pragma unroll
+        for (int k = 0; k < SKC / 4; ++k) {
+            const int c = (t >> 6) + 4 * k;
+            const int64_t j = j0 + (t & 63);
+            xs[t & 63][c] = (c < mc && j < cols) ? X[j + (int64_t)c * ldx] : 0.0;
+        }
+        __syncthreads();
+        double av[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int64_t j = j0 + g + 4 * k;
+            av[k] = (row_ok && j < cols) ? a[j * lda] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const double2* xr = reinterpret_cast<const double2*>(&xs[g + 4 * k][0]);
+#pragma unroll
+            for (int c = 0; c < SKC; c += 2) {
+                const double2 xv = xr[c >> 1];
+                acc[c] = __builtin_fma(av[k], xv.x, acc[c]);
+                acc[c + 1] = __builtin_fma(av[k], xv.y, acc[c + 1]);
+            }
+        }
+        __syncthreads();
+    }
+    if (g > 0) {
+#pragma unroll
+        for (int c = 0; c < SKC; ++c) part[g - 1][c][r] = acc[c];
+    }
+    __syncthreads();
+    if (g == 0 && row_ok) {
+#pragma unroll
+        for (int c = 0; c < SKC; ++c) {
+            if (c < mc) {
+                const double tot = (acc[c] + part[0][c][r]) + (part[1][c][r] + part[2][c][r]);
+                double* y = Y + i + (int64_t)c * ldy;
+                *y = alpha * tot + (beta != 0.0 ? beta * *y : 0.0);
+            }
+        }
+    }
+}
+
+// OUT[j, c] = alpha * sum_i A[i + j lda] Y[i + c ldy] + beta * OUT[j, c]   (A^T Y), c < mc <= SKC.  A 64 x 64 tile of A goes
+// through LDS (read along i, consumed along j) together with the 64 rows of Y it meets; 64 output rows per workgroup, the
+// rows i of a tile dealt to the four waves.
+__global__ __launch_bounds__(256) void skinny_t_kernel(const double* __restrict__ A, int64_t rows, int64_t cols, int64_t lda,
+                                                       const double* __restrict__ Y, int64_t ldy, int mc, double alpha,
+                                                       double beta, double* __restrict__ OUT, int64_t ldo)
+{
+    __shared__ double tile[64][65];                                  // [i][j]
+    __shared__ __attribute__((aligned(16))) double ys[64][SKC];      // [i][c]
+    __shared__ double part[3][SKC][64];
+    const int t = threadIdx.x;
+    const int jl = t & 63;
+    const int g = t >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    double acc[SKC];
+#pragma unroll
+    for (int c = 0; c < SKC; ++c) acc[c] = 0.0;
+    // software pipeline: the global loads of tile k + 1 are in flight while tile k is consumed from LDS
+    double ra[16], ry[SKC / 4];
+    auto fetch = [&](int64_t i0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int jj = (t >> 6) + 4 * k;
+            const int64_t ii = i0 + (t & 63), jc = j0 + jj;
+            ra[k] = (ii < rows && jc < cols) ? A[ii + jc * lda] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < SKC / 4; ++k) {
+            const int c = (t >> 6) + 4 * k;
+            const int64_t ii = i0 + (t & 63);
+            ry[k] = (c < mc && ii < rows) ? Y[ii + (int64_t)c * ldy] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int64_t i0 = 0; i0 < rows; i0 += 64) {
+        // 64 x 64 tile of A: thread (il = t & 63, jg = t >> 6) holds row il of columns jg, jg + 4, ...;  64 rows of Y alongside
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tile[t & 63][(t >> 6) + 4 * k] = ra[k];
+#pragma unroll
+        for (int k = 0; k < SKC / 4; ++k) ys[t & 63][(t >> 6) + 4 * k] = ry[k];
+        __syncthreads();
+        if (i0 + 64 < rows) fetch(i0 + 64);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int ii = g + 4 * k;
+            const double av = tile[ii][jl];
+            const double2* yr = reinterpret_cast<const double2*>(&ys[ii][0]);
+#pragma unroll
+            for (int c = 0; c < SKC; c += 2) {
+                const double2 yv = yr[c >> 1];
+                acc[c] = __builtin_fma(av, yv.x, acc[c]);
+                acc[c + 1] = __builtin_fma(av, yv.y, acc[c + 1]);
+            }
+        }
+        __syncthreads();
+    }
+    if (g > 0) {
+#pragma unroll
+        for (int c = 0; c < SKC; ++c) part[g - 1][c][jl] = acc[c];
+    }
+    __syncthreads();
+    const int64_t j = j0 + jl;
+    if (g == 0 && j < cols) {
+#pragma unroll
+        for (int c = 0; c < SKC; ++c) {
+            if (c < mc) {
+                const double tot = (acc[c] + part[0][c][jl]) + (part[1][c][jl] + part[2][c][jl]);
+                double* o = OUT + j + (int64_t)c * ldo;
+                *o = alpha * tot + (beta != 0.0 ? beta * *o : 0.0);
+            }
+        }
+    }
+}
+
 __global__ void axpby_kernel(int64_t n, double a, const double* x, double b, double* y)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,6 +399,36 @@ int launch_transpose(fr_ctx* ctx, const double* in, int64_t rows, int64_t cols, 
     if (rows <= 0 || cols <= 0) return FR_OK;
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64)), dim3(256), 0,
                        ctx->ls, in, rows, cols, ldi, out, ldo);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+// Y (rows x m) = alpha A (rows x cols) X (cols x m) + beta Y, m small: passes of SKC columns
+int launch_skinny_n(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int64_t lda, const double* X, int64_t ldx,
+                    int64_t m, double alpha, double beta, double* Y, int64_t ldy)
+{
+    if (rows <= 0 || m <= 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)rows * cols * m, 8.0 * (double)rows * cols * ((m + SKC - 1) / SKC));
+    for (int64_t c0 = 0; c0 < m; c0 += SKC) {
+        const int mc = (int)((m - c0) < SKC ? (m - c0) : SKC);
+        hipLaunchKernelGGL(skinny_n_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, ctx->ls, A, rows, cols, lda,
+                           X + c0 * ldx, ldx, mc, alpha, beta, Y + c0 * ldy, ldy);
+    }
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+// OUT (cols x m) = alpha A^T (cols x rows) Y (rows x m) + beta OUT
+int launch_skinny_t(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int64_t lda, const double* Y, int64_t ldy,
+                    int64_t m, double alpha, double beta, double* OUT, int64_t ldo)
+{
+    if (cols <= 0 || m <= 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)rows * cols * m, 8.0 * (double)rows * cols * ((m + SKC - 1) / SKC));
+    for (int64_t c0 = 0; c0 < m; c0 += SKC) {
+        const int mc = (int)((m - c0) < SKC ? (m - c0) : SKC);
+        hipLaunchKernelGGL(skinny_t_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, ctx->ls, A, rows, cols, lda,
+                           Y + c0 * ldy, ldy, mc, alpha, beta, OUT + c0 * ldo, ldo);
+    }
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

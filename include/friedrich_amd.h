@@ -95,6 +95,8 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "nb"            outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "lookahead"     1 (default): factor the next panel on a second stream under the trailing update
  *   "gemm_tile"     tile-order experiments of the GEMM (0 = default; see gemm_f64.hip)
+ *   "narrow_max"    16 (default): solves with at most this many right-hand sides use memory-bound kernels instead of the
+ *                   128-wide GEMM tiles
  *   "splitk"        1 (default): products with few result tiles and a deep contraction are cut along K; 0: never
  *   "leaf512"       1 (default): wide triangular solves (>= 256 right-hand sides) end in 512-row leaves against
  *                   explicit inverses of the 512 x 512 diagonal blocks, built on demand; 0: 128-row leaves only

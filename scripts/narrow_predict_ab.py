@@ -1,4 +1,4 @@
-"""Developer probe: predict / predict_variance with few query rows (narrow right-hand sides), split-K on / off."""
+"""Developer probe: predict / predict_variance with few query rows: memory-bound narrow kernels vs the GEMM path."""
 import sys
 import time
 
@@ -15,10 +15,10 @@ ls = ctx.mean_pairwise_distance(X)
 hp = synth.default_hyperparameters(X, y, ls)
 k = ("squared_exp", hp["ls"], hp["ampl"])
 chol = ctx.cholesky_from_inputs(k, X, hp["noise"], capacity_hint=n)
-for m in (1, 16, 64, 128, 256, 512, 1024):
+for m in (2, 8, 16, 32, 64, 128, 256):
     _, _, Xq = synth.make_problem(n, 16, cfg=4, m=m)
     for sk in (0, 1):
-        ctx.set_option("splitk", sk)
+        ctx.set_option("narrow_max", 4096 if sk else 1)
         tp, tv = [], []
         for rep in range(3):
             t0 = time.perf_counter()
@@ -28,4 +28,4 @@ for m in (1, 16, 64, 128, 256, 512, 1024):
             t2 = time.perf_counter()
             tp.append(t1 - t0)
             tv.append(t2 - t1)
-        print(f"n={n} m={m} splitk={sk}: predict {1e3*min(tp):.2f} ms  variance {1e3*min(tv):.2f} ms", flush=True)
+        print(f"n={n} m={m} narrow={sk}: predict {1e3*min(tp):.2f} ms  variance {1e3*min(tv):.2f} ms", flush=True)

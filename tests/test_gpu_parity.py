@@ -146,10 +146,11 @@ def test_wide_solves_with_512_row_leaves(ctx):
         assert rel_err(chol.solve(B[:n0]), O.chol_solve(L0, B[:n0])) < 1e-8
         assert rel_err(chol.solve_lower(B[:n0]), O.solve_lower(L0, B[:n0])[1]) < 1e-9
     ctx.set_option("leaf512", 1)
-    # a single right-hand side takes the matrix-vector path (L read once); same recursion, same leaves
-    b1 = np.asfortranarray(B[:n0, :1])
-    assert rel_err(chol.solve(b1), O.chol_solve(L0, b1)) < 1e-8
-    assert rel_err(chol.solve_lower(b1), O.solve_lower(L0, b1)[1]) < 1e-9
+    # a few right-hand sides take the memory-bound kernels (L read once per 16 columns); same recursion, same leaves
+    for mm in (1, 2, 7, 16):
+        bb = np.asfortranarray(B[:n0, :mm])
+        assert rel_err(chol.solve(bb), O.chol_solve(L0, bb)) < 1e-8
+        assert rel_err(chol.solve_lower(bb), O.solve_lower(L0, bb)[1]) < 1e-9
     chol.add_rows(kernel, X, n - n0, 0.08)
     _, L1, _ = O.make_cholesky_cov_matrix(kernel, X, 0.08)
     assert rel_err(chol.solve(B), O.chol_solve(L1, B)) < 1e-8
