@@ -10,7 +10,8 @@
 //   mode 2 (add_rows / Cholesky::insert_column, algebra/mod.rs:124; Appendix A.3): plain sqrt(d), NaN and
 //   division by zero propagate exactly as in the reference, nothing is recorded.
 //   mode 3: the block already holds a factor; only its inverse is produced (serde upload, re-alignment).
-// Column scaling (`col /= denom`) is a reciprocal multiply with one residual correction.
+// Column scaling (`col /= denom`) multiplies by 1 / sqrt(d) (v_rsq_f64 seed + two Newton steps, accurate to about an ulp);
+// the stored diagonal sqrt(d) = d / sqrt(d) takes one Heron correction.
 //
 // The factorisation of a diagonal block is a chain of n dependent pivots: what matters is the latency of ONE step, and
 // this kernel sits on the critical path of the look-ahead pipeline (N such steps per fit, next to a chip full of GEMM
@@ -19,18 +20,22 @@
 //   * the 128 x 128 block is cut into 32 x 32 sub-blocks kept in LDS (lower triangle: 10 slots, 80 KiB, which still
 //     fits beside one resident GEMM workgroup);
 //   * F_b: wave 0 factors diagonal sub-block b wave-synchronously.  Row i of the sub-block is split over lanes i and
-//     i + 32 (16 register slots each).  Step j writes the scaled column to LDS (one ds_write: the sub-block's own slot,
-//     dead once it is in registers) and reads L(c, j) back as broadcasts (operands of the rank-1 FMAs), all in flight
-//     at once.  The next pivot does not wait for that
-//     round trip: lane j + 1 updates its own diagonal element from its own L(j + 1, j), one v_readlane publishes it,
-//     and the sqrt / reciprocal chain is interleaved stage by stage with the rank-1 updates;
-//   * T: the rows below (sub-blocks b + 1 .. 3) are solved by one update wave each with the same right-looking
-//     recurrence (L_bb broadcast from LDS); X_bb = L_bb^-1 comes from the same routine applied to e_c;
-//   * the other updates are 32^3 products spread over the update waves (LDS-broadcast operands):
-//     U: A_ik -= L_ib L_kb^T, and the inverse W = L^-1 by block elimination (W_bc = X_bb W_bc;  W_ic -= L_ib W_bc;
-//     W_ib = -L_ib X_bb), which overwrites the L sub-blocks once they are dead.
+//     i + 32 (16 register slots each).  Step j writes the scaled column to LDS (one ds_write into the sub-block's own
+//     slot, dead once it is in registers: the "image" of L_bb, reciprocal pivots on its diagonal), bumps a column counter
+//     and reads L(c, j) back as broadcasts (operands of the rank-1 FMAs), all in flight at once.  The next pivot does
+//     not wait for that round trip: lane j + 1 updates its own diagonal element from its own L(j + 1, j), one v_readlane
+//     publishes it, and the stages of the reciprocal-pivot chain are issued between the other parts of the step;
+//   * the triangular solves of the stage run CONCURRENTLY on the update waves, one column behind the pivot chain (they poll
+//     the LDS counter): T: L_ib = A_ib L_bb^-T for the sub-blocks below, X_bb = L_bb^-1 (the same routine applied to e_c),
+//     and the inverse's row solve W_bc = L_bb^-1 W_bc;
+//   * the remaining updates are 32^3 products as MFMA 16 x 16 tiles over the update waves:  U: A_ik -= L_ib L_kb^T, and the
+//     block elimination of the inverse (W_ic -= L_ib W_bc;  W_ib = -L_ib X_bb), which overwrites the L sub-blocks once
+//     they are dead.  The inverse is kept transposed in LDS so that every product is an "N T" contraction.
 //
 // Factor columns are stored to global memory as they are produced (fire and forget: barriers order LDS only).
+// Alone the kernel takes ~60 us for a full block (F: 4 x 7.8 us); next to a GEMM workgroup ~4x that: every dependent
+// f64 operation then queues behind the neighbour's MFMAs and an LDS round trip costs ~900 cycles instead of ~150
+// (scripts/contention_probe.hip, scripts/potf2_bench_phases.hip).
 #include "fr_internal.hpp"
 
 namespace fr {
@@ -84,48 +89,6 @@ __device__ __forceinline__ int slot_of(int i, int k)
 __device__ __forceinline__ void pin(double& x)
 {
     asm volatile("" : "+v"(x));
-}
-
-// 32^3 products of the update waves.  Lane (r, h) accumulates NC consecutive result columns of row r; the row operand
-// A(r, k) is read from LDS as it is needed (a rolled k loop: with the row held in registers and the loop unrolled the
-// instruction selector hoists every LDS read to the top and spills hundreds of registers).
-//   acc[c] = sum_k A[r + 32 k] * B[(c0 + c) + 32 k]   ("A B^T": B is indexed [column of the result, k])
-template <int NC>
-__device__ __forceinline__ void prod_nt(const double* Arow, const double* B, int c0, double (&acc)[NC])
-{
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-    const double* bp = B + c0;
-#pragma unroll 4
-    for (int k = 0; k < SB; ++k) {
-        const double a = Arow[SB * k];
-        const double2* b2 = reinterpret_cast<const double2*>(bp + SB * k);
-#pragma unroll
-        for (int c = 0; c < NC; c += 2) {
-            const double2 v = b2[c >> 1];
-            acc[c] = __builtin_fma(a, v.x, acc[c]);
-            acc[c + 1] = __builtin_fma(a, v.y, acc[c + 1]);
-        }
-    }
-}
-
-//   acc[c] = sum_k A[r + 32 k] * B[k + 32 (c0 + c)]   ("A B")
-template <int NC>
-__device__ __forceinline__ void prod_nn(const double* Arow, const double* B, int c0, double (&acc)[NC])
-{
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-    const double* bp = B + SB * c0;
-#pragma unroll 2
-    for (int k = 0; k < SB; k += 2) {
-        const double a0 = Arow[SB * k], a1 = Arow[SB * (k + 1)];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const double2 v = *reinterpret_cast<const double2*>(bp + k + SB * c);
-            acc[c] = __builtin_fma(a0, v.x, acc[c]);
-            acc[c] = __builtin_fma(a1, v.y, acc[c]);
-        }
-    }
 }
 
 // ---- split-row layout of the wave-synchronous routines -------------------------------------------------------------
