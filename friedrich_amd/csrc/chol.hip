@@ -9,13 +9,17 @@
 //   Cholesky::inverse               src/gaussian_process/optimizer.rs:32, 169
 //   DMatrix::cholesky().unpack()    src/gaussian_process/multivariate_normal.rs:57
 //
-// Structure.  Three block sizes:
-//   128  K4 potf2 + "inverse block": one workgroup factors a 128 x 128 diagonal block in LDS and emits its explicit
-//        inverse (potf2.hip); the inverses are kept next to the factor (fr_chol::dinv).  Every triangular solve -- inside the factorisation and in the predict
-//        family -- is a chain of FP64-MFMA GEMMs against these inverses; with N (or M) <= 128 the GEMM has a
-//        single tile column (row), so it can safely run in place.
-//   nb   (default 256) outer block: the trailing update A22 -= P P^T is one lower-triangular SYRK launch with
-//        K = nb, the dominant FP64-MFMA kernel (n^3/3 of the flops).
+// Structure.  Block sizes:
+//   128  K4 potf2 + "inverse block": one workgroup factors a 128 x 128 diagonal block and emits its explicit inverse
+//        (potf2.hip); the inverses are kept next to the factor (fr_chol::dinv).  Every triangular solve inside the
+//        factorisation is a GEMM against these inverses; with N (or M) <= 128 the GEMM has a single tile column (row), so
+//        it can safely run in place.
+//   512  leaves of the solves of the predict family: explicit inverses of the 512 x 512 diagonal blocks, assembled on
+//        demand from the 128-block inverses by batched GEMMs (fr_chol::inv512).
+//   nb   outer block (pick_nb: 1024 at N >= 24576 on one GPU, else 512): the trailing update A22 -= P P^T is one
+//        lower-triangular SYRK launch with K = nb, the dominant FP64-MFMA kernel (n^3/3 of the flops).
+// Solves pick their kernels by the number of right-hand sides: <= 16 memory-bound kernels (L streamed once), otherwise
+// the recursive GEMM formulation.
 #include "fr_internal.hpp"
 #include <algorithm>
 
