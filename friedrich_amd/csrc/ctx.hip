@@ -331,6 +331,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->narrow_max = value;
         return FR_OK;
     }
+    if (!strcmp(name, "gemm_lower_probe")) {
+        ctx->gemm_lower_probe = value != 0;
+        return FR_OK;
+    }
     if (!strcmp(name, "splitk")) {
         ctx->splitk = value != 0;
         return FR_OK;

@@ -154,7 +154,19 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
         const int64_t nblk = gridDim.x;
         const int64_t q = nblk >> 3, r8 = nblk & 7;
         const int64_t tlin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
-        if (g.lower) {
+        if (g.lower == 2) {
+            // lower triangle column by column (tm fastest), like the full mode: consecutive workgroups continue down the
+            // same 128 columns of C (the next 1 KiB of every column) and share one B panel.  Column tn holds T - tn tiles.
+            const int64_t T = g.tiles_m;
+            const double tt = 2.0 * (double)T + 1.0;
+            int64_t col = (int64_t)((tt - sqrt(tt * tt - 8.0 * (double)tlin)) * 0.5);
+            if (col < 0) col = 0;
+            if (col >= T) col = T - 1;
+            while (col > 0 && col * T - col * (col - 1) / 2 > tlin) --col;
+            while ((col + 1) * T - (col + 1) * col / 2 <= tlin) ++col;
+            tn = col;
+            tm = col + (tlin - (col * T - col * (col - 1) / 2));
+        } else if (g.lower) {
             int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
             while (row * (row + 1) / 2 > tlin) --row;
             while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
@@ -470,7 +482,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.ldd = d.ldd;
     g.alpha = d.alpha;
     g.beta = d.beta;
-    g.lower = d.lower ? 1 : 0;
+    g.lower = d.lower ? ((ctx->gemm_tile == 5) ? 2 : 1) : 0;
     g.own_world = d.own_world;
     g.own_rank = d.own_rank;
     g.own_nb = d.own_nb > 0 ? d.own_nb : 1;

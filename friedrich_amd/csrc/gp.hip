@@ -282,7 +282,9 @@ int fr_gemm(fr_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t
     g.A = a.dev; g.lda = a.ld; g.a_kmajor = trans_a != 0;   // stored K x M: element (m,k) at A[k + m*lda]
     g.B = b.dev; g.ldb = b.ld; g.b_kmajor = trans_b == 0;   // stored K x N: element (k,n) at B[k + n*ldb]
     g.Cin = c.dev; g.ldcin = c.ld; g.D = c.dev; g.ldd = c.ld;
-    g.alpha = alpha; g.beta = beta; g.lower = false; g.prof_cls = FR_PROF_GEMM_SOLVE;
+    g.alpha = alpha; g.beta = beta; g.prof_cls = FR_PROF_GEMM_SOLVE;
+    // developer probes time the lower-triangular tile set through this entry point (option gemm_lower_probe)
+    g.lower = ctx->gemm_lower_probe != 0 && M == N;
     FR_TRY(launch_gemm(ctx, g));
     return c.commit();
 }

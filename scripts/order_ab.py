@@ -12,6 +12,7 @@ from friedrich_amd.device import Context
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 ctx = Context()
+MODES = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 2, 3]
 ctx.set_option("nb", nb)
 X, y, Xq = synth.make_problem(n, 16, cfg=4, m=1024)
 ls = ctx.mean_pairwise_distance(X)
@@ -19,7 +20,7 @@ hp = synth.default_hyperparameters(X, y, ls)
 k = ("squared_exp", hp["ls"], hp["ampl"])
 chol = ctx.cholesky_from_inputs(k, X, hp["noise"], capacity_hint=n)
 for rnd in range(2):
-    for mode in (0, 1, 2, 3):
+    for mode in MODES:
         ctx.set_option("gemm_tile", mode)
         ts = []
         for rep in range(3):

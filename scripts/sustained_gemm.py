@@ -9,12 +9,12 @@ from friedrich_amd.device import Context
 
 ctx = Context()
 dev = torch.device("cuda", 0)
-M, K = 16384, 1024
+M, K = (int(sys.argv[1]) if len(sys.argv) > 1 else 16384), (int(sys.argv[2]) if len(sys.argv) > 2 else 1024)
 A = torch.randn((K, M), dtype=torch.float64, device=dev).t()
 C = torch.zeros((M, M), dtype=torch.float64, device=dev).t()
 fl = 2.0 * M * M * K
 t_begin = time.perf_counter()
-for burst in range(12):
+for burst in range(4):
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < 0.5:
