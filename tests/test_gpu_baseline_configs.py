@@ -21,6 +21,7 @@ def _empty_cm(torch, n, m, dev):
 @pytest.mark.parametrize("name,n,d,kernel_name,eps", [
     ("config2_matern52_eps", 16384, 16, "matern2", 1e-9),   # BASELINE configs[2]
     ("config3_rbf", 32768, 16, "squared_exp", None),          # BASELINE configs[3] (the bench workload)
+    ("twice_config3", 65536, 16, "squared_exp", None),         # 32 GiB factor: 64-bit indexing, sized for 288 GB of HBM
 ])
 def test_full_size_fit_properties(ctx, name, n, d, kernel_name, eps):
     torch = pytest.importorskip("torch")
