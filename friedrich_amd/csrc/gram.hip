@@ -108,17 +108,28 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a)
         __syncthreads();
     }
 
+    // Epilogue: the kernel program is evaluated per pair.  Its body (a switch over nine leaf kinds, exp / pow inside) is too
+    // large for the compiler to unroll 32 times, and a rolled loop that indexes s[h][b] dynamically sends the accumulators
+    // through scratch memory (measured: 4x the algorithmic bytes written, 2x fetched, per launch).  So the loop over the 16
+    // columns stays rolled but always consumes element 0 and then rotates the register arrays (static indices only).
+#pragma unroll 1
+    for (int b = 0; b < 16; ++b) {
+        const int64_t gj = j0 + g * 16 + b;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int64_t gi = i0 + r + 64 * h;
-        if (gi >= a.n1) continue;
+        for (int h = 0; h < 2; ++h) {
+            const int64_t gi = i0 + r + 64 * h;
+            if (gi < a.n1 && gj < a.n2) {
+                double k = kprog_eval(a.prog, s[h][0], u[h][0]);
+                if (a.sym && gi == gj) k = k + a.noise2;  // algebra/mod.rs:78
+                a.out[gi + gj * a.ldo] = k;
+            }
+        }
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const int64_t gj = j0 + g * 16 + b;
-            if (gj >= a.n2) continue;
-            double k = kprog_eval(a.prog, s[h][b], u[h][b]);
-            if (a.sym && gi == gj) k = k + a.noise2;  // algebra/mod.rs:78
-            a.out[gi + gj * a.ldo] = k;
+        for (int i = 0; i < 15; ++i) {
+            s[0][i] = s[0][i + 1];
+            s[1][i] = s[1][i + 1];
+            u[0][i] = u[0][i + 1];
+            u[1][i] = u[1][i + 1];
         }
     }
 }
