@@ -188,29 +188,50 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradArgs a)
         __syncthreads();
     }
     double acc[MAXG];
+#pragma unroll
     for (int q = 0; q < MAXG; ++q) acc[q] = 0.0;
+    // The gradient program is too large to be unrolled 32 times; a rolled loop indexing s[h][b] dynamically would send the
+    // accumulators through scratch memory (see gram.hip).  The column loop stays rolled, consumes element 0 and rotates the
+    // register arrays; the per-parameter loops are unrolled with a guard so that acc / gv keep static indices.
+    double ai[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int64_t gi = i0 + r + 64 * h;
-        if (gi >= a.n) continue;
-        const double ai = a.alpha[gi];
+        ai[h] = (gi < a.n) ? a.alpha[gi] : 0.0;
+    }
+#pragma unroll 1
+    for (int b = 0; b < 16; ++b) {
+        const int64_t gj = j0 + g * 16 + b;
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const int64_t gj = j0 + g * 16 + b;
-            if (gj > gi) continue;  // lower triangle incl. diagonal (algebra/mod.rs:142-151)
-            double gv[MAXG];
-            const int ng = kprog_grad(a.prog, s[h][b], u[h][b], gv);
-            const double w = (gi == gj) ? 1.0 : 2.0;
-            const double coef = w * (ai * a.alpha[gj] * a.inv_scale - a.Kinv[gi + gj * a.ldk]);
-            for (int q = 0; q < ng; ++q) acc[q] += coef * gv[q];
+        for (int h = 0; h < 2; ++h) {
+            const int64_t gi = i0 + r + 64 * h;
+            if (gi < a.n && gj <= gi) {  // lower triangle incl. diagonal (algebra/mod.rs:142-151)
+                double gv[MAXG];
+                const int ng = kprog_grad(a.prog, s[h][0], u[h][0], gv);
+                const double w = (gi == gj) ? 1.0 : 2.0;
+                const double coef = w * (ai[h] * a.alpha[gj] * a.inv_scale - a.Kinv[gi + gj * a.ldk]);
+#pragma unroll
+                for (int q = 0; q < MAXG; ++q)
+                    if (q < ng) acc[q] += coef * gv[q];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            s[0][i] = s[0][i + 1];
+            s[1][i] = s[1][i + 1];
+            u[0][i] = u[0][i + 1];
+            u[1][i] = u[1][i + 1];
         }
     }
     // block reduction of the ng accumulators
-    for (int q = 0; q < a.ng; ++q) {
-        double v = acc[q];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((t & 63) == 0) red[t >> 6][q] = v;
+    for (int q = 0; q < MAXG; ++q) {
+        if (q < a.ng) {
+            double v = acc[q];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((t & 63) == 0) red[t >> 6][q] = v;
+        }
     }
     __syncthreads();
     if (t < a.ng) a.partials[(int64_t)blockIdx.x * a.ng + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
