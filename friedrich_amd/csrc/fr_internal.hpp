@@ -59,6 +59,7 @@ struct fr_ctx {
     int64_t splitk = 1;         // GEMMs with few result tiles and a deep contraction are cut along K (gemm_f64.hip)
     int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
     int64_t gemm_lower_probe = 0;  // probe: fr_gemm computes only the lower-triangular tile set of a square result
+    bool potf2_lds_set = false;  // dynamic-LDS attribute of the diagonal-block kernel applied on this device
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
     // profiling

@@ -632,11 +632,10 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
 {
     if (nbk <= 0) return FR_OK;
     if (nbk > PB) return set_err(ctx, FR_INVALID_ARGUMENT, "potf2 block too large");
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->potf2_lds_set) {  // per context (= per device): the attribute belongs to the device's copy of the kernel
         FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
-        attr_set = true;
+        ctx->potf2_lds_set = true;
     }
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
     hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv,
