@@ -4,13 +4,15 @@
 #include <vector>
 #include <cmath>
 namespace fr {
-constexpr int PB = 128;
-constexpr int PT = 512;  // threads: 8 waves x <= 128 VGPRs fit beside ONE resident GEMM workgroup (look-ahead overlap)
-constexpr int PE = 32;   // elements per thread
-constexpr int PG = 4;    // column groups
+constexpr int PB = 128;  // largest block
+constexpr int SB = 32;   // sub-block
+constexpr int SBE = SB * SB;
+constexpr int PT = 512;  // 8 waves; <= 128 VGPRs so that they fit beside ONE resident GEMM workgroup
+constexpr int NSLOT = 10;
+constexpr size_t POTF2_LDS = (size_t)NSLOT * SBE * sizeof(double) + 16;  // + the column counter of the panel wave
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the
-// column store of every step to be acknowledged by memory (~2 us per step, 6x the rest of the step).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every
+// outstanding factor-column store to be acknowledged by memory (microseconds under GEMM load).
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -21,11 +23,6 @@ __device__ __forceinline__ void lds_barrier()
 // most of a step.  Results agree with sqrt()/division to the last bit or 1 ulp (the oracle comparison bounds it).
 __device__ __forceinline__ void sqrt_rsqrt(double d, double& p, double& ip)
 {
-    if (d == 0.0) {  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
-        p = 0.0;
-        ip = __builtin_inf();
-        return;
-    }
     double r = __builtin_amdgcn_rsq(d);
     const double h = 0.5 * d;
     r = r * __builtin_fma(-h * r, r, 1.5);
@@ -33,146 +30,564 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double& p, double& ip)
     double q = d * r;
     q = __builtin_fma(0.5 * r, __builtin_fma(-q, q, d), q);  // sqrt(d), corrected
     r = r * __builtin_fma(-q, r, 2.0);                        // 1 / q
-    p = q;
-    ip = r;
+    const bool zero = (d == 0.0);  // plain-sqrt mode: sqrt(0) = 0, then the reference divides by zero
+    p = zero ? 0.0 : q;
+    ip = zero ? __builtin_inf() : r;
 }
 
-// pivot rule for one diagonal value (executed by ONE thread per step): pivot and its reciprocal; logs substitutions
-// and failures
-__device__ __forceinline__ void pivot_of(double d, int mode, double sub, int64_t col, int64_t* __restrict__ info, double& p,
-                                         double& ip)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
-    if (mode == 3) {  // already a factor
-        p = d;
-        ip = 1.0 / d;
-        return;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int slot_of(int i, int k)
+{
+    return (i * (i + 1) / 2 + k) * SBE;
+}
+
+// Optimisation barrier: the value must be materialised in a VGPR at this point of the program.  Without it the
+// instruction selector's scheduler sinks every rank-1 FMA down to the step that next reads the slot (a legal but
+// pathological order: all multipliers and broadcast values of all steps stay live, hundreds of spills).
+__device__ __forceinline__ void pin(double& x)
+{
+    asm volatile("" : "+v"(x));
+}
+
+// ---- split-row layout of the wave-synchronous routines -------------------------------------------------------------
+// A vector of 32 (a row of a sub-block, or a column of the inverse) is held by TWO lanes: lane (r, h) = r + 32 h owns
+// the 16 slots c = 16 h + k.  64 lanes work on one 32 x 32 sub-block, a lane needs 32 VGPRs for its slots and 32 for a
+// whole column of broadcasts, so every LDS read of a step is in flight at once (a ~130-cycle latency paid once per
+// step, behind the pivot chain, instead of once per FMA).
+constexpr int HB = 16;  // slots per lane
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// value of the same row in half H, delivered to both halves (one v_permlane32_swap per dword)
+template <int H>
+__device__ __forceinline__ double bcast_half(double x)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[H], (int)rl[H]);
+}
+
+// broadcasts of one column J of the factor image: L(16 h + k, J) for the lane's 16 slots, as 8 aligned pairs
+struct ColBcast {
+    double2 v[HB / 2];
+};
+
+constexpr int first_live_slot(int J)  // slots k >= this are still live in some half after column J
+{
+    return J < HB ? 0 : (J % HB) + 1;
+}
+
+template <int J, int P>
+__device__ __forceinline__ void col_load(ColBcast& cb, const double* bufh)
+{
+    if constexpr (P < HB / 2) {
+        if constexpr (2 * P + 1 >= first_live_slot(J)) cb.v[P] = *reinterpret_cast<const double2*>(bufh + 2 * P + SB * J);
+        col_load<J, P + 1>(cb, bufh);
     }
-    if (mode == 2 || d > 0.0) {  // insert_column: plain sqrt (NaN for d < 0)
-        sqrt_rsqrt(d, p, ip);
-        return;
+}
+
+// ---- F_b: wave-synchronous factorisation of diagonal sub-block b (executed by wave 0 only) --------------------------
+struct FState {
+    double* gptr;       // &A[row r, current column]
+    double* cptr;       // &image[r]: where the owner half writes its element of the current column
+    const double* bufh; // &image[16 h]: base of this lane's broadcast reads
+    int* flag;          // LDS counter: number of factor columns published so far (all stages)
+    int flag_base;      // 32 b
+    int64_t lda, colbase;  // colbase: global column index of the sub-block's first column
+    double p_exc, ip_exc;  // replacement pivot of the exception rule (NaN = failure)
+    int r, h, lane, mode, ncols_ok;  // ncols_ok: columns j < ncols_ok lie inside the matrix
+    bool row_ok;
+};
+
+// The reciprocal pivot of step J + 1 is a chain of dependent f64 operations on the critical path of the whole
+// factorisation (and every one of them queues behind the MFMAs of a co-resident GEMM wave), so it is kept minimal:
+// v_rsq_f64 seed + two Newton steps give r = 1 / sqrt(d) to about an ulp, and that IS what the next column is
+// multiplied by.  sqrt(d) itself (the stored diagonal) is derived off the chain.  The stages are interleaved with the
+// rest of the step (pinned with sched_barrier).
+struct PivotChain {
+    double d, r, h, t;
+};
+
+template <bool M3, int K>
+__device__ __forceinline__ void chain_stage(PivotChain& c)
+{
+    if constexpr (M3) {  // the block already holds the factor: 1 / d (reciprocal seed + two Newton steps)
+        if constexpr (K == 0) c.r = __builtin_amdgcn_rcp(c.d);
+        if constexpr (K == 1) c.t = __builtin_fma(-c.d, c.r, 1.0);
+        if constexpr (K == 2) c.r = __builtin_fma(c.r, c.t, c.r);
+        if constexpr (K == 3) c.t = __builtin_fma(-c.d, c.r, 1.0);
+        if constexpr (K == 4) c.r = __builtin_fma(c.r, c.t, c.r);
+        if constexpr (K == 0 || K == 2 || K == 4) pin(c.r);
+        if constexpr (K == 1 || K == 3) pin(c.t);
+    } else {
+        if constexpr (K == 0) {
+            c.r = __builtin_amdgcn_rsq(c.d);
+            c.h = -0.5 * c.d;
+        }
+        if constexpr (K == 1) c.t = c.h * c.r;
+        if constexpr (K == 2) c.t = __builtin_fma(c.t, c.r, 1.5);
+        if constexpr (K == 3) c.r = c.r * c.t;
+        if constexpr (K == 4) c.t = c.h * c.r;
+        if constexpr (K == 5) c.t = __builtin_fma(c.t, c.r, 1.5);
+        if constexpr (K == 6) c.r = c.r * c.t;
+        if constexpr (K == 7) c.r = (c.d == 0.0) ? __builtin_inf() : c.r;  // plain-sqrt mode: the reference divides by 0
+        if constexpr (K == 0 || K == 3 || K == 6 || K == 7) pin(c.r);
+        if constexpr (K == 1 || K == 2 || K == 4 || K == 5) pin(c.t);
+        if constexpr (K == 0) pin(c.h);
     }
-    if (mode == 1 && sub > 0.0) {
-        const int64_t q = info[1];
-        info[3 + q] = col;
-        info[1] = q + 1;
-        sqrt_rsqrt(sub, p, ip);
-        return;
+}
+
+template <bool M3>
+struct ChainShape {
+    static constexpr int NST = M3 ? 5 : 8;
+};
+
+// Pivot rule for a diagonal value that is 0, negative or NaN (any mode but plain-sqrt): the replacement pivot
+// (sqrt(sub) and its reciprocal, or NaN = failure) is prepared once per launch and selected without a branch; the
+// column is only noted in a bit mask.  The log in global memory is written after the unrolled steps: a memory access on
+// a rare path inside them would make every step wait for the outstanding factor-column stores at the join.
+__device__ __forceinline__ void pivot_select(const FState& st, double d, int j, double& ip, unsigned& excmask)
+{
+    const bool bad = !(st.mode == 2 || d > 0.0);
+    ip = bad ? st.ip_exc : ip;
+    excmask |= bad ? (1u << j) : 0u;
+}
+
+// pairs P .. of step J: a(r, c) -= L(r, J) L(c, J) for the lane's slots.  Slots whose column is already final are dead
+// registers in this routine: they are updated along with the others (no predicate).
+template <int J, int P>
+__device__ __forceinline__ void f_pairs(double (&a)[HB], double l, const ColBcast& cb)
+{
+    if constexpr (P < HB / 2) {
+        if constexpr (2 * P >= first_live_slot(J)) {
+            a[2 * P] = __builtin_fma(-l, cb.v[P].x, a[2 * P]);
+            pin(a[2 * P]);
+        }
+        if constexpr (2 * P + 1 >= first_live_slot(J)) {
+            a[2 * P + 1] = __builtin_fma(-l, cb.v[P].y, a[2 * P + 1]);
+            pin(a[2 * P + 1]);
+        }
+        f_pairs<J, P + 1>(a, l, cb);
     }
-    if (info[0] == 0) info[0] = 1 + col;
-    p = __builtin_nan("");
-    ip = p;
+}
+
+// one elimination step; J is a compile-time constant so that every register index and lane select is static
+// (template recursion instead of `#pragma unroll`: the body is beyond clang's pragma-unroll budget).
+// d = the diagonal value of column J, ip = its reciprocal pivot after the pivot rule.
+template <bool M3, int J>
+__device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double d, double ip, unsigned& excmask)
+{
+    constexpr int hJ = J / HB, kJ = J % HB;
+    constexpr int hN = (J + 1) / HB, kN = (J + 1) % HB;
+    constexpr int NST = ChainShape<M3>::NST;
+    constexpr bool next = J + 1 < SB;
+    // ---- critical path first: column J scaled by the reciprocal pivot, the next diagonal value, the head of its chain.
+    // The next diagonal value needs no broadcast: its lane multiplies by its own L(J + 1, J).
+    const double v = a[kJ];
+    const double q = M3 ? v : v * ip;
+    PivotChain ch;
+    if constexpr (next && hN == hJ) {
+        double dn = a[kN];
+        if constexpr (!M3) dn = __builtin_fma(-q, q, dn);
+        ch.d = readlane_f64(dn, (J + 1) + SB * hN);  // next pivot candidate (uniform)
+        chain_stage<M3, 0>(ch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- L(r, J) in both halves.  Padding rows / columns (block smaller than 128) are forced to stay the identity:
+    // 0 * inf = NaN would otherwise leak from an overflowing substituted factor into the log
+    const bool live = st.row_ok && J < st.ncols_ok;
+    const double l_own = (st.r > J && live) ? q : 0.0;
+    const double l = bcast_half<hJ>(l_own);
+    if constexpr (next && hN != hJ) {  // the pivot lane sits in the other half (J = 15): it needs the exchange first
+        double dn = a[kN];
+        if constexpr (!M3) dn = __builtin_fma(-l, l, dn);
+        ch.d = readlane_f64(dn, (J + 1) + SB * hN);
+        chain_stage<M3, 0>(ch);
+    }
+    if constexpr (next && 1 < NST) chain_stage<M3, 1>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the LDS image of column J (owner half): 1 / pivot on the diagonal, L below, zeros above; then the counter
+    if (st.h == hJ) {
+        st.cptr[SB * J] = (st.r == J) ? ip : l_own;
+        *st.flag = st.flag_base + J + 1;  // after the column in this wave's LDS order: the solves of P1 may consume it
+    }
+    if constexpr (next && 2 < NST) chain_stage<M3, 2>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    ColBcast cb;
+    if constexpr (!M3) col_load<J, 0>(cb, st.bufh);
+    if constexpr (next && 3 < NST) chain_stage<M3, 3>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- off the chain: the diagonal entry sqrt(d) = d ip with one Heron correction, and the column to global memory
+    if constexpr (!M3) {
+        double pq = d * ip;
+        if constexpr (next && 4 < NST) chain_stage<M3, 4>(ch);
+        __builtin_amdgcn_sched_barrier(0);
+        const double pe = __builtin_fma(-pq, pq, d);
+        if constexpr (next && 5 < NST) chain_stage<M3, 5>(ch);
+        __builtin_amdgcn_sched_barrier(0);
+        pq = __builtin_fma(0.5 * ip, pe, pq);
+        pq = (d == 0.0) ? 0.0 : pq;                            // plain-sqrt mode, d == 0
+        pq = ((excmask >> J) & 1u) ? st.p_exc : pq;            // substituted / failed pivot
+        if (st.h == hJ && st.r >= J && live) *st.gptr = (st.r == J) ? pq : q;
+        st.gptr += st.lda;
+        if constexpr (next && 6 < NST) chain_stage<M3, 6>(ch);
+        if constexpr (next && 7 < NST) chain_stage<M3, 7>(ch);
+        __builtin_amdgcn_sched_barrier(0);
+        f_pairs<J, 0>(a, l, cb);
+    } else {
+        if constexpr (next && 4 < NST) chain_stage<M3, 4>(ch);
+    }
+    if constexpr (next) {
+        double ipn = ch.r;
+        if constexpr (!M3) pivot_select(st, ch.d, J + 1, ipn, excmask);
+        f_step<M3, J + 1>(a, st, ch.d, ipn, excmask);
+    }
+}
+
+template <bool M3>
+__device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, double* __restrict__ A, int64_t lda, int n,
+                                                int64_t col0, int mode, double sub, int64_t* __restrict__ info)
+{
+    FState st;
+    st.flag = reinterpret_cast<int*>(lds + NSLOT * SBE);
+    st.flag_base = SB * b;
+    st.lane = lane;
+    st.r = lane & (SB - 1);
+    st.h = lane >> 5;
+    double* image = lds + slot_of(b, b);
+    st.cptr = image + st.r;
+    st.bufh = image + HB * st.h;
+    st.gptr = A + (SB * b + st.r) + (int64_t)(SB * b) * lda;
+    st.row_ok = SB * b + st.r < n;
+    st.ncols_ok = n - SB * b;
+    st.lda = lda;
+    st.colbase = col0 + SB * b;
+    st.mode = mode;
+    st.p_exc = __builtin_nan("");
+    st.ip_exc = st.p_exc;
+    const bool substitute = (mode == 1 && sub > 0.0);
+    if (substitute) sqrt_rsqrt(sub, st.p_exc, st.ip_exc);
+    double a[HB];
+#pragma unroll
+    for (int k = 0; k < HB; ++k) a[k] = image[st.r + SB * (HB * st.h + k)];
+    // first pivot
+    unsigned excmask = 0;
+    const double d0 = readlane_f64(a[0], 0);
+    double ip;
+    if constexpr (M3) {
+        ip = 1.0 / d0;
+    } else {
+        double p;
+        sqrt_rsqrt(d0, p, ip);
+        pivot_select(st, d0, 0, ip, excmask);
+    }
+    f_step<M3, 0>(a, st, d0, ip, excmask);
+    if (st.ncols_ok < SB) excmask &= (1u << (st.ncols_ok > 0 ? st.ncols_ok : 0)) - 1u;
+    if (excmask != 0 && lane == 0) {  // the log: substituted columns in order, or the first failing column
+        if (substitute) {
+            int64_t q = info[1];
+            for (int j = 0; j < SB; ++j)
+                if (excmask & (1u << j)) info[3 + q++] = st.colbase + j;
+            info[1] = q;
+        } else if (info[0] == 0) {
+            info[0] = 1 + st.colbase + (__builtin_ffs((int)excmask) - 1);
+        }
+    }
+}
+
+// ---- triangular solve against the LDS image of L_bb (one wave, 32 vectors of 32, split-row layout) -------------------
+// x <- solution of  L y = x  (forward substitution, right-looking):  y[J] = x[J] / L(J, J);  x[c] -= y[J] L(c, J), c > J.
+// Used for T (x = a row of A_ib: the row of L_ib is y) and for X_bb (x = e_c: y is column c of L_bb^-1).  Here the slots
+// of finished columns hold results, so a slot is updated only where 16 h + k > J (two multipliers per step).  The
+// broadcasts of column J + 1 are issued while column J is applied (the image is read-only in this phase).
+// The solves run CONCURRENTLY with F_b on other waves: they consume column J of the image as soon as the panel wave has
+// published it (LDS counter, polled), one step behind the pivot chain, and finish a step after it.
+// `avail` caches the last value seen: a solve that has fallen behind the pivot chain does not touch the counter again
+// until it has caught up (next to a GEMM workgroup an LDS round trip costs ~900 cycles).
+__device__ __forceinline__ void wait_columns(const int* flag, int target, int& avail)
+{
+    while (avail < target) {
+        avail = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(flag));
+        if (avail < target) __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void trsm_step(double (&x)[HB], const double* bufh, int h, const ColBcast& cb, double ipj,
+                                          const int* flag, int flag_base, int& avail)
+{
+    constexpr int hJ = J / HB, kJ = J % HB;
+    ColBcast nx;
+    double ipn = 0.0;
+    if constexpr (J + 1 < SB) {
+        wait_columns(flag, flag_base + J + 2, avail);
+        col_load<J + 1, 0>(nx, bufh);
+        ipn = bufh[(J + 1) + SB * (J + 1) - HB * h];  // image[(J+1) + 32 (J+1)], uniform
+    }
+    const double y_own = x[kJ] * ipj;
+    x[kJ] = (h == hJ) ? y_own : x[kJ];
+    pin(x[kJ]);
+    const double y = bcast_half<hJ>(y_own);
+    const double m_ge = (hJ == 0) ? y : ((h == 1) ? y : 0.0);  // halves h >= hJ
+    const double m_gt = (h == 1) ? y : 0.0;                    // halves h >  hJ (only when hJ == 0)
+#pragma unroll
+    for (int k = 0; k < HB; ++k) {
+        const double lv = (k & 1) ? cb.v[k >> 1].y : cb.v[k >> 1].x;
+        if (k > kJ) {
+            x[k] = __builtin_fma(-m_ge, lv, x[k]);
+            pin(x[k]);
+        } else if (hJ == 0) {
+            x[k] = __builtin_fma(-m_gt, lv, x[k]);
+            pin(x[k]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (J + 1 < SB) trsm_step<J + 1>(x, bufh, h, nx, ipn, flag, flag_base, avail);
+}
+
+__device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, int h, const int* flag, int flag_base)
+{
+    const double* bufh = image + HB * h;
+    ColBcast cb;
+    int avail = 0;
+    wait_columns(flag, flag_base + 1, avail);
+    col_load<0, 0>(cb, bufh);
+    const double ip0 = image[0];
+    trsm_step<0>(x, bufh, h, cb, ip0, flag, flag_base, avail);
 }
 
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
                                                    int64_t* __restrict__ info)
 {
-    // Lc[x]      : L(x, j), the scaled column j (x > j)                          -- the row multiplier of the step
-    // Vc[c]      : L(c, j) for c > j (0 in mode 3: no factor update), Vc[PB + c] : X(j, c) for c < j (0 for c >= j)
-    // so that the update of element (i, c) is  a -= Lc[i] * Vc[c > j ? c : PB + c]  with no per-element predicate.
-    __shared__ double Lc[PB];
-    __shared__ double Vc[2 * PB];
-    __shared__ __attribute__((aligned(16))) double piv[2];  // {pivot, 1/pivot} of the current step
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int t = threadIdx.x;
-    const int i = t & (PB - 1);
-    const int cg = t >> 7;  // 4 column groups of 128 threads (two waves): cg is wave-uniform
-    const bool row_ok = i < n;
-    const int wave_row0 = i & 64;  // first row held by this wave
+    const int lane = t & 63;
+    const int w = t >> 6;  // wave, uniform
+    const int r = lane & (SB - 1);
+    const int h = lane >> 5;
+    const int nblk = (n + SB - 1) / SB;
+    const bool want_inv = inv != nullptr;
+    const bool m3 = (mode == 3);
 
-    double a[PE];  // working element (i, cg + 4k): A, then (once column c is done) the inverse X
+    // ---- load the lower triangle into the LDS slots; rows / columns >= n are padded with the identity.  All 20 loads
+    //      of a thread are issued before the first LDS write (one memory round trip, not ten)
+    {
+        const int cg = t >> 5;  // 16 column groups, 2 columns each per slot
+        double v[2 * NSLOT];
 #pragma unroll
-    for (int k = 0; k < PE; ++k) {
-        const int c = cg + PG * k;
-        a[k] = (row_ok && c < n && i >= c) ? A[i + (int64_t)c * lda] : 0.0;
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int i = (sl >= 6) ? 3 : ((sl >= 3) ? 2 : ((sl >= 1) ? 1 : 0));
+            const int k = sl - i * (i + 1) / 2;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int gr = SB * i + r, gc = SB * k + cg * 2 + cc;
+                double x = (gr == gc) ? 1.0 : 0.0;
+                if (gr < n && gc < n && gr >= gc) x = A[gr + (int64_t)gc * lda];
+                if (gr < n && gc < n && gr < gc) x = 0.0;
+                v[2 * sl + cc] = x;
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int i = (sl >= 6) ? 3 : ((sl >= 3) ? 2 : ((sl >= 1) ? 1 : 0));
+            if (i < nblk) {
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) lds[sl * SBE + r + SB * (cg * 2 + cc)] = v[2 * sl + cc];
+            }
+        }
     }
-    if (t == 0) {
-        double p0, ip0;
-        pivot_of(a[0], mode, sub, col0, info, p0, ip0);
-        piv[0] = p0;
-        piv[1] = ip0;
-    }
+    int* colflag = reinterpret_cast<int*>(lds + NSLOT * SBE);
+    if (t == 0) *colflag = 0;
     lds_barrier();
-    const long long tc0 = __builtin_amdgcn_s_memtime();
-    for (int j = 0; j < n; ++j) {
-        const int jcg = j & (PG - 1), jk = j / PG;
-        // ---- phase 1: owners of column j / row j scale and publish (sqrt and reciprocal were computed by ONE thread
-        //      at the end of the previous step)
-        const double p = piv[0], ip = piv[1];
-        if (cg == jcg && i >= j && row_ok) {  // the threads holding column j
-#pragma unroll
-            for (int k = 0; k < PE; ++k) {
-                if (k == jk) {  // uniform: exactly one of the 16 statically indexed bodies runs
-                    const double v = a[k];
-                    // col /= denom: quotient by reciprocal + one residual correction (== IEEE division except for rare
-                    // last-bit ties); the reciprocal is already on hand, a full division is ~35 dependent instructions
-                    double q = v * ip;
-                    q = __builtin_fma(__builtin_fma(-q, p, v), ip, q);
-                    q = (mode == 3) ? v : q;
-                    const bool diag = (i == j);
-                    const double lv = diag ? p : q;  // L(i, j)
-                    Lc[i] = lv;
-                    Vc[i] = (mode == 3) ? 0.0 : lv;
-                    if (mode != 3) A[i + (int64_t)j * lda] = lv;  // fire and forget: the barriers wait on LDS only
-                    a[k] = diag ? ip : -q * ip;  // X(i, j): 1/p on the diagonal, else 0 - L(i,j) X(j,j)
-                }
-            }
+
+    // Per stage b (barriers between the phases):
+    //   P1  wave 0: F_b, the serial pivot chain; concurrently, one step behind it (column counter in LDS):
+    //       T: L_ib = A_ib L_bb^-T (one wave per sub-block below)  |  X_bb (one wave)  |  (1): W_bc = L_bb^-1 W_bc, c < b
+    //       -- all three are the same triangular solve against the image of L_bb, on rows of A_ib, on e_c, on columns of W_bc
+    //   P2  X_bb replaces the image  |  U: A_ik -= L_ib L_kb^T  |  (2): W_ic -= L_ib W_bc      (MFMA 16x16 tiles, all waves)
+    //   P3  (3): W_ib = -L_ib X_bb, in place over the now dead L_ib (one wave per sub-block)
+    // The inverse sub-blocks are kept TRANSPOSED in LDS (WT_ic[y + 32 x] = W_ic(x, y)): it makes every product an
+    // "N T" contraction whose two operand fragments and whose result tile are contiguous along the 16 lanes of an MFMA
+    // register, and it is the layout in which a lane pair of the solve naturally stores its column of X_bb.
+    // Wave 0 runs only F_b and the barriers (its own branch keeps the unrolled pivot chain free of the update phases'
+    // register pressure); waves 1..7 are the update waves.
+    if (w == 0) {
+        // the pivot chain is the critical path of the whole factorisation and shares its SIMD with a GEMM wave of the
+        // co-resident trailing update: take the issue slot whenever both are ready
+        __builtin_amdgcn_s_setprio(3);
+        for (int b = 0; b < nblk; ++b) {
+            if (m3)
+                factor_subblock<true>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+            else
+                factor_subblock<false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+            lds_barrier();
+            lds_barrier();
+            lds_barrier();
         }
-        if (i == j) {  // the 4 threads holding row j: scale and publish X(j, c), c < j
+    } else {
+    const int u = w - 1;
+    for (int b = 0; b < nblk; ++b) {
+        double* Lbb = lds + slot_of(b, b);  // image of L_bb (1 / pivot on the diagonal), later XT_bb
+
+        // ---- P1
+        double xs[HB];
+        const bool do_x = (u == 3) && want_inv;
+        {
+            const int it = b + 1 + u;            // update waves 0..2: T on sub-block it
+            const int c1 = u - 4;                // update waves 4..6: (1) on W_b,c1
+            const bool do_t = (u < 3) && !m3 && (it < nblk);
+            const bool do_1 = (u >= 4) && want_inv && (c1 < b);
+            double* S = lds + (do_t ? slot_of(it, b) : (do_1 ? slot_of(b, c1) : 0));
+            if (do_t || do_x || do_1) {
+                double one = 1.0;
+                pin(one);  // not loop-invariant for the compiler: it would hoist e_c out of the stage loop and spill it
 #pragma unroll
-            for (int k = 0; k < PE; ++k) {
-                const int c = cg + PG * k;
-                const double sc = a[k] * ip;
-                const bool lt = c < j;
-                a[k] = lt ? sc : a[k];
-                Vc[PB + c] = lt ? sc : 0.0;  // zero for c >= j: the update of column j itself must be a no-op
+                for (int k = 0; k < HB; ++k) {
+                    // T: row r of A_ib (normal layout);  (1): column r of W_bc (transposed layout: same addresses);  X: e_r
+                    const double v = S[r + SB * (HB * h + k)];
+                    xs[k] = do_x ? ((HB * h + k == r) ? one : 0.0) : v;
+                }
+                trsm_fwd(xs, Lbb, h, colflag, SB * b);
+            }
+            if (do_t || do_1) {
+                const int gr = SB * it + r;
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    S[r + SB * (HB * h + k)] = xs[k];
+                    const int gc = SB * b + HB * h + k;
+                    if (do_t && gr < n && gc < n) A[gr + (int64_t)gc * lda] = xs[k];
+                }
             }
         }
         lds_barrier();
-        // ---- phase 2: a(i, c) -= L(i, j) * (c > j ? L(c, j) : X(j, c)).  One LDS read + one FMA per element; waves whose
-        //      rows are all finished skip it (the block is VALU-throughput bound: 1024 threads x 16 elements per step)
-        if (wave_row0 + 63 > j) {
-            const bool act = (i > j) && row_ok;
-            const double lraw = Lc[i];
-            const double lij = act ? lraw : 0.0;
-            if (act && i == j + 1 && cg == ((j + 1) & (PG - 1))) {
-                // owner of the next diagonal element: take the next pivot now; the other waves overlap it with their
-                // 16 updates
-                const int nk = (j + 1) / PG;
-                double nd = 0.0;
+
+        // ---- P2
+        if (do_x) {
+            // lane pair (c, h) holds X(16 h + k, c): stored transposed, conflict-free
 #pragma unroll
-                for (int k = 0; k < PE; ++k)
-                    if (k == nk) nd = a[k];
-                if (mode != 3) nd = nd - lij * lij;
-                double pn, ipn;
-                pivot_of(nd, mode, sub, col0 + j + 1, info, pn, ipn);
-                piv[0] = pn;
-                piv[1] = ipn;
-            }
-            // two batches of 16: all LDS reads of a batch first, then its FMAs (keeps the kernel under 128 VGPRs so that
-            // 8 waves fit next to one resident GEMM workgroup: 512 - 240 = 272 registers per SIMD lane)
+            for (int k = 0; k < HB; ++k) Lbb[r + SB * (HB * h + k)] = xs[k];
+        }
+        {
+            const int rem = nblk - b - 1;
+            const int nU = m3 ? 0 : rem * (rem + 1) / 2;
+            const int n2 = want_inv ? rem * b : 0;
+            const int l15 = lane & 15, lq = lane >> 4;
+            // Every wave takes its tile tasks four at a time (independent accumulator chains): next to a GEMM workgroup a
+            // wave gets the matrix core in turns, and a turn takes whatever is ready.  Update wave 3 joins after its
+            // store: the task list is dealt to the other waves first.
+            const int ntask = 4 * (nU + n2);
+            for (int task0 = (u + 3) % 7; task0 < ntask; task0 += 28) {
+                d4_t acc[4];
+                const double* Pp[4];
+                const double* Qp[4];
+                double* Cp[4];
+                bool tr[4], on[4];
 #pragma unroll
-            for (int k0 = 0; k0 < PE; k0 += 16) {
-                double vc[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int c = cg + PG * (k0 + k);
-                    vc[k] = Vc[c + ((c > j) ? 0 : PB)];
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int task = task0 + 7 * s4;
+                    on[s4] = task < ntask;
+                    const int pidx = on[s4] ? (task >> 2) : 0;
+                    const int tx = (task >> 1) & 1, ty = task & 1;
+                    acc[s4] = d4_t{0.0, 0.0, 0.0, 0.0};
+                    if (pidx < nU) {
+                        // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b:  C[x + 32 y] (x along the lanes)
+                        const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
+                        const int rk = pidx - ri * (ri - 1) / 2 + 1;
+                        tr[s4] = false;
+                        Pp[s4] = lds + slot_of(b + ri, b) + HB * tx + l15 + SB * lq;
+                        Qp[s4] = lds + slot_of(b + rk, b) + HB * ty + l15 + SB * lq;
+                        Cp[s4] = lds + slot_of(b + ri, b + rk) + (HB * tx + l15) + SB * (HB * ty + lq);
+                    } else {
+                        // (2): WT_i,cb[y + 32 x] (y along the lanes) -= L_ib WT_b,cb
+                        const int q = pidx - nU;
+                        const int bb = b > 0 ? b : 1;
+                        const int i = b + 1 + q / bb, cb = q % bb;
+                        tr[s4] = true;
+                        Pp[s4] = lds + slot_of(i, b) + HB * tx + l15 + SB * lq;
+                        Qp[s4] = lds + slot_of(b, cb) + HB * ty + l15 + SB * lq;
+                        Cp[s4] = lds + slot_of(i, cb) + (HB * ty + l15) + SB * (HB * tx + lq);
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < 16; ++k) a[k0 + k] = __builtin_fma(-lij, vc[k], a[k0 + k]);
+                for (int kk = 0; kk < SB / 4; ++kk) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        if (on[s4]) {
+                            const double pf = Pp[s4][SB * 4 * kk];
+                            const double qf = Qp[s4][SB * 4 * kk];
+                            // result index of the FIRST operand runs over lq + 4 reg, of the SECOND over the lanes
+                            acc[s4] = tr[s4] ? __builtin_amdgcn_mfma_f64_16x16x4f64(pf, qf, acc[s4], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f64_16x16x4f64(qf, pf, acc[s4], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (on[s4]) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) Cp[s4][SB * 4 * reg] -= acc[s4][reg];
+                    }
+                }
             }
+        }
+        lds_barrier();
+
+        // ---- P3
+        if (want_inv && u < 3 && b + 1 + u < nblk) {
+            const int l15 = lane & 15, lq = lane >> 4;
+            double* Wib = lds + slot_of(b + 1 + u, b);  // L_ib (normal) in, WT_ib out
+            d4_t acc[2][2];
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty) acc[tx][ty] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < SB / 4; ++kk) {
+                double pf[2], qf[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    pf[tt] = Wib[(HB * tt + l15) + SB * (4 * kk + lq)];
+                    qf[tt] = Lbb[(HB * tt + l15) + SB * (4 * kk + lq)];  // XT_bb
+                }
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                    for (int ty = 0; ty < 2; ++ty)
+                        acc[tx][ty] = __builtin_amdgcn_mfma_f64_16x16x4f64(pf[tx], qf[ty], acc[tx][ty], 0, 0, 0);
+            }
+            // every read of L_ib is behind us (one wave, program order): overwrite it with -(...) transposed
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        Wib[(HB * ty + l15) + SB * (HB * tx + lq + 4 * reg)] = -acc[tx][ty][reg];
         }
         lds_barrier();
     }
+    }
 
+    // ---- store the inverse: the LDS sub-blocks are transposed (zeros above the diagonal)
+    if (want_inv) {
+        const int cg = t >> 5;
+        for (int i = 0; i < nblk; ++i)
+            for (int k = 0; k < nblk; ++k) {
+                const double* s = lds + slot_of(i, k <= i ? k : 0);
 #pragma unroll
-    for (int k = 0; k < PE; ++k) {
-        const int c = cg + PG * k;
-        if (row_ok && c < n && i >= c) {
-            if (inv) inv[i + (int64_t)c * ldinv] = a[k];
-        } else if (row_ok && c < n && inv) {
-            inv[i + (int64_t)c * ldinv] = 0.0;
-        }
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int c = cg * 2 + cc;
+                    const int gr = SB * i + r, gc = SB * k + c;
+                    if (gr < n && gc < n) inv[gr + (int64_t)gc * ldinv] = (k <= i) ? s[c + SB * r] : 0.0;
+                }
+            }
     }
 }
 
