@@ -129,6 +129,28 @@ def test_sharded_fit_predict_queries_split():
     assert rel_err(got, want) < TOL
 
 
+def test_sharded_default_block_size():
+    # no explicit nb: the library's choice for sharded runs (512-column panels dealt round-robin)
+    n, world = 1800, 3
+    k = ("squared_exp", 0.9, 1.1)
+    X = rand_inputs(n, 4, 77)
+    _, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    Xq = rand_inputs(300, 4, 78)
+    y = np.sin(X.sum(axis=1))
+    gp = O.OracleGP(O.ZeroPrior(), k, 0.1, None, X, y)
+
+    def fn(ctx, rank):
+        chol = ctx.cholesky_from_inputs(k, X, 0.1)
+        out = (chol.l(), chol.predict_mean(k, y, Xq, None), chol.predict_variance(k, Xq))
+        chol.free()
+        return out
+
+    for L, mean, var in run_ranks(world, fn):
+        assert rel_err(L, np.tril(L_o)) < TOL
+        assert rel_err(mean, gp.predict(Xq)) < 1e-8
+        assert np.max(np.abs(var - gp.predict_variance(Xq))) < 1e-8
+
+
 def test_local_transport_selftest():
     def fn(ctx, rank):
         ctx.comm_selftest()
