@@ -237,7 +237,7 @@ def main():
                 "flops_per_launch": syrk["flops"] / max(syrk["launches"], 1),
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, d, 256, cfg)
         print(json.dumps(out), flush=True)
 
