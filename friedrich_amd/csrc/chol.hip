@@ -267,7 +267,7 @@ static int ensure_inv512(fr_ctx* ctx, const fr_chol* cc, int cls)
         c->inv512 = nullptr;
         c->inv512_cap = 0;
         const int64_t cap = imax(nq, c->capacity / LB);
-        FR_HIP(ctx, hipMalloc(&c->inv512, sizeof(double) * (size_t)cap * LB * LB));
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->inv512, sizeof(double) * (size_t)cap * LB * LB));
         c->inv512_cap = cap;
     }
     const int64_t ld = c->ld_a;
@@ -466,10 +466,10 @@ static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t
     c->d = d;
     const int64_t nblk = (c->capacity + IB - 1) / IB;
     c->info_cap = 3 + c->capacity;
-    hipError_t e = hipMalloc((void**)&c->A, sizeof(double) * (size_t)c->ld_a * (size_t)c->capacity);
-    if (e == hipSuccess && d > 0) e = hipMalloc((void**)&c->X, sizeof(double) * (size_t)c->ld_x * (size_t)d);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->dinv, sizeof(double) * (size_t)nblk * INV_ELEMS);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->info, sizeof(int64_t) * (size_t)c->info_cap);
+    hipError_t e = dev_malloc(ctx, (void**)&c->A, sizeof(double) * (size_t)c->ld_a * (size_t)c->capacity);
+    if (e == hipSuccess && d > 0) e = dev_malloc(ctx, (void**)&c->X, sizeof(double) * (size_t)c->ld_x * (size_t)d);
+    if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->dinv, sizeof(double) * (size_t)nblk * INV_ELEMS);
+    if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->info, sizeof(int64_t) * (size_t)c->info_cap);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         chol_release(c);
@@ -652,6 +652,8 @@ using namespace fr;
 
 extern "C" {
 
+static int check_zero_diag(fr_chol* c, const char* what);
+
 int fr_chol_from_inputs(fr_ctx* ctx, const fr_kprog* kernel, const double* X, int64_t n, int64_t ldx, int64_t d,
                         double noise, int has_eps, double eps, int64_t capacity_hint, fr_chol** out)
 {
@@ -726,6 +728,13 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     if (d != c->d) return set_err(ctx, FR_SHAPE, "add_rows: feature count %lld != %lld", (long long)d, (long long)c->d);
     if (ldx < imax(n_all, 1)) return set_err(ctx, FR_SHAPE, "add_rows: bad leading dimension");
     if (nb_new == 0) return FR_OK;
+    if (c->fail_col >= 0)
+        return set_err(ctx, FR_NOT_POSITIVE_DEFINITE, "add_rows: the factor is not valid (its factorisation failed at column %lld)",
+                       (long long)c->fail_col);
+    // Cholesky::insert_column solves L11 r = col with the CHECKED solve and asserts on a zero diagonal
+    // ("Unable to solve lower triangular system!", nalgebra cholesky.rs); the explicit-inverse solve below would write
+    // inf / NaN silently instead
+    if (n_old > 0) FR_TRY(check_zero_diag(c, "Cholesky::insert_column: Unable to solve lower triangular system!"));
     // (the cached 512-block inverses stay valid: rows below n_old are appended, blocks inside the old factor do not change)
     FR_TRY(chol_grow(c, n_all));
     c->nb = pick_nb(ctx, n_all);

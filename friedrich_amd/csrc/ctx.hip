@@ -28,6 +28,39 @@ bool is_device_ptr(const void* p)
     return a.type == hipMemoryTypeDevice;
 }
 
+// Release every idle buffer of the workspace pool (after fr_grad_terms or a wide predict tens of GB can sit there).
+size_t ws_trim(fr_ctx* ctx)
+{
+    size_t freed = 0;
+    bool synced = false;
+    for (auto& b : ctx->pool)
+        if (!b.in_use && b.p) {
+            if (!synced) {  // stream-ordered reuse: the last kernels that touched the buffers must be done
+                (void)hipStreamSynchronize(ctx->stream);
+                if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+                synced = true;
+            }
+            (void)hipFree(b.p);
+            freed += b.cap;
+            b.p = nullptr;
+            b.cap = 0;
+        }
+    return freed;
+}
+
+// hipMalloc that retries once after trimming the pool: used for EVERY device allocation of the library, so that a factor
+// (or its growth) never fails with FR_OUT_OF_MEMORY while idle workspaces hold the memory
+hipError_t dev_malloc(fr_ctx* ctx, void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    if (ws_trim(ctx) == 0) return e;
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
+
 void* ws_get(fr_ctx* ctx, size_t bytes)
 {
     if (bytes == 0) bytes = 8;
@@ -41,25 +74,13 @@ void* ws_get(fr_ctx* ctx, size_t bytes)
         ctx->pool[best].in_use = true;
         return ctx->pool[best].p;
     }
-    // drop the largest unused buffers if memory is tight; otherwise allocate fresh
+    // allocate fresh; when memory is tight the idle buffers of the pool are released first
     void* p = nullptr;
     size_t cap = (bytes + 255) & ~size_t(255);
-    hipError_t e = hipMalloc(&p, cap);
+    hipError_t e = dev_malloc(ctx, &p, cap);
     if (e != hipSuccess) {
-        (void)hipGetLastError();
-        for (auto& b : ctx->pool)
-            if (!b.in_use && b.p) {
-                (void)hipStreamSynchronize(ctx->stream);
-                (void)hipFree(b.p);
-                b.p = nullptr;
-                b.cap = 0;
-            }
-        e = hipMalloc(&p, cap);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            set_err(ctx, FR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
-            return nullptr;
-        }
+        set_err(ctx, FR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        return nullptr;
     }
     DevBuf nb;
     nb.p = p;

@@ -130,6 +130,8 @@ bool is_device_ptr(const void* p);
 // workspace: returns nullptr on failure (error recorded in ctx)
 void* ws_get(fr_ctx* ctx, size_t bytes);
 void ws_put(fr_ctx* ctx, void* p);
+size_t ws_trim(fr_ctx* ctx);                                   // frees the idle pool buffers, returns the bytes released
+hipError_t dev_malloc(fr_ctx* ctx, void** p, size_t bytes);    // hipMalloc, retried once after ws_trim
 
 struct WsGuard {
     fr_ctx* ctx;

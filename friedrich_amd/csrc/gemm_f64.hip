@@ -521,7 +521,22 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     else
         g.nsuper = 0;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
-    const double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
+    double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
+    if (d.own_world > 1) {
+        // multi-GPU ownership filter: this rank computes only the tile columns it owns (same test as the kernel), so
+        // the profile must credit only those -- otherwise every rank's TFLOP/s reads ~world times too high
+        double own_flops = 0.0, own_c = 0.0;
+        for (int64_t tn = 0; tn < g.tiles_n; ++tn) {
+            const int64_t n0 = tn * BN;
+            if ((int)(((d.own_col0 + n0) / g.own_nb) % d.own_world) != d.own_rank) continue;
+            const double cols = (double)((n0 + BN <= d.N) ? BN : d.N - n0);
+            const double rows = d.lower ? (double)(d.M - n0) : (double)d.M;  // lower mode: rows from the diagonal tile down
+            own_flops += 2.0 * rows * cols * (double)g.K;
+            own_c += rows * cols;
+        }
+        flops = own_flops;
+        bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + 2.0 * own_c);
+    }
     const double nbatch = d.batch > 1 ? (double)d.batch : 1.0;
     ProfScope ps(ctx, d.prof_cls, flops * nbatch, bytes * nbatch);
     g.batch_a = d.batch_a;

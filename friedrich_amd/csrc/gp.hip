@@ -38,7 +38,11 @@ struct QueryCtx {
     }
 };
 
-static int stage_vec_in(fr_ctx* ctx, Staged& s, const double* v, int64_t n) { return s.in(v, n, 1, n > 0 ? n : 1); }
+static int stage_vec_in(fr_ctx* ctx, Staged& s, const double* v, int64_t n)
+{
+    if (n > 0 && !v) return set_err(ctx, FR_INVALID_ARGUMENT, "null training-output vector (y) for a factor of %lld rows", (long long)n);
+    return s.in(v, n, 1, n > 0 ? n : 1);
+}
 static int stage_vec_out(fr_ctx* ctx, Staged& s, double* v, int64_t n) { return s.out(v, n, 1, n > 0 ? n : 1); }
 
 // out = prior_q (or zeros)
@@ -79,6 +83,7 @@ int fr_likelihood(fr_chol* c, const fr_kprog* kernel, const double* y, double no
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));
     const int64_t n = c->n;
+    if (n > 0 && !y) return set_err(ctx, FR_INVALID_ARGUMENT, "null training-output vector (y)");
     FR_TRY(zero_diag_status(c, "likelihood"));  // mod.rs:203
     WsGuard w(ctx);
     const int64_t ld = round_up(n > 0 ? n : 1, kAlign);

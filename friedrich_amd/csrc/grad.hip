@@ -295,6 +295,7 @@ extern "C" int fr_grad_terms(fr_chol* c, const fr_kprog* kernel, const double* y
         if (out_scale) *out_scale = std::nan("");
         return FR_OK;
     }
+    if (!y) return set_err(ctx, FR_INVALID_ARGUMENT, "null training-output vector (y)");
     const int64_t ld = round_up(n, kAlign);
     WsGuard wg(ctx), kg(ctx), vg(ctx), pg(ctx);
     double* W = wg.get(sizeof(double) * (size_t)ld * (size_t)n);

@@ -18,8 +18,10 @@
  *    turns the status back into the reference's panic text.
  *  - Work is enqueued on the context's HIP stream; functions that return host results synchronise that
  *    stream before returning, functions that only touch device memory do not.
- *  - A fr_chol may be read concurrently (predict family) from several host threads only through distinct
- *    contexts created with fr_ctx_create on the same device; mutation (add_rows, refactor) is exclusive.
+ *  - Thread safety: every entry point takes its context's lock, so any number of host threads may call into one
+ *    context / one fr_chol concurrently (friedrich's GaussianProcess is Send + Sync: concurrent &self predicts are
+ *    legal); the calls of one context take turns on its streams and workspaces.  Handles of different contexts are
+ *    independent and run in parallel.
  */
 #ifndef FRIEDRICH_AMD_H
 #define FRIEDRICH_AMD_H

@@ -14,10 +14,74 @@
 #include "friedrich_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define AT(M, ld, r, c) ((M)[(int64_t)(r) + (int64_t)(c) * (int64_t)(ld)])
+
+/* ------------------------------------------------------------------------------------------ */
+/* host threads (NOT part of the reference, which is single-threaded)                          */
+/* Loops whose iterations are independent in the reference -- the right-hand-side columns of a solve, the entries of a
+ * Gram matrix, the rows of an axpy -- may be dealt to host threads so that full-size BASELINE configurations can be
+ * checked in seconds.  Every element still sees exactly the reference's sequence of operations, so results are
+ * bit-identical to the single-thread restatement (tests/test_oracle.py asserts equality, not closeness). */
+static int g_threads = 1;
+
+void fro_set_threads(int n)
+{
+    if (n <= 0) {
+        long c = sysconf(_SC_NPROCESSORS_ONLN);
+        n = (int)(c > 0 ? c : 1);
+    }
+    if (n > 64) n = 64;
+    g_threads = n;
+}
+
+int fro_get_threads(void) { return g_threads; }
+
+typedef void (*par_body)(int64_t lo, int64_t hi, void* arg);
+typedef struct {
+    par_body fn;
+    void* arg;
+    int64_t lo, hi;
+} par_task;
+
+static void* par_tramp(void* q)
+{
+    par_task* t = (par_task*)q;
+    t->fn(t->lo, t->hi, t->arg);
+    return NULL;
+}
+
+/* fn over [0, n) cut into contiguous ranges, one per thread (the calling thread takes the first) */
+static void par_for(int64_t n, par_body fn, void* arg)
+{
+    int T = g_threads;
+    if (T > n) T = (int)(n > 0 ? n : 1);
+    if (T <= 1) {
+        fn(0, n, arg);
+        return;
+    }
+    pthread_t th[64];
+    par_task task[64];
+    for (int t = 0; t < T; ++t) {
+        task[t].fn = fn;
+        task[t].arg = arg;
+        task[t].lo = n * t / T;
+        task[t].hi = n * (t + 1) / T;
+    }
+    int started[64] = {0};
+    for (int t = 1; t < T; ++t) started[t] = pthread_create(&th[t], NULL, par_tramp, &task[t]) == 0;
+    par_tramp(&task[0]);
+    for (int t = 1; t < T; ++t) {
+        if (started[t])
+            pthread_join(th[t], NULL);
+        else
+            par_tramp(&task[t]);
+    }
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* small nalgebra primitives                                                                   */
@@ -484,11 +548,26 @@ void fro_heuristic_fit(fro_kprog* p, const double* X, int64_t n, int64_t ldx, in
 /* src/algebra/mod.rs                                                                          */
 
 /* algebra/mod.rs:41-54 : DMatrix::from_fn fills column by column */
+typedef struct {
+    const fro_kprog* p;
+    const double *A, *B;
+    int64_t n1, lda, ldb, d, ldo;
+    double* out;
+} gram_arg;
+
+static void gram_cols(int64_t c0, int64_t c1, void* q)
+{
+    const gram_arg* g = (const gram_arg*)q;
+    for (int64_t c = c0; c < c1; ++c)
+        for (int64_t r = 0; r < g->n1; ++r)
+            AT(g->out, g->ldo, r, c) = fro_kernel(g->p, g->A + r, g->lda, g->B + c, g->ldb, g->d);
+}
+
 void fro_make_covariance_matrix(const fro_kprog* p, const double* A, int64_t n1, int64_t lda, const double* B,
                                 int64_t n2, int64_t ldb, int64_t d, double* out, int64_t ldo)
 {
-    for (int64_t c = 0; c < n2; ++c)
-        for (int64_t r = 0; r < n1; ++r) AT(out, ldo, r, c) = fro_kernel(p, A + r, lda, B + c, ldb, d);
+    gram_arg g = {p, A, B, n1, lda, ldb, d, ldo, out};
+    par_for(n2, gram_cols, &g); /* entries are independent (algebra/mod.rs:46-51) */
 }
 
 /* [nalgebra] Cholesky::new_internal (linalg/cholesky.rs) */
@@ -524,6 +603,183 @@ int fro_cholesky(double* A, int64_t n, int64_t lda, int has_sub, double sub, int
     return 0;
 }
 
+/* ---- the same factorisation, scheduled for several host threads and for the leading `ncols` columns only ------------
+ * Element (i, j) of the reference's factor is
+ *     ((..((a_ij - l_j0 l_i0) - l_j1 l_i1) ..) - l_j,j-1 l_i,j-1) / l_jj        (fro_cholesky above: k ascending, mul then add)
+ * and depends only on columns < j.  Any schedule that applies the updates to an element in ascending k with the same
+ * unfused multiply-add therefore reproduces fro_cholesky BIT FOR BIT; this one is right-looking in panels of CB columns
+ * (the panel's own columns left-looking, then the panel applied to the later columns < ncols), rows dealt to threads in
+ * blocks.  Columns >= ncols are never touched: their leading-column dependencies are one-way.  tests/test_oracle.py
+ * asserts array_equal against fro_cholesky (substitution list and failure column included). */
+#define CB 64   /* panel width */
+#define RB 256  /* row block */
+
+typedef struct {
+    double* A;
+    int64_t n, lda, ncols;
+    int has_sub;
+    double sub;
+    int64_t* subst_idx;
+    /* shared state, written by thread 0 between barriers */
+    int64_t ns;
+    int fail; /* 1 + failing column, 0 = none */
+    double denom;
+    pthread_barrier_t bar;
+    int T;
+} cholmt;
+
+typedef struct {
+    cholmt* c;
+    int t;
+} cholmt_thread;
+
+static void cholmt_update_block(double* A, int64_t lda, int64_t i0, int64_t i1, int64_t j, int64_t k0, int64_t k1,
+                                const double* f)
+{
+    /* y[i] = f[k] * x_k[i] + y[i] for k = k0..k1-1 in order, rows i0..i1-1 of column j */
+    double* y = &AT(A, lda, i0, j);
+    const int64_t len = i1 - i0;
+    int64_t k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        const double f0 = f[k - k0], f1 = f[k + 1 - k0], f2 = f[k + 2 - k0], f3 = f[k + 3 - k0];
+        const double *x0 = &AT(A, lda, i0, k), *x1 = &AT(A, lda, i0, k + 1), *x2 = &AT(A, lda, i0, k + 2),
+                     *x3 = &AT(A, lda, i0, k + 3);
+        for (int64_t i = 0; i < len; ++i) {
+            double t = y[i];
+            t = f0 * x0[i] + t;
+            t = f1 * x1[i] + t;
+            t = f2 * x2[i] + t;
+            t = f3 * x3[i] + t;
+            y[i] = t;
+        }
+    }
+    for (; k < k1; ++k) axpy1(f[k - k0], &AT(A, lda, i0, k), y, len);
+}
+
+static void* cholmt_worker(void* q)
+{
+    cholmt_thread* me = (cholmt_thread*)q;
+    cholmt* c = me->c;
+    double* A = c->A;
+    const int64_t n = c->n, lda = c->lda, ncols = c->ncols;
+    const int T = c->T, t = me->t;
+    const int64_t nrb = (n + RB - 1) / RB;
+    double f[CB];
+    for (int64_t k0 = 0; k0 < ncols; k0 += CB) {
+        const int64_t k1 = k0 + CB < ncols ? k0 + CB : ncols;
+        /* the panel's own columns */
+        for (int64_t j = k0; j < k1; ++j) {
+            for (int64_t k = k0; k < j; ++k) f[k - k0] = -AT(A, lda, j, k);
+            for (int64_t rb = j / RB + ((t - (j / RB) % T + T) % T); rb < nrb; rb += T) { /* blocks rb == t (mod T) */
+                const int64_t i0 = rb * RB > j ? rb * RB : j, i1 = (rb + 1) * RB < n ? (rb + 1) * RB : n;
+                if (i0 < i1 && j > k0) cholmt_update_block(A, lda, i0, i1, j, k0, j, f);
+            }
+            pthread_barrier_wait(&c->bar);
+            if (t == 0 && !c->fail) {
+                const double diag = AT(A, lda, j, j);
+                if (diag != 0.0 && diag >= 0.0) {
+                    c->denom = sqrt(diag);
+                } else if (c->has_sub && c->sub != 0.0 && c->sub >= 0.0) {
+                    c->denom = sqrt(c->sub);
+                    if (c->subst_idx) c->subst_idx[c->ns] = j;
+                    ++c->ns;
+                } else {
+                    c->fail = (int)(1 + j);
+                }
+                if (!c->fail) AT(A, lda, j, j) = c->denom;
+            }
+            pthread_barrier_wait(&c->bar);
+            if (c->fail) return NULL;
+            const double denom = c->denom;
+            for (int64_t rb = j / RB + ((t - (j / RB) % T + T) % T); rb < nrb; rb += T) {
+                const int64_t i0 = rb * RB > j + 1 ? rb * RB : j + 1, i1 = (rb + 1) * RB < n ? (rb + 1) * RB : n;
+                for (int64_t i = i0; i < i1; ++i) AT(A, lda, i, j) /= denom;
+            }
+            pthread_barrier_wait(&c->bar);
+        }
+        /* the panel applied to the later leading columns */
+        if (k1 < ncols) {
+            for (int64_t rb = k1 / RB + ((t - (k1 / RB) % T + T) % T); rb < nrb; rb += T) {
+                const int64_t r0 = rb * RB, r1 = (rb + 1) * RB < n ? (rb + 1) * RB : n;
+                const int64_t jmax = ncols < r1 ? ncols : r1;
+                for (int64_t j = k1; j < jmax; ++j) {
+                    const int64_t i0 = r0 > j ? r0 : j;
+                    for (int64_t k = k0; k < k1; ++k) f[k - k0] = -AT(A, lda, j, k);
+                    cholmt_update_block(A, lda, i0, r1, j, k0, k1, f);
+                }
+            }
+            pthread_barrier_wait(&c->bar);
+        }
+    }
+    return NULL;
+}
+
+int fro_cholesky_cols_mt(double* A, int64_t n, int64_t lda, int64_t ncols, int has_sub, double sub, int64_t* n_subst,
+                         int64_t* subst_idx)
+{
+    if (ncols > n) ncols = n;
+    cholmt c;
+    memset(&c, 0, sizeof(c));
+    c.A = A;
+    c.n = n;
+    c.lda = lda;
+    c.ncols = ncols;
+    c.has_sub = has_sub;
+    c.sub = sub;
+    c.subst_idx = subst_idx;
+    int T = g_threads;
+    if (T > 64) T = 64;
+    if ((int64_t)T > (n + RB - 1) / RB) T = (int)((n + RB - 1) / RB);
+    if (T < 1) T = 1;
+    c.T = T;
+    if (n_subst) *n_subst = 0;
+    if (ncols <= 0) return 0;
+    pthread_barrier_init(&c.bar, NULL, (unsigned)T);
+    pthread_t th[64];
+    cholmt_thread arg[64];
+    for (int t = 0; t < T; ++t) {
+        arg[t].c = &c;
+        arg[t].t = t;
+    }
+    for (int t = 1; t < T; ++t)
+        if (pthread_create(&th[t], NULL, cholmt_worker, &arg[t]) != 0) abort(); /* the barrier counts T participants */
+    cholmt_worker(&arg[0]);
+    for (int t = 1; t < T; ++t) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&c.bar);
+    if (n_subst) *n_subst = c.ns;
+    return c.fail;
+}
+
+/* algebra/mod.rs:59-92 restricted to the leading ncols columns of the factor (out: n x ncols), threaded as above */
+typedef struct {
+    const fro_kprog* p;
+    const double* X;
+    int64_t n, ldx, d, ldo;
+    double noise;
+    double* out;
+} gramsym_arg;
+
+static void gramsym_cols(int64_t c0, int64_t c1, void* q)
+{
+    const gramsym_arg* g = (const gramsym_arg*)q;
+    for (int64_t col = c0; col < c1; ++col) { /* :70-79 */
+        for (int64_t row = 0; row < col; ++row) AT(g->out, g->ldo, row, col) = NAN; /* :67 */
+        for (int64_t row = col; row < g->n; ++row)
+            AT(g->out, g->ldo, row, col) = fro_kernel(g->p, g->X + col, g->ldx, g->X + row, g->ldx, g->d);
+        AT(g->out, g->ldo, col, col) += g->noise * g->noise;
+    }
+}
+
+int fro_make_cholesky_cov_matrix_cols_mt(const fro_kprog* p, const double* X, int64_t n, int64_t ldx, int64_t d,
+                                         double noise, int has_eps, double eps, int64_t ncols, double* out, int64_t ldo,
+                                         int64_t* n_subst, int64_t* subst_idx)
+{
+    if (ncols > n) ncols = n;
+    gramsym_arg g = {p, X, n, ldx, d, ldo, noise, out};
+    par_for(ncols, gramsym_cols, &g);
+    return fro_cholesky_cols_mt(out, n, ldo, ncols, has_eps, eps, n_subst, subst_idx);
+}
+
 /* algebra/mod.rs:59-92 */
 int fro_make_cholesky_cov_matrix(const fro_kprog* p, const double* X, int64_t n, int64_t ldx, int64_t d,
                                  double noise, int has_eps, double eps, double* out, int64_t ldo,
@@ -538,27 +794,21 @@ int fro_make_cholesky_cov_matrix(const fro_kprog* p, const double* X, int64_t n,
     return fro_cholesky(out, n, ldo, has_eps, eps, n_subst, subst_idx); /* :81-91 */
 }
 
-/* [nalgebra] solve_lower_triangular_mut (checked): column-oriented forward substitution */
-int fro_solve_lower(const double* L, int64_t n, int64_t ldl, double* B, int64_t m, int64_t ldb)
-{
-    for (int64_t c = 0; c < m; ++c) {
-        double* b = B + c * ldb;
-        for (int64_t i = 0; i < n; ++i) {
-            const double diag = AT(L, ldl, i, i);
-            if (diag == 0.0) return -1;
-            const double coeff = b[i] / diag;
-            b[i] = coeff;
-            axpy1(-coeff, &AT(L, ldl, i + 1 < n ? i + 1 : i, i), b + i + 1, n - i - 1);
-        }
-    }
-    return 0;
-}
+typedef struct {
+    const double* L;
+    int64_t n, ldl, ldb;
+    double* B;
+} solve_arg;
 
-/* unchecked variant used by Cholesky::solve_mut */
-static void solve_lower_unchecked(const double* L, int64_t n, int64_t ldl, double* B, int64_t m, int64_t ldb)
+/* [nalgebra] solve_lower_triangular_mut: column-oriented forward substitution, one right-hand side at a time
+ * (the right-hand sides are independent: par_for over them) */
+static void solve_lower_cols(int64_t c0, int64_t c1, void* q)
 {
-    for (int64_t c = 0; c < m; ++c) {
-        double* b = B + c * ldb;
+    const solve_arg* a = (const solve_arg*)q;
+    const double* L = a->L;
+    const int64_t n = a->n, ldl = a->ldl;
+    for (int64_t c = c0; c < c1; ++c) {
+        double* b = a->B + c * a->ldb;
         for (int64_t i = 0; i < n; ++i) {
             const double coeff = b[i] / AT(L, ldl, i, i);
             b[i] = coeff;
@@ -567,16 +817,42 @@ static void solve_lower_unchecked(const double* L, int64_t n, int64_t ldl, doubl
     }
 }
 
-/* [nalgebra] ad_solve_lower_triangular_unchecked_mut: dot-oriented backward substitution with L^T */
-void fro_ad_solve_lower(const double* L, int64_t n, int64_t ldl, double* B, int64_t m, int64_t ldb)
+/* unchecked variant used by Cholesky::solve_mut */
+static void solve_lower_unchecked(const double* L, int64_t n, int64_t ldl, double* B, int64_t m, int64_t ldb)
 {
-    for (int64_t c = 0; c < m; ++c) {
-        double* b = B + c * ldb;
+    solve_arg a = {L, n, ldl, ldb, B};
+    par_for(m, solve_lower_cols, &a);
+}
+
+/* checked: None (here -1) iff a diagonal entry is exactly zero -- the check only depends on L, so it is hoisted */
+int fro_solve_lower(const double* L, int64_t n, int64_t ldl, double* B, int64_t m, int64_t ldb)
+{
+    if (m > 0)
+        for (int64_t i = 0; i < n; ++i)
+            if (AT(L, ldl, i, i) == 0.0) return -1;
+    solve_lower_unchecked(L, n, ldl, B, m, ldb);
+    return 0;
+}
+
+static void ad_solve_cols(int64_t c0, int64_t c1, void* q)
+{
+    const solve_arg* a = (const solve_arg*)q;
+    const double* L = a->L;
+    const int64_t n = a->n, ldl = a->ldl;
+    for (int64_t c = c0; c < c1; ++c) {
+        double* b = a->B + c * a->ldb;
         for (int64_t i = n - 1; i >= 0; --i) {
             const double dot = (i + 1 < n) ? dot8(&AT(L, ldl, i + 1, i), b + i + 1, n - i - 1) : dot8(b, b, 0);
             b[i] = (b[i] - dot) / AT(L, ldl, i, i);
         }
     }
+}
+
+/* [nalgebra] ad_solve_lower_triangular_unchecked_mut: dot-oriented backward substitution with L^T */
+void fro_ad_solve_lower(const double* L, int64_t n, int64_t ldl, double* B, int64_t m, int64_t ldb)
+{
+    solve_arg a = {L, n, ldl, ldb, B};
+    par_for(m, ad_solve_cols, &a);
 }
 
 /* [nalgebra] Cholesky::solve_mut */

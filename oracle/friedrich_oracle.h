@@ -87,6 +87,18 @@ int fro_make_cholesky_cov_matrix(const fro_kprog* p, const double* X, int64_t n,
 /* nalgebra Cholesky::new_internal, in place on the lower triangle. */
 int fro_cholesky(double* A, int64_t n, int64_t lda, int has_sub, double sub, int64_t* n_subst,
                  int64_t* subst_idx);
+/* Host threads for the loops whose iterations are independent in the reference (right-hand sides of a solve, Gram
+ * entries, rows of an axpy).  n <= 0: all online cores.  Default 1.  Results are bit-identical for every thread count. */
+void fro_set_threads(int n);
+int fro_get_threads(void);
+/* fro_cholesky / fro_make_cholesky_cov_matrix restricted to the leading ncols columns (out is n x ncols; the strict upper
+ * part of those columns is NaN), blocked and threaded with the reference's per-element operation order: bit-identical
+ * to the leading columns of the single-thread functions. */
+int fro_cholesky_cols_mt(double* A, int64_t n, int64_t lda, int64_t ncols, int has_sub, double sub, int64_t* n_subst,
+                         int64_t* subst_idx);
+int fro_make_cholesky_cov_matrix_cols_mt(const fro_kprog* p, const double* X, int64_t n, int64_t ldx, int64_t d,
+                                         double noise, int has_eps, double eps, int64_t ncols, double* out, int64_t ldo,
+                                         int64_t* n_subst, int64_t* subst_idx);
 /* :97-126 + Cholesky::insert_column (A.3).  L: buffer with ldl >= n_old+nb_new holding the n_old factor;
  * on return holds the (n_old+nb_new) factor.  No epsilon, no failure check (plain sqrt => NaN). */
 void fro_add_rows_cholesky_cov_matrix(const fro_kprog* p, double* L, int64_t ldl, const double* Xall,

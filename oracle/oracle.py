@@ -114,6 +114,15 @@ def lib():
                                                    ctypes.c_double, _dp, _i64, _ip, _ip]
         L.fro_cholesky.restype = ctypes.c_int
         L.fro_cholesky.argtypes = [_dp, _i64, _i64, ctypes.c_int, ctypes.c_double, _ip, _ip]
+        L.fro_set_threads.restype = None
+        L.fro_set_threads.argtypes = [ctypes.c_int]
+        L.fro_get_threads.restype = ctypes.c_int
+        L.fro_get_threads.argtypes = []
+        L.fro_cholesky_cols_mt.restype = ctypes.c_int
+        L.fro_cholesky_cols_mt.argtypes = [_dp, _i64, _i64, _i64, ctypes.c_int, ctypes.c_double, _ip, _ip]
+        L.fro_make_cholesky_cov_matrix_cols_mt.restype = ctypes.c_int
+        L.fro_make_cholesky_cov_matrix_cols_mt.argtypes = [_kp, _dp, _i64, _i64, _i64, ctypes.c_double, ctypes.c_int,
+                                                           ctypes.c_double, _i64, _dp, _i64, _ip, _ip]
         L.fro_add_rows_cholesky_cov_matrix.restype = None
         L.fro_add_rows_cholesky_cov_matrix.argtypes = [_kp, _dp, _i64, _dp, _i64, _i64, _i64, _i64, ctypes.c_double]
         L.fro_make_gradient_covariance_matrices.restype = None
@@ -257,6 +266,55 @@ def make_cholesky_cov_matrix(spec, X, noise, eps=None):
                                             0 if eps is None else 1, 0.0 if eps is None else float(eps), _ptr(out),
                                             max(n, 1), ctypes.byref(ns), idx.ctypes.data_as(_ip))
     return st, out, idx[:ns.value].copy()
+
+
+def set_threads(n=0):
+    """host threads for the independent loops (right-hand sides, Gram entries, axpy rows); n <= 0: every online core.
+    Results are bit-identical for every thread count.  Returns the count in effect."""
+    lib().fro_set_threads(int(n))
+    return lib().fro_get_threads()
+
+
+class threads:
+    """with O.threads(): ... -- all cores inside the block, one thread (the reference's execution) outside"""
+
+    def __init__(self, n=0):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = lib().fro_get_threads()
+        return set_threads(self.n)
+
+    def __exit__(self, *exc):
+        lib().fro_set_threads(self.prev)
+
+
+def make_cholesky_cov_matrix_cols(spec, X, noise, eps=None, ncols=None):
+    """leading `ncols` columns of make_cholesky_cov_matrix's factor (n x ncols, NaN above the diagonal), computed with
+    the blocked multi-thread schedule that is bit-identical to the reference order -> (status, Lcols, subst idx < ncols)"""
+    p = kprog(spec)
+    X = fmat(X)
+    n = X.shape[0]
+    ncols = n if ncols is None else min(int(ncols), n)
+    out = np.empty((n, max(ncols, 1)), order="F")
+    ns = ctypes.c_int64(0)
+    idx = np.zeros(max(n, 1), dtype=np.int64)
+    st = lib().fro_make_cholesky_cov_matrix_cols_mt(ctypes.byref(p), _ptr(X), n, _ld(X), X.shape[1], float(noise),
+                                                    0 if eps is None else 1, 0.0 if eps is None else float(eps), ncols,
+                                                    _ptr(out), max(n, 1), ctypes.byref(ns), idx.ctypes.data_as(_ip))
+    return st, out[:, :ncols], idx[:ns.value].copy()
+
+
+def cholesky_cols(A, sub=None, ncols=None):
+    """fro_cholesky on the leading ncols columns of a copy of A (blocked, threaded, bit-identical)"""
+    A = fmat(A).copy(order="F")
+    n = A.shape[0]
+    ncols = n if ncols is None else min(int(ncols), n)
+    ns = ctypes.c_int64(0)
+    idx = np.zeros(max(n, 1), dtype=np.int64)
+    st = lib().fro_cholesky_cols_mt(_ptr(A), n, max(n, 1), ncols, 0 if sub is None else 1,
+                                    0.0 if sub is None else float(sub), ctypes.byref(ns), idx.ctypes.data_as(_ip))
+    return st, A[:, :ncols], idx[:ns.value].copy()
 
 
 def cholesky(A, sub=None):

@@ -1,4 +1,7 @@
-// friedrich.hpp -- C++ mirror of friedrich's public API on top of the C ABI (include/friedrich_amd.h).
+// friedrich.hpp -- TEST HARNESS (not a product component): a C++ stand-in for the reference's own host code, so that the
+// reference's doctests / src/main.rs can be replayed against the C ABI (include/friedrich_amd.h) in an image without a
+// Rust toolchain.  In a real integration these layers (builder, priors, Input conversion, ADAM scalars: SURVEY.md
+// section 2 rows 6, 8, 9 -- OUT OF SCOPE) stay friedrich's unchanged Rust; see INTEGRATION.md for the Rust side.
 //
 // The reference is a Rust crate and this image has no Rust toolchain, so the host side that a Rust maintainer would
 // write is mirrored here in C++ with the reference's names, argument meaning and error behaviour:

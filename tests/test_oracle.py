@@ -176,3 +176,45 @@ def test_heuristics():
     assert abs(O.fit_bandwidth_mean(X) - np.mean(dists)) < 1e-13
     y = np.random.default_rng(1).standard_normal(50)
     assert abs(O.variance(y) - np.var(y)) < 1e-14  # population variance
+
+
+# ---- host threads / blocked schedule: the same arithmetic, bit for bit ------------------------------------------------
+@pytest.mark.parametrize("n,ncols,threads", [(1, 1, 4), (5, 5, 3), (300, 300, 4), (777, 500, 8), (1300, 1300, 5), (1300, 70, 8)])
+def test_threaded_blocked_cholesky_is_bit_identical(n, ncols, threads):
+    """fro_cholesky_cols_mt (right-looking panels of 64, rows dealt to threads) applies the updates of every element in
+    ascending k with unfused multiply-adds, exactly like the left-looking restatement of nalgebra's Cholesky::new_internal:
+    equal bits, equal substitution list, equal failure column."""
+    rng = np.random.default_rng(n + ncols)
+    Q = rng.standard_normal((n, n))
+    A = Q @ Q.T + n * np.eye(n)
+    if n > 100:
+        A[n // 2, n // 2] = -1.0  # a negative pivot: failure without a substitute, one substitution with
+    for sub in (None, 3.0):
+        st, L1, idx1 = O.cholesky(A, sub)
+        with O.threads(threads):
+            st2, Lc, idx2 = O.cholesky_cols(A, sub, ncols)
+        assert O.lib().fro_get_threads() == 1
+        if st == 0 or st > ncols:
+            assert st2 == 0
+            assert np.array_equal(np.tril(Lc), np.tril(L1)[:, :ncols])
+            assert idx2.tolist() == [i for i in idx1.tolist() if i < ncols]
+        else:
+            assert st2 == st
+
+
+def test_threaded_gram_factor_and_solves_are_bit_identical():
+    k = PD_KERNELS[1]
+    X = rand_inputs(700, 4, 3)
+    B = np.asfortranarray(np.random.default_rng(1).standard_normal((700, 37)))
+    st, L1, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    K1 = O.make_covariance_matrix(k, X, X[:100])
+    Z1, W1 = O.chol_solve(L1, B), O.solve_lower(L1, B)[1]
+    with O.threads(6):
+        st2, L2, _ = O.make_cholesky_cov_matrix_cols(k, X, 0.1)
+        K2 = O.make_covariance_matrix(k, X, X[:100])
+        Z2, W2 = O.chol_solve(L1, B), O.solve_lower(L1, B)[1]
+        st3, L3, _ = O.make_cholesky_cov_matrix_cols(k, X, 0.1, None, 200)
+    assert st == st2 == st3 == 0
+    assert np.array_equal(np.tril(L1), np.tril(L2)) and np.array_equal(np.tril(L1)[:, :200], np.tril(L3))
+    assert np.all(np.isnan(L2[np.triu_indices(700, 1)]))  # algebra/mod.rs:67
+    assert np.array_equal(K1, K2) and np.array_equal(Z1, Z2) and np.array_equal(W1, W2)
