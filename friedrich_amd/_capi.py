@@ -95,6 +95,7 @@ SIGNATURES = {
     "fr_chol_download_l": (_int, [_vp, _dp, _i64, _int]),
     "fr_chol_upload_l": (_int, [_vp, _dp, _i64, _i64, _dp, _i64, _i64, _i64, _pp]),
     "fr_chol_free": (None, [_vp]),
+    "fr_chol_set_targets": (_int, [_vp, _dp]),
     "fr_likelihood": (_int, [_vp, _kp, _dp, _dbl, _pdbl]),
     "fr_predict_mean": (_int, [_vp, _kp, _dp, _dp, _i64, _i64, _dp, _dp]),
     "fr_predict_variance": (_int, [_vp, _kp, _dp, _i64, _i64, _dp]),

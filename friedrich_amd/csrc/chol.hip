@@ -410,6 +410,7 @@ static bool wide_solve(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
+    if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, true, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, true);
     WsGuard w(ctx);
     double* tmp = nullptr;
@@ -424,6 +425,7 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
 int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
+    if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, false, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, false);
     WsGuard w(ctx);
     double* tmp = nullptr;
@@ -442,6 +444,11 @@ static void chol_release(fr_chol* c)
     if (c->dinv) (void)hipFree(c->dinv);
     if (c->info) (void)hipFree(c->info);
     if (c->inv512) (void)hipFree(c->inv512);
+    if (c->yt) (void)hipFree(c->yt);
+    if (c->alpha) (void)hipFree(c->alpha);
+    c->yt = c->alpha = nullptr;
+    c->targets_cap = 0;
+    c->targets_n = -1;
     c->A = c->X = c->dinv = c->inv512 = nullptr;
     c->info = nullptr;
     c->inv512_cap = c->inv512_rows = 0;
@@ -460,7 +467,8 @@ static int64_t pick_nb(const fr_ctx* ctx, int64_t n)
 static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t d)
 {
     c->capacity = imax(capacity, 1);
-    c->ld_a = round_up(c->capacity, kAlign);
+    // a multiple of 128: the persistent solves (trsv.hip) read whole 128-row blocks, the rows behind the last one included
+    c->ld_a = round_up(c->capacity, IB);
     if (c->ld_a % 1024 == 0) c->ld_a += ctx->ld_pad;
     c->ld_x = c->ld_a;
     c->d = d;
@@ -547,6 +555,7 @@ static int merge_info(fr_chol* c)
 int potrf_device(fr_ctx* ctx, fr_chol* c, int64_t j0, int64_t n, int mode, double sub)
 {
     c->inv512_rows = 0;
+    ++c->gen;
     return potrf_blocked(ctx, c->A + j0 + j0 * c->ld_a, c->ld_a, n, j0, mode, sub, c->dinv + (j0 / IB) * INV_ELEMS, c->info,
                          c->nb);
 }
@@ -575,6 +584,7 @@ static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise,
 {
     fr_ctx* ctx = c->ctx;
     c->inv512_rows = 0;
+    ++c->gen;
     FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
     FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank,
                            c->nb));
@@ -737,6 +747,7 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     if (n_old > 0) FR_TRY(check_zero_diag(c, "Cholesky::insert_column: Unable to solve lower triangular system!"));
     // (the cached 512-block inverses stay valid: rows below n_old are appended, blocks inside the old factor do not change)
     FR_TRY(chol_grow(c, n_all));
+    ++c->gen;  // cached alpha is stale; the targets cover n_old rows only and have to be handed over again
     c->nb = pick_nb(ctx, n_all);
     // new rows of the EMatrix mirror
     FR_TRY(upload_rows(ctx, Xall + n_old, ldx, c->X + n_old, c->ld_x, nb_new, d));

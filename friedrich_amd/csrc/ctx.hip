@@ -183,6 +183,34 @@ int Staged::commit()
     FR_HIP(ctx, hipMemcpy2DAsync(host, sizeof(double) * host_ld, dev, sizeof(double) * ld, sizeof(double) * rows, cols,
                                  is_device_ptr(host) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return check_status_word(ctx);
+}
+
+// ---- device-side wait status -----------------------------------------------------------------------
+int ensure_status_word(fr_ctx* ctx)
+{
+    if (ctx->dev_status) return FR_OK;
+    void* h = nullptr;
+    FR_HIP(ctx, hipHostMalloc(&h, 64, hipHostMallocMapped));
+    memset(h, 0, 64);
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        (void)hipHostFree(h);
+        return set_err(ctx, FR_HIP_ERROR, "hipHostGetDevicePointer failed");
+    }
+    ctx->host_status = (unsigned*)h;
+    ctx->dev_status = (unsigned*)d;
+    return FR_OK;
+}
+
+int check_status_word(fr_ctx* ctx)
+{
+    if (!ctx->host_status) return FR_OK;
+    volatile unsigned* s = ctx->host_status;
+    if (s[0] != 0) {
+        s[0] = 0;
+        return set_err(ctx, FR_HIP_ERROR, "a device-side wait timed out (persistent kernel hand-off); results are invalid");
+    }
     return FR_OK;
 }
 
@@ -265,6 +293,7 @@ int fr_ctx_create(fr_ctx** out, int device)
     }
     fr_ctx* ctx = new fr_ctx();
     ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return FR_HIP_ERROR;
@@ -297,6 +326,8 @@ void fr_ctx_destroy(fr_ctx* ctx)
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     for (auto& b : ctx->pool)
         if (b.p) (void)hipFree(b.p);
+    if (ctx->trsv_gran) (void)hipFree(ctx->trsv_gran);
+    if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamDestroy(ctx->stream2);
@@ -324,7 +355,7 @@ int fr_ctx_synchronize(fr_ctx* ctx)
     if (!ctx) return FR_INVALID_ARGUMENT;
     FR_LOCK(ctx);
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FR_OK;
+    return check_status_word(ctx);
 }
 
 const char* fr_last_error(const fr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -358,6 +389,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     }
     if (!strcmp(name, "splitk")) {
         ctx->splitk = value != 0;
+        return FR_OK;
+    }
+    if (!strcmp(name, "trsv")) {
+        ctx->trsv = value != 0;
         return FR_OK;
     }
     if (!strcmp(name, "leaf512")) {

@@ -71,6 +71,15 @@ struct fr_ctx {
     int64_t prof_launches[FR_PROF_COUNT] = {0};
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
+    int64_t trsv = 1;           // single right-hand-side solves as one persistent launch per direction (trsv.hip)
+    // device-side waits report a timeout here (host-mapped, so the host can read it after any synchronisation)
+    unsigned* host_status = nullptr;
+    unsigned* dev_status = nullptr;
+    int num_cus = 256;
+    // hand-off granules of the persistent solves (grow-only)
+    void* trsv_gran = nullptr;
+    size_t trsv_gran_cap = 0;
+    bool trsv_lds_set = false;
     // RCCL
     void* comm = nullptr;   // ncclComm_t
     void* local = nullptr;  // in-process ("local") communicator: ranks are host threads sharing one device
@@ -100,6 +109,14 @@ struct fr_chol {
     int64_t* info = nullptr;  // device: [0] = 1 + first failing column (0: none), [1] = n_subst,
                               //         [2] = 1 if a zero diagonal was seen, [3..] substituted columns
     int64_t info_cap = 0;
+    // cached alpha = K^-1 y (todo.md:10): the residual training outputs handed over with
+    // fr_chol_set_targets and the solve they imply.  `gen` counts the changes of the factor (refactor, add_rows, upload);
+    // alpha is recomputed lazily when its generation is stale, the targets must be handed over again when n changed.
+    double* yt = nullptr;     // capacity doubles: targets
+    double* alpha = nullptr;  // capacity doubles: K^-1 yt
+    int64_t targets_n = -1;   // rows the targets were set for (-1: never)
+    int64_t targets_cap = 0;
+    uint64_t gen = 1, alpha_gen = 0;
     // host mirror of info after the last factorisation
     int64_t fail_col = -1;
     int64_t n_subst = 0;
@@ -259,6 +276,12 @@ int launch_gemv_n(fr_ctx* ctx, const double* A, int64_t rows, int64_t cols, int6
 int launch_axpby_vec(fr_ctx* ctx, int64_t n, double a, const double* x, double b, double* y);  // y = a*x + b*y
 int launch_diag_check_zero(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, int64_t* flag);
 int launch_sum_log_abs(fr_ctx* ctx, const double* v, int64_t n, double* out);
+
+// K8 (trsv.hip): b <- L^-1 b (fwd) or L^-T b with one right-hand side, one persistent launch
+int launch_trsv(fr_ctx* ctx, const fr_chol* c, double* b, bool fwd, int prof_cls);
+int ensure_status_word(fr_ctx* ctx);
+// FR_HIP_ERROR if a device-side wait timed out since the last check (call after a synchronisation)
+int check_status_word(fr_ctx* ctx);
 
 // ---- collectives (comm.hip): RCCL over xGMI, or the in-process local transport; enqueue on ctx->ls ----------
 int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root);

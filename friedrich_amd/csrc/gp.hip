@@ -69,11 +69,59 @@ static int zero_diag_status(fr_chol* c, const char* what)
     return FR_OK;
 }
 
+// alpha = K^-1 targets, recomputed when the factor changed since it was last solved (two single-column solves: trsv.hip)
+static int ensure_alpha(fr_chol* c)
+{
+    fr_ctx* ctx = c->ctx;
+    if (c->targets_n != c->n || !c->yt)
+        return set_err(ctx, FR_INVALID_ARGUMENT,
+                       "no training outputs cached for the current %lld rows: call fr_chol_set_targets after the factor's row "
+                       "count changed (or pass y)", (long long)c->n);
+    if (c->alpha_gen == c->gen) return FR_OK;
+    if (c->n > 0) {
+        FR_HIP(ctx, hipMemcpyAsync(c->alpha, c->yt, sizeof(double) * (size_t)c->n, hipMemcpyDeviceToDevice, ctx->stream));
+        const int64_t ld = c->targets_cap;
+        FR_TRY(trsm_lower_fwd(ctx, c, c->n, c->alpha, 1, ld, FR_PROF_GEMM_SOLVE));
+        FR_TRY(trsm_lower_bwd(ctx, c, c->n, c->alpha, 1, ld, FR_PROF_GEMM_SOLVE));
+    }
+    c->alpha_gen = c->gen;
+    return FR_OK;
+}
+
 }  // namespace fr
 
 using namespace fr;
 
 extern "C" {
+
+int fr_chol_set_targets(fr_chol* c, const double* y)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    if (c->n > 0 && !y) return set_err(ctx, FR_INVALID_ARGUMENT, "null training-output vector (y)");
+    if (c->targets_cap < c->capacity || !c->yt) {
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (c->yt) (void)hipFree(c->yt);
+        if (c->alpha) (void)hipFree(c->alpha);
+        c->yt = c->alpha = nullptr;
+        c->targets_cap = 0;
+        const int64_t cap = round_up(c->capacity > 0 ? c->capacity : 1, kAlign);
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->yt, sizeof(double) * (size_t)cap));
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->alpha, sizeof(double) * (size_t)cap));
+        c->targets_cap = cap;
+    }
+    if (c->n > 0) {
+        const bool dev = is_device_ptr(y);
+        FR_HIP(ctx, hipMemcpyAsync(c->yt, y, sizeof(double) * (size_t)c->n, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                   ctx->stream));
+        if (!dev) FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    c->targets_n = c->n;
+    c->alpha_gen = 0;  // solved lazily by the first predict
+    return FR_OK;
+}
 
 int fr_likelihood(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, double* out)
 {
@@ -122,6 +170,15 @@ int fr_predict_mean(fr_chol* c, const fr_kprog* kernel, const double* y, const d
     QueryCtx q(c);
     FR_TRY(q.init(kernel, Xq, m, ldq));
     Staged ys(ctx), mean(ctx);
+    if (!y) {
+        // cached alpha = K^-1 y (fr_chol_set_targets): prior + K*^T alpha -- no solve at all once alpha is current, the
+        // n x m cross-Gram and one pass over it are all that is left (todo.md:10)
+        FR_TRY(ensure_alpha(c));
+        FR_TRY(stage_vec_out(ctx, mean, out_mean, m));
+        FR_TRY(init_with_prior(ctx, mean.dev, prior_q, m));
+        FR_TRY(launch_gemv_t(ctx, q.K, c->n, m, q.ldk, c->alpha, 1.0, 1.0, mean.dev));
+        return mean.commit();
+    }
     FR_TRY(stage_vec_in(ctx, ys, y, c->n));
     FR_TRY(stage_vec_out(ctx, mean, out_mean, m));
     FR_TRY(init_with_prior(ctx, mean.dev, prior_q, m));

@@ -1,0 +1,362 @@
+// trsv.hip -- K8: triangular solves with ONE right-hand side (L x = b, L^T x = b) as one persistent launch per direction.
+//
+// Replaces nalgebra's solve_lower_triangular / ad_solve_lower_triangular on a single column: K^-1 y inside predict (with
+// predict_assoc = 1) and the cached alpha, likelihood (mod.rs:203), and every predict / predict_variance of ONE query
+// point (mod.rs:235, 260-263) -- the Bayesian-optimisation inner loop of readme.md:7.
+//
+// The work is HBM-bound: the lower triangle of L is read exactly once (8 n^2 / 2 bytes: 4.3 GB at n = 32768).  Round 1
+// issued it as a recursion of ~127 dependent launches per direction (10 ms at n = 32768 against a floor of 0.7 ms).  Here
+// the solve is ONE launch: the 128-row blocks are dealt to the workgroups (one per CU); block r's owner streams its row of
+// tiles L[r, c] (forward) or its column of tiles L[i, r] (backward) while the solution blocks x_c it needs become
+// available, finishes with the explicit inverse of the diagonal block (fr_chol::dinv) and publishes x_r.  The only
+// serial part is the hand-off of x_r from owner to owner, which uses the data-is-the-flag form of
+// cdna_hip_programming.md Guideline 16 (R2): every double travels as two 8-byte {epoch, half} granules written by
+// write-through (sc1) stores and polled with relaxed agent-scope loads -- no fence, no separate flag, placement
+// independent.  The tile that a block needs LAST (the one next to the diagonal) and its inverse block are already in
+// registers when the hand-off arrives, so a step of the chain costs one poll + 2 x 64 FMAs per lane + two small reductions.
+//
+// Deterministic: every sum has a fixed order (no atomics on data).  Every spin is bounded (wall-clock timeout -> status
+// word in host-visible memory -> FR_HIP_ERROR), so a scheduling accident cannot hang the GPU.
+#include "fr_internal.hpp"
+
+namespace fr {
+
+constexpr int TB = 128;  // block = the inverse-block size of the factor
+constexpr int NT = 512;  // threads: 8 waves, two per SIMD -- VALU code can only name 256 VGPRs, and a lane keeps two tiles in flight
+constexpr int NW = NT / 64;
+constexpr int NC = TB / NW;  // columns of a tile per wave (16): a lane holds rows 2 rp, 2 rp + 1 of them = 32 doubles
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+struct TrsvArgs {
+    const double* L;
+    int64_t ld, n;
+    const double* dinv;  // block b at dinv + b * TB * TB, ld TB
+    double* b;           // right-hand side in, solution out
+    u64* gran;           // 2 granules per entry of x: [2 i] = {epoch, low word}, [2 i + 1] = {epoch, high word}
+    unsigned* status;    // host-visible: [0] != 0 after a timed-out wait
+    int nblk, G;
+    unsigned epoch;
+};
+
+__device__ __forceinline__ u64 gran_load(const u64* p)
+{
+    return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gran_store(u64* p, unsigned epoch, unsigned v)
+{
+    __hip_atomic_store((gu64*)p, ((u64)epoch << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Block `blk` of the solution (TB doubles = 2 TB granules, one per thread of the first four waves) -> xs[0 .. TB).  Returns false after a
+// timeout (the caller abandons the solve; the host reports it).
+__device__ __forceinline__ bool wait_block(const TrsvArgs& a, int blk, double* xs, int t)
+{
+    bool ok = true;
+    if (t < 2 * TB) {
+    const u64* p = a.gran + (int64_t)blk * (2 * TB) + t;
+    u64 g = gran_load(p);
+    if ((unsigned)(g >> 32) != a.epoch) {
+        const u64 t0 = wall_clock64();  // 100 MHz
+        unsigned spins = 0;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(1);
+            g = gran_load(p);
+            if ((unsigned)(g >> 32) == a.epoch) break;
+            if ((++spins & 255u) == 0) {
+                const bool dead = __hip_atomic_load((gu32*)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                if (dead || wall_clock64() - t0 > 300000000ull) {  // 3 s
+                    __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    g = 0;
+                    break;
+                }
+            }
+        }
+    }
+    ok = (unsigned)(g >> 32) == a.epoch;
+    // lanes 2 i / 2 i + 1 hold the low / high word of double i
+    const unsigned mine = (unsigned)g;
+    const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
+    if ((t & 1) == 0) xs[t >> 1] = __hiloint2double((int)other, (int)mine);
+    }
+    return __syncthreads_and(ok ? 1 : 0) != 0;
+}
+
+__device__ __forceinline__ void publish_entry(const TrsvArgs& a, int64_t i, double v)
+{
+    gran_store(a.gran + 2 * i, a.epoch, (unsigned)__double2loint(v));
+    gran_store(a.gran + 2 * i + 1, a.epoch, (unsigned)__double2hiint(v));
+}
+
+// One 128 x 128 operand block in registers: a lane holds rows 2 rp, 2 rp + 1 of the NC columns of its wave's column group
+// (2 NC doubles), loaded 16 bytes wide and coalesced along the rows (1 KiB per wave-instruction).  The same routine serves
+// the tiles of L (column stride ld) and the inverse of a diagonal block (column stride TB): one load site per register
+// buffer keeps the address arithmetic -- and with it the register pressure -- of the unrolled loads in one place.
+struct Operand {
+    const double* base;  // element (0, 0) of the block
+    int64_t stride;      // column stride
+    int rows, cols;      // valid extent (entries outside read as zero); 128 x 128 for every block but the last
+};
+
+__device__ __forceinline__ Operand tile_operand(const TrsvArgs& a, int rb, int cb)
+{
+    Operand o;
+    o.base = a.L + (int64_t)rb * TB + (int64_t)cb * TB * a.ld;
+    o.stride = a.ld;
+    const int64_t rr = a.n - (int64_t)rb * TB;
+    o.rows = rr < TB ? (int)rr : TB;
+    o.cols = TB;  // cb < rb: the column block is complete
+    return o;
+}
+
+__device__ __forceinline__ Operand inv_operand(const TrsvArgs& a, int b)
+{
+    Operand o;
+    o.base = a.dinv + (int64_t)b * (TB * TB);
+    o.stride = TB;
+    const int64_t rr = a.n - (int64_t)b * TB;
+    o.rows = o.cols = rr < TB ? (int)rr : TB;
+    return o;
+}
+
+__device__ __forceinline__ void load_operand(const Operand& o, int rp, int cg, double2 (&buf)[NC])
+{
+    // The loads are unconditional: the factor's leading dimension is a multiple of 128 (chol_alloc_buffers) and an inverse
+    // block is a full 128 x 128 slot, so every address of a partial block exists; what lies outside its valid extent is
+    // replaced by zeros afterwards (selects, no branches, no second set of addresses).
+    // address = wave-uniform part (block, column: scalar registers) + the lane's row offset (one 32-bit VGPR shared by all
+    // NC loads): no per-load 64-bit address registers
+    const double* ub = o.base + (int64_t)(cg * NC) * o.stride;
+    const unsigned lane_off = 2u * (unsigned)rp;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) buf[k] = *reinterpret_cast<const double2*>(ub + (int64_t)k * o.stride + lane_off);
+    if (o.rows < TB || o.cols < TB) {  // uniform per block: only the last block of a factor whose size is not a multiple of 128
+        const bool okx = 2 * rp < o.rows, oky = 2 * rp + 1 < o.rows;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const bool cok = cg * NC + k < o.cols;
+            buf[k].x = (cok && okx) ? buf[k].x : 0.0;
+            buf[k].y = (cok && oky) ? buf[k].y : 0.0;
+        }
+    }
+}
+
+// ---- forward: L x = b ---------------------------------------------------------------------------------------------
+// acc(rows 2 rp, 2 rp + 1) += tile[:, cols of this wave] . x[cols of this wave]
+__device__ __forceinline__ void fwd_fma(const double2 (&buf)[NC], const double* xs, int cg, double& acc0, double& acc1)
+{
+    const double2* xv = reinterpret_cast<const double2*>(xs + cg * NC);
+#pragma unroll
+    for (int k = 0; k < NC / 2; ++k) {
+        const double2 x = xv[k];  // same address in every lane: LDS broadcast
+        acc0 = __builtin_fma(buf[2 * k].x, x.x, acc0);
+        acc1 = __builtin_fma(buf[2 * k].y, x.x, acc1);
+        acc0 = __builtin_fma(buf[2 * k + 1].x, x.y, acc0);
+        acc1 = __builtin_fma(buf[2 * k + 1].y, x.y, acc1);
+    }
+}
+
+// The inverse of the block's diagonal block waits in LDS (128 KiB, dynamic) from the start of the block: it is staged once,
+// off the chain, through the tile registers, and the closing product reads it back in the register layout of a tile.
+struct Shared {
+    double xs[2][TB];
+    double part[NW][TB];
+    double tv[TB];
+};
+constexpr size_t TRSV_LDS = sizeof(double) * TB * TB;
+
+__device__ __forceinline__ void stage_inverse(const TrsvArgs& a, int b, double* wl, int rp, int cg, double2 (&buf)[NC])
+{
+    load_operand(inv_operand(a, b), rp, cg, buf);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) *reinterpret_cast<double2*>(wl + (cg * NC + k) * TB + 2 * rp) = buf[k];
+}
+__device__ __forceinline__ void fetch_inverse(const double* wl, int rp, int cg, double2 (&buf)[NC])
+{
+#pragma unroll
+    for (int k = 0; k < NC; ++k) buf[k] = *reinterpret_cast<const double2*>(wl + (cg * NC + k) * TB + 2 * rp);
+}
+
+__device__ __forceinline__ double sum_parts(const Shared& s, int t)
+{
+    return ((s.part[0][t] + s.part[1][t]) + (s.part[2][t] + s.part[3][t])) +
+           ((s.part[4][t] + s.part[5][t]) + (s.part[6][t] + s.part[7][t]));
+}
+
+__global__ __launch_bounds__(NT, 2) void trsv_fwd_kernel(const TrsvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double wl[];  // TB x TB inverse block
+    __shared__ Shared s;
+    const int t = threadIdx.x, rp = t & 63, cg = __builtin_amdgcn_readfirstlane(t >> 6);  // cg: wave-uniform
+#pragma nounroll
+    for (int r = blockIdx.x; r < a.nblk; r += a.G) {
+        const int64_t r0 = (int64_t)r * TB;
+        double acc0 = 0.0, acc1 = 0.0;
+        double2 A[NC], B[NC];
+        stage_inverse(a, r, wl, rp, cg, A);
+        // tiles L[r, q], q = 0 .. r - 1, through two register buffers: while tile q is consumed, tile q + 1 is in flight --
+        // the loads do not depend on the hand-offs, only the FMAs do
+        if (r > 0) load_operand(tile_operand(a, r, 0), rp, cg, A);
+#pragma nounroll
+        for (int q = 0; q < r; q += 2) {
+            if (q + 1 < r) load_operand(tile_operand(a, r, q + 1), rp, cg, B);
+            if (!wait_block(a, q, s.xs[0], t)) return;
+            fwd_fma(A, s.xs[0], cg, acc0, acc1);
+            if (q + 1 >= r) break;
+            if (q + 2 < r) load_operand(tile_operand(a, r, q + 2), rp, cg, A);
+            if (!wait_block(a, q + 1, s.xs[1], t)) return;
+            fwd_fma(B, s.xs[1], cg, acc0, acc1);
+        }
+        // x_r = W_r (b_r - acc)
+        s.part[cg][2 * rp] = acc0;
+        s.part[cg][2 * rp + 1] = acc1;
+        __syncthreads();  // also: the staged inverse is complete
+        if (t < TB) s.tv[t] = (r0 + t < a.n) ? a.b[r0 + t] - sum_parts(s, t) : 0.0;
+        fetch_inverse(wl, rp, cg, A);
+        __syncthreads();
+        double q0 = 0.0, q1 = 0.0;
+        fwd_fma(A, s.tv, cg, q0, q1);
+        s.part[cg][2 * rp] = q0;
+        s.part[cg][2 * rp + 1] = q1;
+        __syncthreads();
+        if (t < TB) {
+            const double x = sum_parts(s, t);
+            publish_entry(a, r0 + t, x);  // first: the next owner is waiting for it
+            if (r0 + t < a.n) a.b[r0 + t] = x;
+        }
+        __syncthreads();  // wl / part / tv are reused by the next block of this workgroup
+    }
+}
+
+// ---- backward: L^T x = b --------------------------------------------------------------------------------------------
+// Block j needs every x_i below it: its owner streams the tiles L[i, j], i = nblk - 1 .. j + 1 (rows along the lanes, so the
+// loads stay coalesced) and keeps per-lane partial sums for its 16 columns; the 64-lane reduction happens once per block.
+__device__ __forceinline__ void bwd_fma(const double2 (&buf)[NC], double x0, double x1, double (&p)[NC])
+{
+#pragma unroll
+    for (int k = 0; k < NC; ++k) p[k] = __builtin_fma(buf[k].y, x1, __builtin_fma(buf[k].x, x0, p[k]));
+}
+
+// Sum p[k] over the 64 lanes of the wave for all NC = 16 k at once (recursive halving: 8 + 4 + 2 + 1 exchanges, then the two
+// remaining lane bits).  Returns, in every lane, the total of column (lane >> 2).
+__device__ __forceinline__ double wave_reduce_cols(double (&p)[NC], int lane)
+{
+    static_assert(NC == 16, "the halving below is written for 16 columns per lane");
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+        const int half = 8 >> step, bit = 32 >> step;
+        const bool hi = (lane & bit) != 0;
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+            const double send = hi ? p[k] : p[k + half];
+            const double keep = hi ? p[k + half] : p[k];
+            p[k] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+    double v = p[0] + __shfl_xor(p[0], 2, 64);
+    return v + __shfl_xor(v, 1, 64);
+}
+
+__global__ __launch_bounds__(NT, 2) void trsv_bwd_kernel(const TrsvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double wl[];
+    __shared__ Shared s;
+    const int t = threadIdx.x, rp = t & 63, cg = __builtin_amdgcn_readfirstlane(t >> 6);  // cg: wave-uniform
+#pragma nounroll
+    for (int jj = blockIdx.x; jj < a.nblk; jj += a.G) {
+        const int j = a.nblk - 1 - jj;
+        const int last = a.nblk - 1;
+        const int cnt = last - j;  // tiles L[last - q, j], q = 0 .. cnt - 1
+        const int64_t j0 = (int64_t)j * TB;
+        double p[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) p[k] = 0.0;
+        double2 A[NC], B[NC];
+        stage_inverse(a, j, wl, rp, cg, A);
+        if (cnt > 0) load_operand(tile_operand(a, last, j), rp, cg, A);
+#pragma nounroll
+        for (int q = 0; q < cnt; q += 2) {
+            if (q + 1 < cnt) load_operand(tile_operand(a, last - q - 1, j), rp, cg, B);
+            if (!wait_block(a, last - q, s.xs[0], t)) return;
+            {
+                const double2 x = *reinterpret_cast<const double2*>(&s.xs[0][2 * rp]);
+                bwd_fma(A, x.x, x.y, p);
+            }
+            if (q + 1 >= cnt) break;
+            if (q + 2 < cnt) load_operand(tile_operand(a, last - q - 2, j), rp, cg, A);
+            if (!wait_block(a, last - q - 1, s.xs[1], t)) return;
+            {
+                const double2 x = *reinterpret_cast<const double2*>(&s.xs[1][2 * rp]);
+                bwd_fma(B, x.x, x.y, p);
+            }
+        }
+        // x_j = W_j^T (b_j - u), u = column sums of the partial products
+        const int col = cg * NC + (rp >> 2);
+        const double u = wave_reduce_cols(p, rp);
+        if ((rp & 3) == 0) s.tv[col] = (j0 + col < a.n) ? a.b[j0 + col] - u : 0.0;
+        fetch_inverse(wl, rp, cg, A);
+        __syncthreads();  // tv complete (and, for cnt == 0, the staged inverse)
+        const double2 tt = *reinterpret_cast<const double2*>(&s.tv[2 * rp]);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) p[k] = __builtin_fma(A[k].y, tt.y, A[k].x * tt.x);
+        const double x = wave_reduce_cols(p, rp);
+        if ((rp & 3) == 0) {
+            publish_entry(a, j0 + col, x);
+            if (j0 + col < a.n) a.b[j0 + col] = x;
+        }
+        __syncthreads();
+    }
+}
+
+// b (n entries, device) <- L^-1 b or L^-T b with the factor's 128-block inverses.  One launch (+ one memset of the
+// hand-off granules).  Enqueued on ctx->ls.
+int launch_trsv(fr_ctx* ctx, const fr_chol* c, double* b, bool fwd, int prof_cls)
+{
+    const int64_t n = c->n;
+    if (n <= 0) return FR_OK;
+    const int nblk = (int)((n + TB - 1) / TB);
+    FR_TRY(ensure_status_word(ctx));
+    const size_t gran_bytes = sizeof(u64) * 2 * (size_t)nblk * TB;
+    if (ctx->trsv_gran_cap < gran_bytes) {
+        if (ctx->trsv_gran) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(ctx->trsv_gran);
+            ctx->trsv_gran = nullptr;
+            ctx->trsv_gran_cap = 0;
+        }
+        FR_HIP(ctx, dev_malloc(ctx, &ctx->trsv_gran, gran_bytes));
+        ctx->trsv_gran_cap = gran_bytes;
+    }
+    // tags are compared with a per-call epoch; zeroing the granules before EVERY launch keeps the protocol independent of
+    // whatever a previous (possibly aborted) call left behind (Guideline 16, "re-initialise every call")
+    FR_HIP(ctx, hipMemsetAsync(ctx->trsv_gran, 0, gran_bytes, ctx->ls));
+    TrsvArgs a;
+    a.L = c->A;
+    a.ld = c->ld_a;
+    a.n = n;
+    a.dinv = c->dinv;
+    a.b = b;
+    a.gran = (u64*)ctx->trsv_gran;
+    a.status = ctx->dev_status;
+    a.nblk = nblk;
+    a.G = nblk < ctx->num_cus ? nblk : ctx->num_cus;
+    a.epoch = 1u;
+    if (!ctx->trsv_lds_set) {  // per context (= per device): > 64 KiB of dynamic LDS needs the attribute
+        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_fwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSV_LDS));
+        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_bwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSV_LDS));
+        ctx->trsv_lds_set = true;
+    }
+    ProfScope ps(ctx, prof_cls, (double)n * (double)n, 4.0 * (double)n * (double)n);
+    if (fwd)
+        hipLaunchKernelGGL(trsv_fwd_kernel, dim3((unsigned)a.G), dim3(NT), TRSV_LDS, ctx->ls, a);
+    else
+        hipLaunchKernelGGL(trsv_bwd_kernel, dim3((unsigned)a.G), dim3(NT), TRSV_LDS, ctx->ls, a);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+}  // namespace fr

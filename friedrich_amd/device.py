@@ -312,6 +312,12 @@ class Cholesky:
         return out
 
     # src/gaussian_process/mod.rs ------------------------------------------------------------------
+    def set_targets(self, y):
+        """cache the residual training outputs: predict_mean(kernel, None, ...) then uses alpha = K^-1 y, solved once per
+        change of the factor (todo.md:10)"""
+        yp, _, keep = _vecptr(y)
+        self.ctx.check(self.lib.fr_chol_set_targets(self.h, yp))
+
     def likelihood(self, kernel, y, noise):
         p = C.kprog(kernel)
         yp, _, keep = _vecptr(y)

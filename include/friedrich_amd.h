@@ -189,7 +189,14 @@ void fr_chol_free(fr_chol* chol);
  * (m values, may be NULL for a zero prior); Xq is m x d. */
 /* likelihood (mod.rs:196-220) */
 int fr_likelihood(fr_chol* chol, const fr_kprog* kernel, const double* y, double noise, double* out);
-/* predict (mod.rs:226-244) */
+/* Cached alpha = K^-1 y (the reference's own todo.md:10 -- "cache K^-1 y").  Hands the residual
+ * training outputs (training_outputs.as_vector(), n values, host or device) to the factor; fr_predict_mean called with
+ * y == NULL then returns prior + K*^T alpha, solving K alpha = y (two single-column solves) only when the factor changed
+ * since the last solve (fr_chol_refactor, fr_chol_add_rows).  After fr_chol_add_rows the row count changed: hand the
+ * n_all outputs over again (GaussianProcess::add_samples, mod.rs:173-190, updates both).  Values agree with the reference's
+ * association (K^-1 K*)^T y to rounding. */
+int fr_chol_set_targets(fr_chol* chol, const double* y);
+/* predict (mod.rs:226-244).  y == NULL: use the targets / alpha cached by fr_chol_set_targets. */
 int fr_predict_mean(fr_chol* chol, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m,
                     int64_t ldq, const double* prior_q, double* out_mean);
 /* predict_variance (mod.rs:248-273) */

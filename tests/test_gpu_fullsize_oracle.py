@@ -76,7 +76,7 @@ def test_config1_n4096_factor_and_predict_variance_vs_oracle(ctx):
     with O.threads():
         st, L_o, idx = O.make_cholesky_cov_matrix_cols(k, X, hp["noise"])
         assert st == 0 and len(idx) == 0
-        L_o = np.tril(L_o)
+        L_o = np.asfortranarray(np.tril(L_o))
         kl = O.make_covariance_matrix(k, X, Xq)
         st, kl = O.solve_lower(L_o, kl)  # mod.rs:260-263
         assert st == 0
@@ -101,7 +101,7 @@ def test_config4_n8192_grown_factor_and_sample_at_vs_oracle(ctx):
     with O.threads():
         st, L_o, _ = O.make_cholesky_cov_matrix_cols(k, X, noise)
         assert st == 0
-        L_o = np.tril(L_o)
+        L_o = np.asfortranarray(np.tril(L_o))
     grown = ctx.cholesky_from_inputs(k, X[:n // 2], noise, capacity_hint=n)
     for hi in range(n // 2 + chunk, n + 1, chunk):
         grown.add_rows(k, X[:hi], chunk, noise)

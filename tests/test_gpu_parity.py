@@ -466,3 +466,66 @@ def test_concurrent_predict_from_threads(ctx):
     for (m0, v0), (m1, v1) in zip(expect, got):
         assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
     chol.free()
+
+
+# ---- cached alpha = K^-1 y (the reference's todo.md:10) ---------------------------------------
+def test_cached_alpha_interleaved_with_add_samples_and_refit(ctx):
+    """fr_chol_set_targets + predict with y = NULL: the cache is invalidated by add_samples (row count changes: targets have
+    to be handed over again) and by a re-fit (alpha re-solved lazily), and every prediction equals the oracle's predict of
+    the reference association.  Also the m = 1 persistent solves against the recursive path they replace."""
+    from friedrich_amd.device import FriedrichError
+
+    k = ("matern2", 0.8, 1.1)
+    d, n0 = 4, 700
+    chunks = [1, 130, 300]
+    total = n0 + sum(chunks)
+    Xall = rand_inputs(total, d, 91)
+    yall = np.sin(Xall.sum(axis=1)) + 0.2
+    Xq = rand_inputs(40, d, 92)
+    prior = O.ConstantPrior(0.1)
+    noise = 0.09
+    gp = O.OracleGP(prior, k, noise, None, Xall[:n0], yall[:n0])
+    chol = ctx.cholesky_from_inputs(k, Xall[:n0], noise)  # capacity == n0: growth reallocates the cache as well
+    pq = prior.prior(Xq)
+    with pytest.raises(FriedrichError):  # nothing cached yet
+        chol.predict_mean(k, None, Xq, pq)
+    chol.set_targets(gp.y)
+    assert rel_err(chol.predict_mean(k, None, Xq, pq), gp.predict(Xq)) < TOL
+    n = n0
+    for c in chunks:
+        gp.add_samples(Xall[n:n + c], yall[n:n + c])
+        chol.add_rows(k, np.asfortranarray(Xall[:n + c]), c, noise)
+        n += c
+        with pytest.raises(FriedrichError):  # the cached targets cover the old rows only
+            chol.predict_mean(k, None, Xq, pq)
+        chol.set_targets(gp.y)
+        assert rel_err(chol.predict_mean(k, None, Xq, pq), gp.predict(Xq)) < TOL
+        assert rel_err(chol.predict_mean(k, None, Xq, pq), chol.predict_mean(k, gp.y, Xq, pq)) < TOL
+    # re-fit with other hyper-parameters: same targets, alpha must follow the new factor
+    k2 = ("matern2", 0.6, 0.9)
+    gp2 = O.OracleGP(prior, k2, 0.12, None, Xall, yall)
+    chol.refactor(k2, 0.12)
+    assert rel_err(chol.predict_mean(k2, None, Xq, pq), gp2.predict(Xq)) < TOL
+    chol.free()
+
+
+@pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 300, 1000, 2049])
+def test_single_rhs_persistent_solves(ctx, n):
+    """m = 1: one persistent launch per direction (trsv.hip) vs the oracle, vs the recursive path (option trsv = 0), for
+    sizes around the 128-row block boundaries (partial last block, single block)."""
+    k = PD_KERNELS[0]
+    X = rand_inputs(n, 3, 1000 + n)
+    b = np.random.default_rng(n).standard_normal((n, 1))
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    chol = ctx.cholesky_from_inputs(k, X, 0.1)
+    z1, w1 = chol.solve(b), chol.solve_lower(b)
+    assert rel_err(z1, O.chol_solve(L_o, b)) < TOL
+    assert rel_err(w1, O.solve_lower(L_o, b)[1]) < TOL
+    ctx.set_option("trsv", 0)
+    try:
+        assert rel_err(chol.solve(b), z1) < 1e-11 and rel_err(chol.solve_lower(b), w1) < 1e-11
+    finally:
+        ctx.set_option("trsv", 1)
+    # repeated calls are deterministic bit for bit (fixed summation order, hand-off granules re-initialised per call)
+    assert np.array_equal(chol.solve(b), z1)
+    chol.free()
