@@ -22,6 +22,7 @@
 // the recursive GEMM formulation.
 #include "fr_internal.hpp"
 #include <algorithm>
+#include <chrono>
 
 #include "kprog_device.hpp"
 
@@ -71,16 +72,145 @@ static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, doubl
     return launch_potf2(ctx, A, ld, sb, 0, 3, 0.0, inv, IB, nullptr);
 }
 
+// ---- fused panel factorisation (panel.hip + the diagonal-block server of potf2.hip) ---------------------------------------
+struct Fused {
+    bool on = false;
+    int* ready = nullptr;
+    int* done = nullptr;
+    int* tdone = nullptr;
+};
+
+// Start the diagonal-block server for the factorisation of the n x n matrix at A: flags zeroed, server launched on its own
+// stream behind everything already queued on the current launch stream, and the host waits (microseconds) until the
+// server's workgroup is resident -- it needs a CU to itself, and the row-tile workgroups enqueued afterwards spin on it.
+static int fused_start(fr_ctx* ctx, Fused& f, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
+                       int64_t* info, int64_t nb, bool dist)
+{
+    f.on = false;
+    const int64_t nblk = (n + IB - 1) / IB;
+    if (!ctx->panel_fused || !ctx->stream3 || mode == 3 || nblk < 2) return FR_OK;
+    if (dist && ctx->world > 1) return FR_OK;  // the experimental variants are single-GPU only
+    FR_TRY(ensure_status_word(ctx));
+    if (ctx->panel_flags_cap < (size_t)(9 * nblk)) {
+        if (ctx->panel_flags) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream3);
+            (void)hipFree(ctx->panel_flags);
+            ctx->panel_flags = nullptr;
+            ctx->panel_flags_cap = 0;
+        }
+        const size_t cap = (size_t)(9 * nblk) + 2304;
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&ctx->panel_flags, sizeof(int) * cap));
+        ctx->panel_flags_cap = cap;
+    }
+    f.ready = ctx->panel_flags;  // 4 per block
+    f.done = f.ready + 4 * nblk;
+    f.tdone = f.done + nblk;  // 4 per block
+    // the previous users of the flags and of the matrix are ordered through the launch stream
+    FR_HIP(ctx, hipEventRecord(ctx->ev_server, ctx->ls));
+    FR_HIP(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_server, 0));
+    FR_HIP(ctx, hipMemsetAsync(ctx->panel_flags, 0, sizeof(int) * (size_t)(9 * nblk), ctx->stream3));
+    ServerArgs a;
+    a.A = A;
+    a.lda = ld;
+    a.n = n;
+    a.col0 = col0;
+    a.mode = mode;
+    a.sub = sub;
+    a.dinv = dinv;
+    a.info = info;
+    a.ready = f.ready;
+    a.done = f.done;
+    a.status = ctx->dev_status;
+    a.dbg = nullptr;
+    if (ctx->panel_debug && nblk <= 1024) {
+        if (!ctx->panel_dbg) {
+            void* h = nullptr;
+            FR_HIP(ctx, hipHostMalloc(&h, sizeof(unsigned long long) * 4 * 1024, hipHostMallocMapped));
+            ctx->panel_dbg = (unsigned long long*)h;
+        }
+        memset(ctx->panel_dbg, 0, sizeof(unsigned long long) * 4 * 1024);
+        void* d = nullptr;
+        FR_HIP(ctx, hipHostGetDevicePointer(&d, ctx->panel_dbg, 0));
+        a.dbg = (unsigned long long*)d;
+    }
+    a.token = ++ctx->server_token;
+    if (a.token == 0) a.token = ++ctx->server_token;
+    a.nblocks = (int)nblk;
+    a.own_world = dist ? ctx->world : 1;
+    a.own_rank = ctx->rank;
+    a.own_nb = nb;
+    FR_TRY(launch_potf2_server(ctx, ctx->stream3, a));
+    // the server must be resident before the first row-tile launch is enqueued
+    volatile unsigned* hs = ctx->host_status;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hs[1] != a.token) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            hs[0] = 1;  // whatever did start gives up
+            (void)hipStreamSynchronize(ctx->stream3);
+            hs[0] = 0;
+            return set_err(ctx, FR_HIP_ERROR, "the diagonal-block server did not start");
+        }
+    }
+    // every launch that writes the flags comes after the memset: order the launch stream behind it
+    // (the memset ran before the server started, and the server is running: every row-tile launch from here on finds
+    // zeroed flags)
+    f.on = true;
+    return FR_OK;
+}
+
+// The server exits by itself after its last block; the launch stream must not run ahead of it.
+static int fused_finish(fr_ctx* ctx, Fused& f, hipStream_t s)
+{
+    if (!f.on) return FR_OK;
+    f.on = false;
+    if (ctx->panel_fused == 3) {  // developer probe: the server was resident but unused -- release it
+        (void)hipStreamSynchronize(ctx->stream);
+        volatile unsigned* hs = ctx->host_status;
+        hs[0] = 1;
+        (void)hipStreamSynchronize(ctx->stream3);
+        hs[0] = 0;
+        return FR_OK;
+    }
+    FR_HIP(ctx, hipEventRecord(ctx->ev_server, ctx->stream3));
+    FR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_server, 0));
+    return FR_OK;
+}
+
+// error path: make the server (and every waiting row tile) give up, then clear the word
+static void fused_abort(fr_ctx* ctx, Fused& f)
+{
+    if (!f.on) return;
+    f.on = false;
+    if (ctx->host_status) {
+        volatile unsigned* hs = ctx->host_status;
+        hs[0] = 1;
+        (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+        hs[0] = 0;
+    }
+}
+
 // Factor the kb-wide column block starting at column k (rows k..n), which must already carry every update of the
 // earlier panels.  Recursive halving down to the 128-wide inverse blocks: the second half of the block is updated by
 // the first with ONE GEMM of depth kb/2 (instead of a depth-128 GEMM per 128 columns) -- the read-modify-write of the
 // result tile is a fixed cost per tile, so the deeper the contraction the closer the GEMM runs to the MFMA rate.
 static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
-                        double sub, double* dinv, int64_t* info, double* T)
+                        double sub, double* dinv, int64_t* info, double* T, const Fused* f = nullptr)
 {
+    // experimental: row-tile kernels; the diagonal blocks are factored by the resident server
+    if (f && f->on && ctx->panel_fused == 2) return launch_panel_tiles(ctx, A, ld, n, k, kb, dinv, f->ready, f->done, f->tdone);
     if (kb <= IB) {
         double* inv = dinv + (k / IB) * INV_ELEMS;
-        FR_TRY(factor_block128(ctx, A + k + k * ld, ld, kb, col0 + k, mode, sub, inv, info, T));
+        if (f && f->on && ctx->panel_fused != 3) {
+            // the block goes to the resident server (its own CU: ~55 us per block whatever else runs, instead of 150 - 265 us
+            // next to the trailing update) and the stream waits for it
+            const int64_t g = k / IB;
+            FR_TRY(launch_server_block(ctx, f->ready + 4 * g, f->done + g, ctx->dev_status));
+        } else {
+            FR_TRY(factor_block128(ctx, A + k + k * ld, ld, kb, col0 + k, mode, sub, inv, info, T));
+        }
         const int64_t below = n - (k + kb);
         if (below > 0) {
             // K5: panel TRSM  B <- B * L_kk^-T  as a GEMM against the explicit inverse (in place: one tile column)
@@ -90,14 +220,14 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
         return FR_OK;
     }
     const int64_t kb1 = ((kb / IB + 1) / 2) * IB;  // first half, a multiple of 128
-    FR_TRY(factor_panel(ctx, A, ld, n, k, kb1, col0, mode, sub, dinv, info, T));
+    FR_TRY(factor_panel(ctx, A, ld, n, k, kb1, col0, mode, sub, dinv, info, T, f));
     const int64_t below = n - (k + kb1);
     if (below > 0) {
         const double* P1 = A + (k + kb1) + k * ld;  // rows below the first half, its kb1 columns
         FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, kb - kb1, kb1, P1, ld, false, P1, ld, false, -1.0, 1.0,
                     A + (k + kb1) + (k + kb1) * ld, ld));
     }
-    return factor_panel(ctx, A, ld, n, k + kb1, kb - kb1, col0, mode, sub, dinv, info, T);
+    return factor_panel(ctx, A, ld, n, k + kb1, kb - kb1, col0, mode, sub, dinv, info, T, f);
 }
 
 // Multi-GPU: block column b (width nb) of the matrix being factored is owned by rank b % world.
@@ -136,8 +266,27 @@ static int exchange_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t
 // the panel then travels to every rank with one broadcast on the panel stream (so it overlaps the trailing updates
 // still running on the main stream), and every rank updates only the trailing block columns it owns.  Because every
 // panel is broadcast, each rank ends up holding the complete factor -- no final all-gather is needed.
+static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
+                              int64_t* info, int64_t nb, bool dist, const Fused* fz);
+
+// `pre`: a diagonal-block server started by the caller (before it queued the Gram assembly); otherwise one is started here.
 static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
-                         int64_t* info, int64_t nb, bool dist = false)
+                         int64_t* info, int64_t nb, bool dist = false, Fused* pre = nullptr)
+{
+    if (n <= 0) return FR_OK;
+    Fused local;
+    Fused* f = pre ? pre : &local;
+    if (!pre) FR_TRY(fused_start(ctx, *f, A, ld, n, col0, mode, sub, dinv, info, nb, dist));
+    const int st = potrf_blocked_impl(ctx, A, ld, n, col0, mode, sub, dinv, info, nb, dist, f);
+    if (st != FR_OK) {
+        fused_abort(ctx, *f);
+        return st;
+    }
+    return fused_finish(ctx, *f, ctx->stream);
+}
+
+static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
+                              int64_t* info, int64_t nb, bool dist, const Fused* fz)
 {
     if (n <= 0) return FR_OK;
     WsGuard tg(ctx), pg(ctx);
@@ -150,7 +299,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     if (!la) {
         for (int64_t k = 0; k < n; k += nb) {
             const int64_t kb = imin(nb, n - k);
-            FR_TRY(factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T));
+            FR_TRY(factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T, fz));
             const int64_t rest = n - (k + kb);
             if (rest > 0) {
                 // K6: trailing update, lower triangle only
@@ -179,7 +328,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     ctx->ls = S1;
     {
         const int64_t kb0 = imin(nb, n);
-        if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T);
+        if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, fz);
         if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
         if (st != FR_OK) return fail(st);
     }
@@ -203,7 +352,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         if (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess)
             return fail(FR_HIP_ERROR);
         ctx->ls = S1;
-        if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T);
+        if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, fz);
         if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
         if (st != FR_OK) return fail(st);
         if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
@@ -586,9 +735,16 @@ static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise,
     c->inv512_rows = 0;
     ++c->gen;
     FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
-    FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank,
-                           c->nb));
-    FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true));
+    // the diagonal-block server takes its CU while the chip is still idle: before the Gram assembly is queued
+    Fused fz;
+    FR_TRY(fused_start(ctx, fz, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true));
+    int gst = launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank,
+                              c->nb);
+    if (gst != FR_OK) {
+        fused_abort(ctx, fz);
+        return gst;
+    }
+    FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true, &fz));
     FR_TRY(chol_fetch_info(c));
     if (ctx->world > 1) FR_TRY(merge_info(c));
     if (c->fail_col >= 0)

@@ -303,6 +303,8 @@ int fr_ctx_create(fr_ctx** out, int device)
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
     if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo) != hipSuccess ||  // resident for a whole fit: a busy HIGH-priority queue throttles the dispatch of every other queue (measured: +16 % on the trailing updates)
+        hipEventCreateWithFlags(&ctx->ev_server, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_la, hipEventDisableTiming) != hipSuccess) {
         fr_ctx_destroy(ctx);
@@ -328,6 +330,13 @@ void fr_ctx_destroy(fr_ctx* ctx)
         if (b.p) (void)hipFree(b.p);
     if (ctx->trsv_gran) (void)hipFree(ctx->trsv_gran);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
+    if (ctx->stream3) {
+        (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipStreamDestroy(ctx->stream3);
+    }
+    if (ctx->ev_server) (void)hipEventDestroy(ctx->ev_server);
+    if (ctx->panel_flags) (void)hipFree(ctx->panel_flags);
+    if (ctx->panel_dbg) (void)hipHostFree(ctx->panel_dbg);
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamDestroy(ctx->stream2);
@@ -389,6 +398,35 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     }
     if (!strcmp(name, "splitk")) {
         ctx->splitk = value != 0;
+        return FR_OK;
+    }
+    if (!strcmp(name, "panel_debug")) {
+        ctx->panel_debug = value;
+        if (value == 2 && ctx->panel_dbg) {  // dump the last factorisation's server time stamps (us, relative)
+            const unsigned long long* t = ctx->panel_dbg;
+            double wait = 0, fac = 0, pub = 0;
+            int cnt = 0;
+            for (int g = 1; g < 1024 && t[4 * g + 3]; ++g) {
+                wait += (double)(t[4 * g + 1] - t[4 * (g - 1) + 3]);
+                fac += (double)(t[4 * g + 2] - t[4 * g + 1]);
+                pub += (double)(t[4 * g + 3] - t[4 * g + 2]);
+                ++cnt;
+            }
+            if (getenv("FR_PANEL_DEBUG_VERBOSE")) {
+                for (int g = 1; g < 40 && t[4 * g + 3]; ++g)
+                    fprintf(stderr, "  block %d: outside %.1f us, factor %.1f us\n", g, (double)(t[4 * g + 1] - t[4 * (g - 1) + 3]) / 100.0,
+                            (double)(t[4 * g + 2] - t[4 * g + 1]) / 100.0);
+            }
+            if (cnt)
+                fprintf(stderr, "panel server: %d blocks, per block: turnaround outside the server %.1f us, factor %.1f us, publish %.1f us\n",
+                        cnt, wait / cnt / 100.0, fac / cnt / 100.0, pub / cnt / 100.0);
+            ctx->panel_debug = 1;
+        }
+        return FR_OK;
+    }
+    if (!strcmp(name, "panel_fused")) {
+        if (value < 0 || value > 3) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_fused must be 0, 1, 2 (or the probe value 3)");
+        ctx->panel_fused = value;
         return FR_OK;
     }
     if (!strcmp(name, "trsv")) {

@@ -60,6 +60,18 @@ struct fr_ctx {
     int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
     int64_t gemm_lower_probe = 0;  // probe: fr_gemm computes only the lower-triangular tile set of a square result
     bool potf2_lds_set = false;  // dynamic-LDS attribute of the diagonal-block kernel applied on this device
+    bool potf2_server_lds_set = false;
+    // Experimental panel-factorisation variants, measured in round 2 and NOT adopted: 0 (default): one
+    // diagonal-block launch per 128 columns; 1: the diagonal blocks go to a resident server workgroup on a CU of its own
+    // (potf2.hip), handed over at stream level; 2: fused row-tile kernels (panel.hip); 3: probe (server resident, unused)
+    int64_t panel_fused = 0;
+    hipStream_t stream3 = nullptr;  // the diagonal-block server's stream
+    hipEvent_t ev_server = nullptr;
+    int* panel_flags = nullptr;     // ready (4 per 128-block) / done (1) / tdone (4), grow-only
+    size_t panel_flags_cap = 0;     // ints
+    unsigned server_token = 0;
+    int64_t panel_debug = 0;              // developer probe: the server records time stamps per block
+    unsigned long long* panel_dbg = nullptr;  // host-mapped, 4 x 1024 entries
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
     // profiling
@@ -249,6 +261,30 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 //   mode 3: the block already holds a factor, only the inverse is produced
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub,
                  double* inv, int64_t ldinv, int64_t* info);
+
+// Fused panel factorisation (potf2.hip server + panel.hip row tiles).  Flags: one int per 128-block of the matrix.
+struct ServerArgs {
+    double* A;        // the n x n matrix being factored (lower triangle), block g at A + 128 g (lda + 1)
+    int64_t lda, n, col0;
+    int mode;
+    double sub;
+    double* dinv;     // inverse of block g at dinv + g * 128 * 128
+    int64_t* info;
+    int* ready;       // [4 g + a] = 1: 32-row slice a of diagonal block g carries every update; all four: it may be factored
+    int* done;        // [g] = 1: block g factored, inverse written
+    unsigned* status; // host-visible: [0] timeout word, [1] <- token when the server workgroup is resident
+    unsigned token;
+    unsigned long long* dbg;  // developer probe: 4 time stamps per block, or NULL
+    int nblocks;
+    int own_world, own_rank;
+    int64_t own_nb;
+};
+int launch_potf2_server(fr_ctx* ctx, hipStream_t stream, const ServerArgs& a);
+// hand block over to the server (ready4: its 4 ready flags) and hold the launch stream until it is factored
+int launch_server_block(fr_ctx* ctx, int* ready4, const int* done, unsigned* status);
+// one launch per panel: rows k .. n of the kb columns starting at k; enqueued on ctx->ls
+int launch_panel_tiles(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv,
+                       int* ready, int* done, int* tdone);
 
 // small helpers (elementwise / reductions)
 int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v);

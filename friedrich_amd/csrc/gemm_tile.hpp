@@ -1,0 +1,315 @@
+// gemm_tile.hpp -- device code of the FP64 matrix-core GEMM tile (see gemm_f64.hip for the design notes): shared by the
+// GEMM kernels (gemm_f64.hip) and the fused panel kernel (panel.hip).
+#pragma once
+
+#include "fr_internal.hpp"
+
+namespace fr {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int S_MMAJ = 144;  // [BK][144]
+constexpr int S_KMAJ = 18;   // [128][18]
+constexpr int TILE_ELEMS = 2304;  // 16*144 == 128*18
+
+struct GemmArgs {
+    int64_t M, N, K;
+    const double* A;
+    int64_t lda;
+    const double* B;
+    int64_t ldb;
+    const double* Cin;
+    int64_t ldcin;
+    double* D;
+    int64_t ldd;
+    double alpha, beta;
+    int lower;
+    int64_t tiles_m, tiles_n;
+    int sw_log2;                       // super-tile = (64 >> sw_log2) x (1 << sw_log2) tiles
+    int64_t super_m, nsuper, per_xcd;  // super-tiles along m, in total, per XCD
+    // multi-GPU column ownership: a tile is computed only by the rank owning its block column
+    // ((own_col0 + n0) / own_nb) % own_world == own_rank; own_world <= 1 disables the filter
+    int own_world, own_rank;
+    int64_t own_nb, own_col0;
+    // batch: blockIdx.y selects a problem; operands advance by these strides (elements)
+    int64_t batch_a, batch_b, batch_c, batch_d;
+};
+
+// element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile
+template <bool KMAJ>
+__device__ __forceinline__ int lds_idx(int x, int k)
+{
+    return KMAJ ? x * S_KMAJ + k : k * S_MMAJ + x;
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void load_tile(const double* __restrict__ P, int64_t ld, int64_t x0, int64_t X, int64_t k0,
+                                          int64_t K, int t, double (&reg)[8])
+{
+    if (!KMAJ) {
+        const int x = t & 127;
+        const bool xok = (x0 + x) < X;
+        const double* p = P + (x0 + x) + k0 * ld;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = (t >> 7) + 2 * i;
+            reg[i] = (xok && (k0 + k) < K) ? p[(int64_t)k * ld] : 0.0;
+        }
+    } else {
+        const int k = t & 15;
+        const bool kok = (k0 + k) < K;
+        const double* p = P + (k0 + k) + x0 * ld;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = (t >> 4) + 16 * i;
+            reg[i] = (kok && (x0 + x) < X) ? p[(int64_t)x * ld] : 0.0;
+        }
+    }
+}
+
+// Branch-free variant for tiles that lie entirely inside the operand (every tile but the last row / column of
+// tiles, every K-step but a ragged last one).  The predicated loader above compiles to one exec-masked branch per
+// element -- ~300 scalar/branch instructions per K-step in front of the MFMAs -- so the hot path must avoid it.
+template <bool KMAJ>
+__device__ __forceinline__ void load_tile_fast(const double* __restrict__ p, int64_t ld, double (&reg)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reg[i] = p[(int64_t)(KMAJ ? 16 * i : 2 * i) * ld];
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ const double* tile_thread_base(const double* P, int64_t ld, int64_t x0, int t)
+{
+    return KMAJ ? P + (t & 15) + (x0 + (t >> 4)) * ld : P + (x0 + (t & 127)) + (int64_t)(t >> 7) * ld;
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void store_tile(double* __restrict__ S, int t, const double (&reg)[8])
+{
+    if (!KMAJ) {
+        const int x = t & 127;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) S[((t >> 7) + 2 * i) * S_MMAJ + x] = reg[i];
+    } else {
+        const int k = t & 15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) S[((t >> 4) + 16 * i) * S_KMAJ + k] = reg[i];
+    }
+}
+
+// One 128 x 128 result tile at (m0, n0): the whole K-loop and the epilogue.  Called by the GEMM kernels (one tile per
+// workgroup) and by the fused panel kernel (panel.hip: a workgroup walks through the tile products of its row tile).
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, const int64_t m0, const int64_t n0)
+{
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    d4_t acc[4][4];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    const int64_t nk = (g.K + BK - 1) / BK;
+    const int64_t nk_full = g.K / BK;  // K-steps that need no k predicate
+    const bool a_fast = (m0 + BM) <= g.M, b_fast = (n0 + BN) <= g.N;
+    // per-thread pointers of the branch-free loader, advanced by one K-step at a time
+    const double* pa = tile_thread_base<A_KMAJ>(g.A, g.lda, m0, t);
+    const double* pb = tile_thread_base<B_KMAJ>(g.B, g.ldb, n0, t);
+    const int64_t step_a = A_KMAJ ? BK : BK * g.lda, step_b = B_KMAJ ? BK : BK * g.ldb;
+    double ra[8], rb[8];
+    if (nk > 0) {
+        if (a_fast && nk_full > 0)
+            load_tile_fast<A_KMAJ>(pa, g.lda, ra);
+        else
+            load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, 0, g.K, t, ra);
+        // op(B) element (k, n): B_KMAJ -> B[k + n*ldb] (k contiguous), else B[n + k*ldb]
+        if (b_fast && nk_full > 0)
+            load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+        else
+            load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, 0, g.K, t, rb);
+        store_tile<A_KMAJ>(lds, t, ra);
+        store_tile<B_KMAJ>(lds + TILE_ELEMS, t, rb);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    if (a_fast && b_fast && nk_full == nk) {
+        // Interior tile, K a multiple of 16: one branch-free basic block per K-step, with the instruction order
+        // pinned by sched_group_barrier.  A wave issues its next MFMA only when the matrix pipe is free (64 cycles
+        // each), so everything else -- the 16 global loads of the next K-slice, the LDS fragment reads of the next
+        // k-substep, the 16 LDS stores of the prefetched slice -- is slotted BETWEEN MFMAs instead of in front of /
+        // behind the 64-MFMA block, which leaves only the barrier and the first fragment read exposed per K-step.
+        // The last K-step re-loads its own slice (pointer not advanced) into the unused buffer: harmless, and it
+        // keeps the loop body free of branches.
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1) < nk;
+            pa += more ? step_a : 0;
+            pb += more ? step_b : 0;
+            load_tile_fast<A_KMAJ>(pa, g.lda, ra);
+            load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+            const double* As = lds + cur * 2 * TILE_ELEMS;
+            const double* Bs = As + TILE_ELEMS;
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const int kq = ks * 4 + lq;
+                double af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = As[lds_idx<A_KMAJ>(wm * 64 + i * 16 + l15, kq)];
+                    bf[i] = Bs[lds_idx<B_KMAJ>(wn * 64 + i * 16 + l15, kq)];
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            }
+            double* An = lds + (cur ^ 1) * 2 * TILE_ELEMS;
+            store_tile<A_KMAJ>(An, t, ra);
+            store_tile<B_KMAJ>(An + TILE_ELEMS, t, rb);
+            // pipeline description (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // fragments of k-substep 0
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // k-substep 0: 16 MFMA + the 16 global loads (+ fragments of substep 1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                if (j >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int ks = 1; ks < 3; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // k-substeps 1, 2: 16 MFMA + the fragments of the next substep
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (j >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // k-substep 3: 16 MFMA + the 16 LDS stores of the prefetched slice
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1) < nk;
+            if (more) {
+                pa += step_a;
+                pb += step_b;
+                const bool kfull = (kt + 1) < nk_full;
+                if (a_fast && kfull)
+                    load_tile_fast<A_KMAJ>(pa, g.lda, ra);
+                else
+                    load_tile<A_KMAJ>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, t, ra);
+                if (b_fast && kfull)
+                    load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+                else
+                    load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, t, rb);
+            }
+            const double* As = lds + cur * 2 * TILE_ELEMS;
+            const double* Bs = As + TILE_ELEMS;
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const int kq = ks * 4 + lq;
+                double af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = As[lds_idx<A_KMAJ>(wm * 64 + i * 16 + l15, kq)];
+                    bf[i] = Bs[lds_idx<B_KMAJ>(wn * 64 + i * 16 + l15, kq)];
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            }
+            if (more) {
+                double* An = lds + (cur ^ 1) * 2 * TILE_ELEMS;
+                store_tile<A_KMAJ>(An, t, ra);
+                store_tile<B_KMAJ>(An + TILE_ELEMS, t, rb);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // epilogue: accumulator register r of tile (nt, mt) holds D[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
+    //
+    // D may alias Cin, so the compiler must keep every Cin load behind the preceding D stores; a naive
+    // load-modify-store loop therefore pays one full memory round trip per element (64 per lane).  The loads
+    // of a whole 16-column strip are issued back to back into registers, one strip ahead of the stores.
+    const bool use_c = g.beta != 0.0;
+    const bool interior = a_fast && b_fast;  // whole 128 x 128 tile inside D: no per-element predicate
+    auto c_index = [&](int nt, int r, int mt, int64_t& m, int64_t& n) {
+        n = n0 + wn * 64 + nt * 16 + lq + 4 * r;
+        m = m0 + wm * 64 + mt * 16 + l15;
+    };
+    if (interior && use_c) {
+        // Interior tile: straight-line code, THREE of the four 16-column strips of C in flight at once (the registers of
+        // the K-loop's prefetch / fragment buffers are dead here); the fourth is issued as soon as strip 0 is stored.
+        // Measured before this change: the epilogue was 38 % of a K = 512 tile's lifetime (4 dependent round trips).
+        const double* cbase = g.Cin + (m0 + wm * 64 + l15) + (n0 + wn * 64 + lq) * g.ldcin;
+        double* dbase = g.D + (m0 + wm * 64 + l15) + (n0 + wn * 64 + lq) * g.ldd;
+        double c0[16], c1[16], c2[16];
+        auto ld_strip = [&](int nt, double (&c)[16]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) c[r * 4 + mt] = cbase[mt * 16 + (int64_t)(nt * 16 + 4 * r) * g.ldcin];
+        };
+        auto st_strip = [&](int nt, const double (&c)[16]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    dbase[mt * 16 + (int64_t)(nt * 16 + 4 * r) * g.ldd] = g.alpha * acc[nt][mt][r] + g.beta * c[r * 4 + mt];
+        };
+        ld_strip(0, c0);
+        ld_strip(1, c1);
+        ld_strip(2, c2);
+        st_strip(0, c0);
+        ld_strip(3, c0);
+        st_strip(1, c1);
+        st_strip(2, c2);
+        st_strip(3, c0);
+        return;
+    }
+    double cv[2][16];
+    auto load_strip = [&](int nt, double (&c)[16]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                int64_t m, n;
+                c_index(nt, r, mt, m, n);
+                c[r * 4 + mt] = (n < g.N && m < g.M) ? g.Cin[m + n * g.ldcin] : 0.0;
+            }
+        }
+    };
+    if (use_c) load_strip(0, cv[0]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        if (use_c && nt + 1 < 4) load_strip(nt + 1, cv[(nt + 1) & 1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                int64_t m, n;
+                c_index(nt, r, mt, m, n);
+                double v = g.alpha * acc[nt][mt][r];
+                if (use_c) v += g.beta * cv[nt & 1][r * 4 + mt];
+                if (n < g.N && m < g.M) g.D[m + n * g.ldd] = v;
+            }
+        }
+    }
+}
+
+
+}  // namespace fr
