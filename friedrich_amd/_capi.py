@@ -88,6 +88,7 @@ SIGNATURES = {
     "fr_chol_from_matrix": (_int, [_vp, _dp, _i64, _i64, _int, _dbl, _pp]),
     "fr_chol_add_rows": (_int, [_vp, _kp, _dp, _i64, _i64, _i64, _i64, _dbl]),
     "fr_chol_info": (_int, [_vp, _pi64, _pi64, _pi64, _pi64, _pi64]),
+    "fr_chol_conditioning": (_int, [_vp, _pdbl, _pint]),
     "fr_chol_substitutions": (_int, [_vp, _pi64, _i64]),
     "fr_chol_solve": (_int, [_vp, _dp, _i64, _i64]),
     "fr_chol_solve_lower": (_int, [_vp, _dp, _i64, _i64]),

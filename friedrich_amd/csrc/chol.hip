@@ -59,11 +59,13 @@ static int gemm(fr_ctx* ctx, int cls, int64_t M, int64_t N, int64_t K, const dou
     return launch_gemm(ctx, g);
 }
 
+static inline int64_t ctx_cest_col0(const fr_ctx*) { return 0; }  // estimates are only kept for whole-matrix factorisations (col0 == 0)
+
 // Factor the sb x sb (sb <= 128) diagonal block at A and produce its inverse in `inv` (ld 128): one K4 launch.
 static int factor_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, int64_t col, int mode, double sub, double* inv,
                            int64_t* info, double* /*T*/)
 {
-    return launch_potf2(ctx, A, ld, sb, col, mode, sub, inv, IB, info);
+    return launch_potf2(ctx, A, ld, sb, col, mode, sub, inv, IB, info, ctx->cur_cest ? ctx->cur_cest + (col - ctx_cest_col0(ctx)) / IB : nullptr);
 }
 
 // Rebuild the inverse of an already factored 128-block (serde upload, add_rows re-alignment).
@@ -215,7 +217,26 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
         if (below > 0) {
             // K5: panel TRSM  B <- B * L_kk^-T  as a GEMM against the explicit inverse (in place: one tile column)
             double* B = A + (k + kb) + k * ld;
-            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, kb, kb, B, ld, false, inv, IB, false, 1.0, 0.0, B, ld));
+            if (ctx->refine_now && T) {
+                // one step of iterative refinement against the triangular factor itself (its strict upper triangle was
+                // zeroed by the diagonal-block kernel):  X0 = B W^T;  R = B - X0 L^T;  X = X0 + R W^T.  The explicit inverse
+                // alone leaves a residual of cond(L_kk) u; after the step it is what substitution would leave.
+                const double* Lkk = A + k + k * ld;
+                GemmDesc g;
+                g.M = below; g.N = kb; g.K = kb;
+                g.A = B; g.lda = ld; g.a_kmajor = false;
+                g.B = inv; g.ldb = IB; g.b_kmajor = false;
+                g.Cin = T; g.ldcin = below; g.D = T; g.ldd = below;
+                g.alpha = 1.0; g.beta = 0.0; g.lower = false; g.prof_cls = FR_PROF_GEMM_PANEL;
+                FR_TRY(launch_gemm(ctx, g));                                      // X0 -> T
+                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, kb, kb, T, below, false, Lkk, ld, false, -1.0, 1.0, B, ld));  // R (in B)
+                g.A = B; g.lda = ld;
+                g.Cin = T; g.ldcin = below; g.D = B; g.ldd = ld;
+                g.alpha = 1.0; g.beta = 1.0;
+                FR_TRY(launch_gemm(ctx, g));                                      // B <- X0 + R W^T  (in place: one tile column)
+            } else {
+                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, kb, kb, B, ld, false, inv, IB, false, 1.0, 0.0, B, ld));
+            }
         }
         return FR_OK;
     }
@@ -290,8 +311,11 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
 {
     if (n <= 0) return FR_OK;
     WsGuard tg(ctx), pg(ctx);
-    double* T = tg.get(sizeof(double) * 64 * 64);
-    if (!T) return FR_OUT_OF_MEMORY;
+    double* T = nullptr;  // scratch of the refined panel solves (rows below a block x 128)
+    if (ctx->refine_now) {
+        T = tg.get(sizeof(double) * (size_t)n * (size_t)IB);
+        if (!T) return FR_OUT_OF_MEMORY;
+    }
     const int world = dist ? ctx->world : 1;
     const int rank = ctx->rank;
     if (world > 1 && nb % IB != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "multi-GPU factorisation needs nb %% 128 == 0");
@@ -451,16 +475,40 @@ static int leaf512(fr_ctx* ctx, const fr_chol* c, int64_t row0, double* B, int64
     return gemm(ctx, cls, LB, m, LB, W, LB, !fwd, tmp, LB, true, 1.0, 0.0, B, ldb);
 }
 
+// One 128-row leaf with a step of iterative refinement (handles with fr_chol::refine):  X0 = W B;  R = B - L_bb X0;
+// X = X0 + W R  (forward; backward with the transposes).  tmp: n x m scratch (ld 128).
+static int refined_leaf(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* B, int64_t m, int64_t ldb, int cls,
+                        bool fwd, double* tmp)
+{
+    const double* W = c->dinv + (row0 / IB) * INV_ELEMS;
+    const double* Lbb = c->A + row0 + row0 * c->ld_a;
+    GemmDesc g;
+    g.M = n; g.N = m; g.K = n;
+    g.A = W; g.lda = IB; g.a_kmajor = !fwd;
+    g.B = B; g.ldb = ldb; g.b_kmajor = true;
+    g.Cin = tmp; g.ldcin = IB; g.D = tmp; g.ldd = IB;
+    g.alpha = 1.0; g.beta = 0.0; g.lower = false; g.prof_cls = cls;
+    FR_TRY(launch_gemm(ctx, g));  // X0 -> tmp
+    FR_TRY(gemm(ctx, cls, n, m, n, Lbb, c->ld_a, !fwd, tmp, IB, true, -1.0, 1.0, B, ldb));  // R = B - op(L_bb) X0 (in B)
+    g.Cin = tmp; g.ldcin = IB; g.D = B; g.ldd = ldb;
+    g.beta = 1.0;
+    return launch_gemm(ctx, g);  // B <- X0 + op(W) R   (in place: one tile row)
+}
+
 // B (n x m) <- L^-1 B.  row0 = first row of this sub-problem in the factor; tmp != nullptr enables the 512-row leaves
 static int trsm_fwd_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* B, int64_t m, int64_t ldb, int cls,
                         double* tmp)
 {
     const double* L = c->A + row0 + row0 * c->ld_a;
     const int64_t ld = c->ld_a;
-    if (tmp && n == LB && row0 % LB == 0 && row0 + LB <= c->inv512_rows) return leaf512(ctx, c, row0, B, m, ldb, cls, true, tmp);
-    if (n <= IB) return gemm(ctx, cls, n, m, n, c->dinv + (row0 / IB) * INV_ELEMS, IB, false, B, ldb, true, 1.0, 0.0, B, ldb);
+    if (!c->refine && tmp && n == LB && row0 % LB == 0 && row0 + LB <= c->inv512_rows) return leaf512(ctx, c, row0, B, m, ldb, cls, true, tmp);
+    if (n <= IB) {
+        const double* W = c->dinv + (row0 / IB) * INV_ELEMS;
+        if (c->refine && tmp) return refined_leaf(ctx, c, row0, n, B, m, ldb, cls, true, tmp);
+        return gemm(ctx, cls, n, m, n, W, IB, false, B, ldb, true, 1.0, 0.0, B, ldb);
+    }
     // split at a multiple of 512 while the problem is larger than a leaf (so that the leaves line up with the blocks)
-    const int64_t n1 = (tmp && n > LB) ? (((n + LB - 1) / LB) / 2) * LB : split128(n);
+    const int64_t n1 = (!c->refine && tmp && n > LB) ? (((n + LB - 1) / LB) / 2) * LB : split128(n);
     FR_TRY(trsm_fwd_rec(ctx, c, row0, n1, B, m, ldb, cls, tmp));
     FR_TRY(gemm(ctx, cls, n - n1, m, n1, L + n1, ld, false, B, ldb, true, -1.0, 1.0, B + n1, ldb));
     return trsm_fwd_rec(ctx, c, row0 + n1, n - n1, B + n1, m, ldb, cls, tmp);
@@ -472,9 +520,13 @@ static int trsm_bwd_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, 
 {
     const double* L = c->A + row0 + row0 * c->ld_a;
     const int64_t ld = c->ld_a;
-    if (tmp && n == LB && row0 % LB == 0 && row0 + LB <= c->inv512_rows) return leaf512(ctx, c, row0, B, m, ldb, cls, false, tmp);
-    if (n <= IB) return gemm(ctx, cls, n, m, n, c->dinv + (row0 / IB) * INV_ELEMS, IB, true, B, ldb, true, 1.0, 0.0, B, ldb);
-    const int64_t n1 = (tmp && n > LB) ? (((n + LB - 1) / LB) / 2) * LB : split128(n);
+    if (!c->refine && tmp && n == LB && row0 % LB == 0 && row0 + LB <= c->inv512_rows) return leaf512(ctx, c, row0, B, m, ldb, cls, false, tmp);
+    if (n <= IB) {
+        const double* W = c->dinv + (row0 / IB) * INV_ELEMS;
+        if (c->refine && tmp) return refined_leaf(ctx, c, row0, n, B, m, ldb, cls, false, tmp);
+        return gemm(ctx, cls, n, m, n, W, IB, true, B, ldb, true, 1.0, 0.0, B, ldb);
+    }
+    const int64_t n1 = (!c->refine && tmp && n > LB) ? (((n + LB - 1) / LB) / 2) * LB : split128(n);
     FR_TRY(trsm_bwd_rec(ctx, c, row0 + n1, n - n1, B + n1, m, ldb, cls, tmp));
     // B1 -= L21^T * B2    (op(A)[m][k] = L21[k][m]: k-major)
     FR_TRY(gemm(ctx, cls, n1, m, n - n1, L + n1, ld, true, B + n1, ldb, true, -1.0, 1.0, B, ldb));
@@ -559,6 +611,12 @@ static bool wide_solve(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
+    if (c->refine) {  // ill-conditioned diagonal blocks: 128-row leaves with a refinement step each
+        WsGuard w(ctx);
+        double* tmp = w.get(sizeof(double) * (size_t)IB * (size_t)m);
+        if (!tmp) return FR_OUT_OF_MEMORY;
+        return trsm_fwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
+    }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, true, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, true);
     WsGuard w(ctx);
@@ -574,6 +632,12 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
 int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
+    if (c->refine) {
+        WsGuard w(ctx);
+        double* tmp = w.get(sizeof(double) * (size_t)IB * (size_t)m);
+        if (!tmp) return FR_OUT_OF_MEMORY;
+        return trsm_bwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
+    }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, false, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, false);
     WsGuard w(ctx);
@@ -593,6 +657,8 @@ static void chol_release(fr_chol* c)
     if (c->dinv) (void)hipFree(c->dinv);
     if (c->info) (void)hipFree(c->info);
     if (c->inv512) (void)hipFree(c->inv512);
+    if (c->cest) (void)hipFree(c->cest);
+    c->cest = nullptr;
     if (c->yt) (void)hipFree(c->yt);
     if (c->alpha) (void)hipFree(c->alpha);
     c->yt = c->alpha = nullptr;
@@ -627,6 +693,7 @@ static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t
     if (e == hipSuccess && d > 0) e = dev_malloc(ctx, (void**)&c->X, sizeof(double) * (size_t)c->ld_x * (size_t)d);
     if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->dinv, sizeof(double) * (size_t)nblk * INV_ELEMS);
     if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->info, sizeof(int64_t) * (size_t)c->info_cap);
+    if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->cest, sizeof(double) * (size_t)nblk);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         chol_release(c);
@@ -729,9 +796,57 @@ int potrf_matrix_ws(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int mode, dou
 }
 
 // Gram (lower + noise^2) from the resident inputs, then the factorisation; fills the host info mirror.
+static int assemble_and_factor_once(fr_chol* c, const fr_kprog* kernel, double noise, int has_eps, double eps);
+
+// The largest conditioning estimate of the diagonal blocks of the factorisation that just ran (stream synchronised).
+static int fetch_max_cest(fr_chol* c)
+{
+    fr_ctx* ctx = c->ctx;
+    const int64_t nblk = (c->n + IB - 1) / IB;
+    c->max_cest = 0.0;
+    if (nblk <= 0 || !c->cest) return FR_OK;
+    std::vector<double> h((size_t)nblk);
+    FR_HIP(ctx, hipMemcpyAsync(h.data(), c->cest, sizeof(double) * (size_t)nblk, hipMemcpyDeviceToHost, ctx->stream));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (double v : h)
+        if (v > c->max_cest) c->max_cest = v;  // (NaN: a failed block, reported through fail_col)
+    return FR_OK;
+}
+
+// Gram + factorisation with the refinement policy of fr_ctx::refine: automatic = factor with the plain explicit-inverse
+// products; if a diagonal block turns out ill-conditioned, factor once more with a refinement step behind every such
+// product, and keep refining on this handle until a refined factorisation sees well-conditioned blocks again.
 static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise, int has_eps, double eps)
 {
     fr_ctx* ctx = c->ctx;
+    const bool sharded = ctx->world > 1;  // (the ranks would have to agree on the decision: not refined when sharded)
+    if (ctx->refine == 0 || sharded) c->refine = false;
+    if (ctx->refine == 1 && !sharded) c->refine = true;
+    int st = assemble_and_factor_once(c, kernel, noise, has_eps, eps);
+    if (sharded || ctx->refine != -1 || (st != FR_OK && st != FR_NOT_POSITIVE_DEFINITE)) return st;
+    const bool ill = c->max_cest > ctx->refine_threshold;
+    if (!c->refine && ill) {
+        c->refine = true;
+        st = assemble_and_factor_once(c, kernel, noise, has_eps, eps);
+    } else if (c->refine && c->max_cest * 4.0 < ctx->refine_threshold) {
+        c->refine = false;  // the next factorisation takes the plain products again
+    }
+    return st;
+}
+
+static int assemble_and_factor_once(fr_chol* c, const fr_kprog* kernel, double noise, int has_eps, double eps)
+{
+    fr_ctx* ctx = c->ctx;
+    struct Scope {  // per-operation state of the context (entry points hold its lock)
+        fr_ctx* ctx;
+        ~Scope()
+        {
+            ctx->refine_now = false;
+            ctx->cur_cest = nullptr;
+        }
+    } scope{ctx};
+    ctx->refine_now = c->refine;
+    ctx->cur_cest = c->cest;
     c->inv512_rows = 0;
     ++c->gen;
     FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
@@ -746,6 +861,7 @@ static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise,
     }
     FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true, &fz));
     FR_TRY(chol_fetch_info(c));
+    FR_TRY(fetch_max_cest(c));
     if (ctx->world > 1) FR_TRY(merge_info(c));
     if (c->fail_col >= 0)
         return set_err(ctx, FR_NOT_POSITIVE_DEFINITE,
@@ -803,6 +919,8 @@ static int chol_grow(fr_chol* c, int64_t required)
     c->X = nc.X;
     c->dinv = nc.dinv;
     c->info = nc.info;
+    c->cest = nc.cest;
+    nc.cest = nullptr;
     c->capacity = nc.capacity;
     c->ld_a = nc.ld_a;
     c->ld_x = nc.ld_x;
@@ -903,6 +1021,11 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     if (n_old > 0) FR_TRY(check_zero_diag(c, "Cholesky::insert_column: Unable to solve lower triangular system!"));
     // (the cached 512-block inverses stay valid: rows below n_old are appended, blocks inside the old factor do not change)
     FR_TRY(chol_grow(c, n_all));
+    struct Scope {
+        fr_ctx* ctx;
+        ~Scope() { ctx->refine_now = false; }
+    } scope{ctx};
+    ctx->refine_now = c->refine;
     ++c->gen;  // cached alpha is stale; the targets cover n_old rows only and have to be handed over again
     c->nb = pick_nb(ctx, n_all);
     // new rows of the EMatrix mirror
@@ -962,6 +1085,14 @@ int fr_chol_info(const fr_chol* c, int64_t* n, int64_t* capacity, int64_t* d, in
     if (d) *d = c->d;
     if (n_subst) *n_subst = c->n_subst;
     if (fail_col) *fail_col = c->fail_col;
+    return FR_OK;
+}
+
+int fr_chol_conditioning(const fr_chol* c, double* max_estimate, int* refined)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    if (max_estimate) *max_estimate = c->max_cest;
+    if (refined) *refined = c->refine ? 1 : 0;
     return FR_OK;
 }
 

@@ -329,6 +329,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
     for (auto& b : ctx->pool)
         if (b.p) (void)hipFree(b.p);
     if (ctx->trsv_gran) (void)hipFree(ctx->trsv_gran);
+    if (ctx->syrk_ctr) (void)hipFree(ctx->syrk_ctr);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
@@ -427,6 +428,25 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "panel_fused")) {
         if (value < 0 || value > 3) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_fused must be 0, 1, 2 (or the probe value 3)");
         ctx->panel_fused = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "refine")) {
+        if (value < -1 || value > 1) return set_err(ctx, FR_INVALID_ARGUMENT, "refine must be -1 (automatic), 0 or 1");
+        ctx->refine = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "refine_threshold")) {
+        if (value < 1) return set_err(ctx, FR_INVALID_ARGUMENT, "refine_threshold must be >= 1");
+        ctx->refine_threshold = (double)value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "syrk_dynamic_tiles")) {
+        if (value < 1 || value > 1024) return set_err(ctx, FR_INVALID_ARGUMENT, "syrk_dynamic_tiles must be in [1, 1024]");
+        ctx->syrk_dynamic_tiles = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "syrk_dynamic")) {
+        ctx->syrk_dynamic = value != 0;
         return FR_OK;
     }
     if (!strcmp(name, "trsv")) {

@@ -83,6 +83,17 @@ struct fr_ctx {
     int64_t prof_launches[FR_PROF_COUNT] = {0};
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
+    int64_t syrk_dynamic = 0;   // trailing update: tiles pulled from per-XCD work lists by resident workgroups (gemm_f64.hip)
+    unsigned* syrk_ctr = nullptr;
+    int64_t syrk_dynamic_tiles = 3;
+    // Products with explicit inverse blocks lose a factor cond(L_bb) of backward accuracy against substitution.  refine:
+    // -1 (default) automatic -- a factorisation whose diagonal blocks turn out ill-conditioned (estimate from the
+    // diagonal-block kernel above refine_threshold) is repeated with one step of iterative refinement behind every such
+    // product, and the handle keeps refining (factor, add_rows, solves); 0 never; 1 always
+    int64_t refine = -1;
+    double refine_threshold = 30.0;
+    bool refine_now = false;      // state of the running operation (set under the context lock)
+    double* cur_cest = nullptr;   // where the diagonal-block kernel of the running factorisation puts its estimates
     int64_t trsv = 1;           // single right-hand-side solves as one persistent launch per direction (trsv.hip)
     // device-side waits report a timeout here (host-mapped, so the host can read it after any synchronisation)
     unsigned* host_status = nullptr;
@@ -121,6 +132,11 @@ struct fr_chol {
     int64_t* info = nullptr;  // device: [0] = 1 + first failing column (0: none), [1] = n_subst,
                               //         [2] = 1 if a zero diagonal was seen, [3..] substituted columns
     int64_t info_cap = 0;
+    // conditioning estimates of the 128 x 128 diagonal blocks (device, one double per block), their maximum after the
+    // last factorisation, and whether this handle applies iterative refinement (fr_ctx::refine)
+    double* cest = nullptr;
+    double max_cest = 0.0;
+    bool refine = false;
     // cached alpha = K^-1 y (todo.md:10): the residual training outputs handed over with
     // fr_chol_set_targets and the solve they imply.  `gen` counts the changes of the factor (refactor, add_rows, upload);
     // alpha is recomputed lazily when its generation is stale, the targets must be handed over again when n changed.
@@ -260,7 +276,7 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 //   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows),
 //   mode 3: the block already holds a factor, only the inverse is produced
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub,
-                 double* inv, int64_t ldinv, int64_t* info);
+                 double* inv, int64_t ldinv, int64_t* info, double* cest = nullptr);
 
 // Fused panel factorisation (potf2.hip server + panel.hip row tiles).  Flags: one int per 128-block of the matrix.
 struct ServerArgs {
@@ -269,6 +285,7 @@ struct ServerArgs {
     int mode;
     double sub;
     double* dinv;     // inverse of block g at dinv + g * 128 * 128
+    double* cest;     // conditioning estimate of block g, or NULL
     int64_t* info;
     int* ready;       // [4 g + a] = 1: 32-row slice a of diagonal block g carries every update; all four: it may be factored
     int* done;        // [g] = 1: block g factored, inverse written

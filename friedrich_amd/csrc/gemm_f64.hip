@@ -112,6 +112,49 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g
     gemm_f64_body<false, false>(g, lds);
 }
 
+// The same trailing update with the tiles pulled from work lists instead of dealt statically: 2 workgroups per CU stay
+// resident and fetch their next tile with one device-scope atomic.  The hardware deals a grid's workgroups evenly over
+// the shader engines, so with one tile per workgroup a CU that is (partly) taken by the panel stream's kernels makes its
+// engine -- and with it the whole launch -- finish late (round-2 probe: one CU held by another dispatch costs the trailing
+// updates 12 %, = 1/8 of an engine of 8 CUs).  Pulling tiles lets every CU take what it can.  One list per XCD (the static
+// order's contiguous runs, so that the tiles an XCD works on share operand panels in its L2); a workgroup that finds its
+// XCD's list empty steals from the next.  ctr: 8 counters, zeroed before the launch.
+__global__ __launch_bounds__(256, 2) void syrk_lower_dyn_kernel(const GemmArgs g, unsigned* __restrict__ ctr, const int max_tiles)
+{
+    __shared__ double lds[4 * TILE_ELEMS];
+    __shared__ long long next_tile;
+    const int64_t T = g.tiles_m;
+    const int64_t nt = T * (T + 1) / 2;
+    const int64_t q = nt >> 3, r8 = nt & 7;
+    int y = (int)(blockIdx.x & 7);  // observed: block b runs on XCD b % 8 (used for locality only)
+    int tried = 0;
+    for (int done_tiles = 0; done_tiles < max_tiles; ++done_tiles) {
+        if (threadIdx.x == 0) {
+            long long tl = -1;
+            while (tried < 8) {
+                const int64_t len = q + (y < r8 ? 1 : 0);
+                const unsigned i = __hip_atomic_fetch_add(ctr + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int64_t)i < len) {
+                    tl = (y < r8 ? y * (q + 1) : r8 * (q + 1) + (y - r8) * q) + (int64_t)i;
+                    break;
+                }
+                y = (y + 1) & 7;
+                ++tried;
+            }
+            next_tile = tl;
+        }
+        __syncthreads();
+        const int64_t tlin = next_tile;
+        __syncthreads();  // next_tile and the tile buffers are free again
+        if (tlin < 0) return;
+        int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
+        while (row * (row + 1) / 2 > tlin) --row;
+        while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
+        const int64_t tm = row, tn = tlin - row * (row + 1) / 2;
+        gemm_f64_tile<false, false>(g, lds, tm * BM, tn * BN);
+    }
+}
+
 // D = beta * Cin + sum over slices of the partial products (split-K), slices M x N with leading dimension M
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __restrict__ part, int64_t M, int64_t N, int slices,
                                                             const double* __restrict__ cin, int64_t ldcin, double beta,
@@ -249,7 +292,17 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.batch_d = d.batch_d;
     if (d.batch > 1 && d.lower) return set_err(ctx, FR_INVALID_ARGUMENT, "batched GEMM is full-mode only");
     dim3 grid((unsigned)ntiles, (unsigned)(d.batch > 1 ? d.batch : 1)), block(256);
-    if (d.lower && !d.a_kmajor && !d.b_kmajor)
+    if (d.lower && !d.a_kmajor && !d.b_kmajor && ctx->syrk_dynamic && d.own_world <= 1 && g.nsuper == 0 && g.lower == 1 &&
+        ntiles > 2 * (int64_t)ctx->num_cus) {
+        if (!ctx->syrk_ctr) FR_HIP(ctx, dev_malloc(ctx, (void**)&ctx->syrk_ctr, 64));
+        FR_HIP(ctx, hipMemsetAsync(ctx->syrk_ctr, 0, 32, ctx->ls));
+        // a workgroup retires after `per` tiles: its slot is then up for grabs again (the panel stream's kernels take theirs
+        // that way), and the grid holds 1/8 more workgroups than the tiles need, so that the engines that run ahead can
+        // take more than their share -- the last workgroups to start find the lists empty
+        const int per = (int)ctx->syrk_dynamic_tiles;
+        const int64_t wgs = (ntiles + per - 1) / per;
+        hipLaunchKernelGGL(syrk_lower_dyn_kernel, dim3((unsigned)(wgs + wgs / 8 + 8)), block, 0, ctx->ls, g, ctx->syrk_ctr, per);
+    } else if (d.lower && !d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL(syrk_lower_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, ctx->ls, g);

@@ -315,7 +315,10 @@ int fr_posterior(fr_chol* c, const fr_kprog* kernel, const double* y, const doub
     }
     // MultivariateNormal::new: covariance.cholesky().expect(..).unpack()   (multivariate_normal.rs:56-57)
     int64_t fail_col = -1;
-    FR_TRY(potrf_matrix_ws(ctx, covl.dev, covl.ld, m, 0, 0.0, &fail_col));
+    ctx->refine_now = c->refine;  // an ill-conditioned training factor usually means an ill-conditioned posterior
+    const int pst = potrf_matrix_ws(ctx, covl.dev, covl.ld, m, 0, 0.0, &fail_col);
+    ctx->refine_now = false;
+    FR_TRY(pst);
     FR_TRY(launch_tri_fill(ctx, covl.dev, m, covl.ld, 0.0));
     FR_TRY(mean.commit());
     FR_TRY(covl.commit());

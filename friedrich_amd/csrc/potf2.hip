@@ -404,7 +404,7 @@ __device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, i
 
 __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                             double sub, double* __restrict__ inv, int64_t ldinv,
-                                            int64_t* __restrict__ info)
+                                            int64_t* __restrict__ info, double* __restrict__ cest = nullptr)
 {
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -614,9 +614,13 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
     }
     }
 
-    // ---- store the inverse: the LDS sub-blocks are transposed (zeros above the diagonal)
+    // ---- store the inverse: the LDS sub-blocks are transposed (zeros above the diagonal).  Along the way: a conditioning
+    // estimate of the block, max |W_ij| * max L_jj (W = L^-1 has 1 / L_jj on its diagonal), for the host's decision whether
+    // the products with W need a step of iterative refinement (chol.hip); and zeros above the diagonal of the factored
+    // block in A, so that refinement can use L_bb as a plain 128 x 128 operand.
     if (want_inv) {
         const int cg = t >> 5;
+        double wmax = 0.0, dmin = __builtin_inf();
         for (int i = 0; i < nblk; ++i)
             for (int k = 0; k < nblk; ++k) {
                 const double* s = lds + slot_of(i, k <= i ? k : 0);
@@ -624,18 +628,47 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
                 for (int cc = 0; cc < 2; ++cc) {
                     const int c = cg * 2 + cc;
                     const int gr = SB * i + r, gc = SB * k + c;
-                    if (gr < n && gc < n) inv[gr + (int64_t)gc * ldinv] = (k <= i) ? s[c + SB * r] : 0.0;
+                    if (gr < n && gc < n) {
+                        const double v = (k <= i) ? s[c + SB * r] : 0.0;
+                        inv[gr + (int64_t)gc * ldinv] = v;
+                        const double av = __builtin_fabs(v);
+                        wmax = (av > wmax || av != av) ? av : wmax;  // NaN sticks
+                        if (gr == gc) dmin = (av < dmin || av != av) ? av : dmin;
+                        if (gr < gc) A[gr + (int64_t)gc * lda] = 0.0;
+                    }
                 }
             }
+        if (cest) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ow = __shfl_xor(wmax, off, 64), od = __shfl_xor(dmin, off, 64);
+                wmax = (ow > wmax || ow != ow) ? ow : wmax;
+                dmin = (od < dmin || od != od) ? od : dmin;
+            }
+            lds_barrier();  // every read of the inverse slots is done: their memory takes the per-wave partials
+            if (lane == 0) {
+                lds[2 * w] = wmax;
+                lds[2 * w + 1] = dmin;
+            }
+            lds_barrier();
+            if (t == 0) {
+                for (int q = 1; q < PT / 64; ++q) {
+                    const double ow = lds[2 * q], od = lds[2 * q + 1];
+                    wmax = (ow > wmax || ow != ow) ? ow : wmax;
+                    dmin = (od < dmin || od != od) ? od : dmin;
+                }
+                *cest = wmax / dmin;
+            }
+        }
     }
 }
 
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
-                                                   int64_t* __restrict__ info)
+                                                   int64_t* __restrict__ info, double* __restrict__ cest)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info);
+    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
 }
 
 // ---- the diagonal-block SERVER of the fused panel factorisation (panel.hip) ----------------------------------------------
@@ -659,7 +692,7 @@ __global__ __launch_bounds__(PT, 2) void potf2_server_kernel(const ServerArgs a)
         if (a.dbg) t1 = wall_clock64();
         const int64_t left = a.n - j;
         potf2_block(lds, a.A + j + j * a.lda, a.lda, (int)(left < PB ? left : PB), a.col0 + j, a.mode, a.sub,
-                    a.dinv + (int64_t)g * (PB * PB), PB, a.info);
+                    a.dinv + (int64_t)g * (PB * PB), PB, a.info, a.cest ? a.cest + g : nullptr);
         if (a.dbg) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             t2 = wall_clock64();
@@ -722,7 +755,7 @@ int launch_potf2_server(fr_ctx* ctx, hipStream_t stream, const ServerArgs& a)
 }
 
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub, double* inv,
-                 int64_t ldinv, int64_t* info)
+                 int64_t ldinv, int64_t* info, double* cest)
 {
     if (nbk <= 0) return FR_OK;
     if (nbk > PB) return set_err(ctx, FR_INVALID_ARGUMENT, "potf2 block too large");
@@ -733,7 +766,7 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
     }
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
     hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv,
-                       info);
+                       info, cest);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

@@ -264,6 +264,12 @@ class Cholesky:
     def n(self):
         return self.info()["n"]
 
+    def conditioning(self):
+        """-> (largest conditioning estimate of the 128 x 128 diagonal blocks, whether the handle refines)"""
+        est, ref = ctypes.c_double(), ctypes.c_int()
+        self.ctx.check(self.lib.fr_chol_conditioning(self.h, ctypes.byref(est), ctypes.byref(ref)))
+        return est.value, bool(ref.value)
+
     def substitutions(self):
         ns = self.info()["n_subst"]
         idx = (ctypes.c_int64 * max(ns, 1))()

@@ -102,6 +102,8 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "splitk"        1 (default): products with few result tiles and a deep contraction are cut along K; 0: never
  *   "leaf512"       1 (default): wide triangular solves (>= 256 right-hand sides) end in 512-row leaves against
  *                   explicit inverses of the 512 x 512 diagonal blocks, built on demand; 0: 128-row leaves only
+ *   "refine"        -1 (default): automatic -- see fr_chol_conditioning; 0: never; 1: always.  "refine_threshold": 30
+ *   "trsv"          1 (default): solves with ONE right-hand side run as one persistent launch per direction
  *   "predict_assoc" 0 (default): predict as the reference associates it, prior + (K^-1 K*)^T y  (mod.rs:234-241,
  *                   two n x m triangular solves);  1: prior + K*^T (K^-1 y), the same value up to rounding with two
  *                   n x 1 solves instead */
@@ -167,6 +169,11 @@ int fr_chol_add_rows(fr_chol* chol, const fr_kprog* kernel, const double* Xall, 
 /* n, capacity (row capacity of the device buffers), d, number of substituted pivots, failing column (-1) */
 int fr_chol_info(const fr_chol* chol, int64_t* n, int64_t* capacity, int64_t* d, int64_t* n_subst,
                  int64_t* fail_col);
+/* Conditioning report of the last factorisation: *max_estimate = the largest estimate max|W_ij| * max L_jj over the
+ * 128 x 128 diagonal blocks (W = explicit inverse of the block), *refined = 1 when the handle applies a step of iterative
+ * refinement behind every product with an inverse block (option "refine": -1 automatic, the default: on when an estimate
+ * exceeds "refine_threshold", 30).  No reference counterpart: nalgebra substitutes, which needs no such step. */
+int fr_chol_conditioning(const fr_chol* chol, double* max_estimate, int* refined);
 /* ordered list of columns where cholesky_epsilon replaced the pivot ("pivot indices" of BASELINE.json) */
 int fr_chol_substitutions(const fr_chol* chol, int64_t* idx, int64_t max_idx);
 /* Cholesky::solve_mut (mod.rs:235; solve = clone + solve_mut :298,:379): B <- K^-1 B, B is n x m, in place */

@@ -46,6 +46,7 @@ for n in sizes:
     rec = {"n": n, "d": d, "kernel": kname, "opts": opts}
     rec["fit_ms"] = timed(lambda: chol.refactor(k, hp["noise"], eps=eps))
     rec["fit_tflops"] = n ** 3 / 3.0 / (rec["fit_ms"] * 1e-3) / 1e12
+    rec["cond_estimate"], rec["refined"] = chol.conditioning()
     for m in (1, 16, 1024):
         q, pq = np.asfortranarray(Xq[:m]), np.full(m, hp["prior"])
         rec[f"predict_m{m}_ms"] = timed(lambda: chol.predict_mean(k, yres, q, pq))

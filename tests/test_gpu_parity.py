@@ -529,3 +529,25 @@ def test_single_rhs_persistent_solves(ctx, n):
     # repeated calls are deterministic bit for bit (fixed summation order, hand-off granules re-initialised per call)
     assert np.array_equal(chol.solve(b), z1)
     chol.free()
+
+
+def test_refinement_policy_and_forced_modes(ctx):
+    """option "refine": well-conditioned fits never refine (no second factorisation, the fast kernels stay in use), the
+    forced modes give the same factor to round-off, and an ill-conditioned handle refines its solves as well."""
+    k = PD_KERNELS[0]
+    X = rand_inputs(900, 3, 5)
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    B = np.asfortranarray(np.random.default_rng(2).standard_normal((900, 5)))
+    Ls = []
+    for mode in (-1, 0, 1):
+        ctx.set_option("refine", mode)
+        chol = ctx.cholesky_from_inputs(k, X, 0.1)
+        est, refined = chol.conditioning()
+        assert refined == (mode == 1) and 1.0 <= est < 30.0
+        assert rel_err(chol.l(), np.tril(L_o)) < TOL
+        assert rel_err(chol.solve(B), O.chol_solve(L_o, B)) < TOL
+        assert rel_err(chol.solve_lower(B[:, :1]), O.solve_lower(L_o, B[:, :1])[1]) < TOL
+        Ls.append(chol.l())
+        chol.free()
+    ctx.set_option("refine", -1)
+    assert rel_err(Ls[0], Ls[2]) < 1e-13 and np.array_equal(Ls[0], Ls[1])
