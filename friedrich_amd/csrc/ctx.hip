@@ -403,6 +403,35 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     }
     if (!strcmp(name, "panel_debug")) {
         ctx->panel_debug = value;
+        if (value == 4) {  // developer probe: allocate the stamp buffer (trsv backward stamps)
+            if (!ctx->panel_dbg) {
+                void* h = nullptr;
+                FR_HIP(ctx, hipHostMalloc(&h, sizeof(unsigned long long) * 4 * 1024, hipHostMallocMapped));
+                ctx->panel_dbg = (unsigned long long*)h;
+            }
+            memset(ctx->panel_dbg, 0, sizeof(unsigned long long) * 4 * 1024);
+            ctx->panel_debug = 1;
+            return FR_OK;
+        }
+        if (value == 5 && ctx->panel_dbg) {  // dump trsv backward stamps: per block, relative to the previous block's publish
+            const unsigned long long* t = ctx->panel_dbg;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+            int cnt = 0;
+            for (int j = 0; j + 1 < 512; ++j) {
+                if (!t[8 * j + 4] || !t[8 * (j + 1) + 4]) continue;
+                // block j follows block j + 1 in the backward sweep
+                a0 += (double)(t[8 * j + 0] - t[8 * (j + 1) + 4]);  // publish of j+1 -> last FMA of j done
+                a1 += (double)(t[8 * j + 1] - t[8 * j + 0]);        // first reduction
+                a2 += (double)(t[8 * j + 2] - t[8 * j + 1]);        // b load, tv, inverse fetch, barrier
+                a3 += (double)(t[8 * j + 3] - t[8 * j + 2]);        // product + second reduction
+                a4 += (double)(t[8 * j + 4] - t[8 * j + 3]);        // publish
+                ++cnt;
+            }
+            if (cnt)
+                fprintf(stderr, "trsv backward, %d steps (us): hand-off + last tile %.2f, reduce %.2f, b/tv/inverse/barrier %.2f, product + reduce %.2f, publish %.2f\n",
+                        cnt, a0 / cnt / 100, a1 / cnt / 100, a2 / cnt / 100, a3 / cnt / 100, a4 / cnt / 100);
+            return FR_OK;
+        }
         if (value == 2 && ctx->panel_dbg) {  // dump the last factorisation's server time stamps (us, relative)
             const unsigned long long* t = ctx->panel_dbg;
             double wait = 0, fac = 0, pub = 0;

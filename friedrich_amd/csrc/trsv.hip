@@ -39,6 +39,7 @@ struct TrsvArgs {
     unsigned* status;    // host-visible: [0] != 0 after a timed-out wait
     int nblk, G;
     unsigned epoch;
+    unsigned long long* dbg;  // developer probe: 8 time stamps per block (100 MHz), or NULL
 };
 
 __device__ __forceinline__ u64 gran_load(const u64* p)
@@ -239,42 +240,81 @@ __device__ __forceinline__ void bwd_fma(const double2 (&buf)[NC], double x0, dou
     for (int k = 0; k < NC; ++k) p[k] = __builtin_fma(buf[k].y, x1, __builtin_fma(buf[k].x, x0, p[k]));
 }
 
-// Sum p[k] over the 64 lanes of the wave for all NC = 16 k at once (recursive halving: 8 + 4 + 2 + 1 exchanges, then the two
-// remaining lane bits).  Returns, in every lane, the total of column (lane >> 2).
-__device__ __forceinline__ double wave_reduce_cols(double (&p)[NC], int lane)
+// ---- the backward kernel's LDS (dynamic) --------------------------------------------------------------------------------
+// (1) W_j^T, packed: the rows of W_j in groups of 16 (one group per wave of the closing product), group g holding its
+//     16 (g + 1) possibly non-zero columns: element (row 16 g + k, col) at WT_OFF(g) + k * 16 (g + 1) + col;  72 KiB.
+// (2) the transposition scratch of the column sums: per wave 16 x RS doubles;  66 KiB.
+constexpr int RS = 66;                                  // row stride of the scratch (doubles): 2-way conflicts at worst
+constexpr int WT_ELEMS = 128 * (NW * (NW + 1) / 2) * 2;  // sum over g of 16 * 16 (g + 1) = 9216
+constexpr size_t TRSV_BWD_LDS = sizeof(double) * (WT_ELEMS + NW * NC * RS);
+__device__ __forceinline__ int wt_off(int g) { return 128 * g * (g + 1); }
+
+__device__ __forceinline__ double dpp_quad_xor(double v, const int ctrl_is_xor2)
 {
-    static_assert(NC == 16, "the halving below is written for 16 columns per lane");
-#pragma unroll
-    for (int step = 0; step < 4; ++step) {
-        const int half = 8 >> step, bit = 32 >> step;
-        const bool hi = (lane & bit) != 0;
-#pragma unroll
-        for (int k = 0; k < half; ++k) {
-            const double send = hi ? p[k] : p[k + half];
-            const double keep = hi ? p[k + half] : p[k];
-            p[k] = keep + __shfl_xor(send, bit, 64);
-        }
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int rl, rh;
+    if (ctrl_is_xor2) {
+        rl = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);  // quad_perm [2, 3, 0, 1]
+        rh = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+    } else {
+        rl = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+        rh = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
     }
-    double v = p[0] + __shfl_xor(p[0], 2, 64);
-    return v + __shfl_xor(v, 1, 64);
+    return __hiloint2double(rh, rl);
+}
+
+// Sum p[k] over the 64 lanes of the wave, for the wave's 16 columns k at once, through the wave's scratch: every lane
+// writes its 16 partials (lanes along the fast axis), then lane l adds a quarter (l & 3) of column l >> 2, and two DPP
+// exchanges inside the quad finish.  Returns, in every lane, the total of column (lane >> 2).  (The shuffle-based halving
+// this replaces took 3.4 us per call -- 34 ds_bpermute per lane from eight waves at once -- two thirds of a chain step.)
+__device__ __forceinline__ double wave_reduce_cols(const double (&p)[NC], int lane, double* red)
+{
+#pragma unroll
+    for (int k = 0; k < NC; ++k) red[k * RS + lane] = p[k];
+    // same wave writes and reads: the LDS operations of one wave complete in order
+    const double2* src = reinterpret_cast<const double2*>(red + (lane >> 2) * RS + 16 * (lane & 3));
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double2 v = src[i];
+        acc0 += v.x;
+        acc1 += v.y;
+    }
+    double v = acc0 + acc1;
+    v += dpp_quad_xor(v, 0);
+    v += dpp_quad_xor(v, 1);
+    return v;
 }
 
 __global__ __launch_bounds__(NT, 2) void trsv_bwd_kernel(const TrsvArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double wl[];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ Shared s;
+    double* wt = dyn;
     const int t = threadIdx.x, rp = t & 63, cg = __builtin_amdgcn_readfirstlane(t >> 6);  // cg: wave-uniform
+    double* red = dyn + WT_ELEMS + cg * (NC * RS);
 #pragma nounroll
     for (int jj = blockIdx.x; jj < a.nblk; jj += a.G) {
         const int j = a.nblk - 1 - jj;
         const int last = a.nblk - 1;
         const int cnt = last - j;  // tiles L[last - q, j], q = 0 .. cnt - 1
         const int64_t j0 = (int64_t)j * TB;
+        const int col = cg * NC + (rp >> 2);  // the column whose sum this lane ends up with
+        const double bj = (j0 + col < a.n) ? a.b[j0 + col] : 0.0;  // early: not on the chain
         double p[NC];
 #pragma unroll
         for (int k = 0; k < NC; ++k) p[k] = 0.0;
         double2 A[NC], B[NC];
-        stage_inverse(a, j, wl, rp, cg, A);
+        // stage W_j^T (packed) once per block, off the chain: the lane holds W[rows 2 rp, 2 rp + 1][cols 16 cg + k]
+        load_operand(inv_operand(a, j), rp, cg, A);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int c = cg * NC + k;
+            const int r0 = 2 * rp, r1 = 2 * rp + 1;
+            // (every slot of the packed groups is written: above the diagonal the inverse block holds explicit zeros)
+            if (c < 16 * ((r0 >> 4) + 1)) wt[wt_off(r0 >> 4) + (r0 & 15) * 16 * ((r0 >> 4) + 1) + c] = A[k].x;
+            if (c < 16 * ((r1 >> 4) + 1)) wt[wt_off(r1 >> 4) + (r1 & 15) * 16 * ((r1 >> 4) + 1) + c] = A[k].y;
+        }
         if (cnt > 0) load_operand(tile_operand(a, last, j), rp, cg, A);
 #pragma nounroll
         for (int q = 0; q < cnt; q += 2) {
@@ -292,21 +332,47 @@ __global__ __launch_bounds__(NT, 2) void trsv_bwd_kernel(const TrsvArgs a)
                 bwd_fma(B, x.x, x.y, p);
             }
         }
-        // x_j = W_j^T (b_j - u), u = column sums of the partial products
-        const int col = cg * NC + (rp >> 2);
-        const double u = wave_reduce_cols(p, rp);
-        if ((rp & 3) == 0) s.tv[col] = (j0 + col < a.n) ? a.b[j0 + col] - u : 0.0;
-        fetch_inverse(wl, rp, cg, A);
-        __syncthreads();  // tv complete (and, for cnt == 0, the staged inverse)
-        const double2 tt = *reinterpret_cast<const double2*>(&s.tv[2 * rp]);
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+        if (a.dbg) ts0 = wall_clock64();
+        // t_j = b_j - u, u = column sums of the partial products
+        const double u = wave_reduce_cols(p, rp, red);
+        if (a.dbg) ts1 = wall_clock64();
+        if ((rp & 3) == 0) s.tv[col] = bj - u;
+        __syncthreads();  // tv complete (and the staged inverse)
+        if (a.dbg) ts2 = wall_clock64();
+        // x_j = W_j^T t_j: the lane owns the outputs 2 rp, 2 rp + 1, its wave the rows 16 cg .. 16 cg + 15 of W_j
+        double x0 = 0.0, x1 = 0.0;
+        if (2 * rp < 16 * (cg + 1)) {
+            const double* wrow = wt + wt_off(cg) + 2 * rp;
+            const double2* tv2 = reinterpret_cast<const double2*>(s.tv + cg * NC);
 #pragma unroll
-        for (int k = 0; k < NC; ++k) p[k] = __builtin_fma(A[k].y, tt.y, A[k].x * tt.x);
-        const double x = wave_reduce_cols(p, rp);
-        if ((rp & 3) == 0) {
-            publish_entry(a, j0 + col, x);
-            if (j0 + col < a.n) a.b[j0 + col] = x;
+            for (int k = 0; k < NC / 2; ++k) {
+                const double2 tt = tv2[k];
+                const double2 w0 = *reinterpret_cast<const double2*>(wrow + (2 * k) * 16 * (cg + 1));
+                const double2 w1 = *reinterpret_cast<const double2*>(wrow + (2 * k + 1) * 16 * (cg + 1));
+                x0 = __builtin_fma(w0.x, tt.x, x0);
+                x1 = __builtin_fma(w0.y, tt.x, x1);
+                x0 = __builtin_fma(w1.x, tt.y, x0);
+                x1 = __builtin_fma(w1.y, tt.y, x1);
+            }
         }
+        s.part[cg][2 * rp] = x0;
+        s.part[cg][2 * rp + 1] = x1;
         __syncthreads();
+        if (a.dbg) ts3 = wall_clock64();
+        if (t < TB) {
+            const double x = sum_parts(s, t);
+            publish_entry(a, j0 + t, x);
+            if (j0 + t < a.n) a.b[j0 + t] = x;
+        }
+        __syncthreads();  // wt / part / tv are reused by the next block of this workgroup
+        if (a.dbg && t == 0) {
+            a.dbg[8 * j + 0] = ts0;
+            a.dbg[8 * j + 1] = ts1;
+            a.dbg[8 * j + 2] = ts2;
+            a.dbg[8 * j + 3] = ts3;
+            a.dbg[8 * j + 4] = wall_clock64();
+        }
     }
 }
 
@@ -343,18 +409,24 @@ int launch_trsv(fr_ctx* ctx, const fr_chol* c, double* b, bool fwd, int prof_cls
     a.nblk = nblk;
     a.G = nblk < ctx->num_cus ? nblk : ctx->num_cus;
     a.epoch = 1u;
+    a.dbg = nullptr;
+    if (ctx->panel_debug && ctx->panel_dbg && !fwd && nblk <= 512) {
+        void* d = nullptr;
+        FR_HIP(ctx, hipHostGetDevicePointer(&d, ctx->panel_dbg, 0));
+        a.dbg = (unsigned long long*)d;
+    }
     if (!ctx->trsv_lds_set) {  // per context (= per device): > 64 KiB of dynamic LDS needs the attribute
         FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_fwd_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSV_LDS));
         FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSV_LDS));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSV_BWD_LDS));
         ctx->trsv_lds_set = true;
     }
     ProfScope ps(ctx, prof_cls, (double)n * (double)n, 4.0 * (double)n * (double)n);
     if (fwd)
         hipLaunchKernelGGL(trsv_fwd_kernel, dim3((unsigned)a.G), dim3(NT), TRSV_LDS, ctx->ls, a);
     else
-        hipLaunchKernelGGL(trsv_bwd_kernel, dim3((unsigned)a.G), dim3(NT), TRSV_LDS, ctx->ls, a);
+        hipLaunchKernelGGL(trsv_bwd_kernel, dim3((unsigned)a.G), dim3(NT), TRSV_BWD_LDS, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
