@@ -618,6 +618,7 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         return trsm_fwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, true, cls);
+    if (m <= 16 && m <= ctx->narrow_max && n == c->n && ctx->trsv) return launch_trsm_narrow(ctx, c, B, m, ldb, true, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, true);
     WsGuard w(ctx);
     double* tmp = nullptr;
@@ -639,6 +640,7 @@ int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         return trsm_bwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, false, cls);
+    if (m <= 16 && m <= ctx->narrow_max && n == c->n && ctx->trsv) return launch_trsm_narrow(ctx, c, B, m, ldb, false, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, false);
     WsGuard w(ctx);
     double* tmp = nullptr;
@@ -659,6 +661,10 @@ static void chol_release(fr_chol* c)
     if (c->inv512) (void)hipFree(c->inv512);
     if (c->cest) (void)hipFree(c->cest);
     c->cest = nullptr;
+    if (c->dinvt) (void)hipFree(c->dinvt);
+    c->dinvt = nullptr;
+    c->dinvt_cap = 0;
+    c->ut_gen = 0;
     if (c->yt) (void)hipFree(c->yt);
     if (c->alpha) (void)hipFree(c->alpha);
     c->yt = c->alpha = nullptr;
@@ -689,7 +695,8 @@ static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t
     c->d = d;
     const int64_t nblk = (c->capacity + IB - 1) / IB;
     c->info_cap = 3 + c->capacity;
-    hipError_t e = dev_malloc(ctx, (void**)&c->A, sizeof(double) * (size_t)c->ld_a * (size_t)c->capacity);
+    // (columns rounded up to a whole 128-block: the persistent solves read whole blocks of the transposed copy)
+    hipError_t e = dev_malloc(ctx, (void**)&c->A, sizeof(double) * (size_t)c->ld_a * (size_t)round_up(c->capacity, IB));
     if (e == hipSuccess && d > 0) e = dev_malloc(ctx, (void**)&c->X, sizeof(double) * (size_t)c->ld_x * (size_t)d);
     if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->dinv, sizeof(double) * (size_t)nblk * INV_ELEMS);
     if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->info, sizeof(int64_t) * (size_t)c->info_cap);

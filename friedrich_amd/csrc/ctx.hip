@@ -330,6 +330,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
         if (b.p) (void)hipFree(b.p);
     if (ctx->trsv_gran) (void)hipFree(ctx->trsv_gran);
     if (ctx->syrk_ctr) (void)hipFree(ctx->syrk_ctr);
+    if (ctx->trsmn_buf) (void)hipFree(ctx->trsmn_buf);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);

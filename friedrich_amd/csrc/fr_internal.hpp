@@ -103,6 +103,9 @@ struct fr_ctx {
     void* trsv_gran = nullptr;
     size_t trsv_gran_cap = 0;
     bool trsv_lds_set = false;
+    // hand-off payload + flags of the multi-column persistent solves (trsm_narrow.hip), grow-only
+    void* trsmn_buf = nullptr;
+    size_t trsmn_buf_cap = 0;
     // RCCL
     void* comm = nullptr;   // ncclComm_t
     void* local = nullptr;  // in-process ("local") communicator: ranks are host threads sharing one device
@@ -132,6 +135,11 @@ struct fr_chol {
     int64_t* info = nullptr;  // device: [0] = 1 + first failing column (0: none), [1] = n_subst,
                               //         [2] = 1 if a zero diagonal was seen, [3..] substituted columns
     int64_t info_cap = 0;
+    // transposed copy for the backward persistent solves with several right-hand sides (trsm_narrow.hip): the off-diagonal
+    // blocks of L^T live in the strict upper triangle of A, the transposed inverse blocks in dinvt; valid for generation ut_gen
+    double* dinvt = nullptr;
+    int64_t dinvt_cap = 0;
+    uint64_t ut_gen = 0;
     // conditioning estimates of the 128 x 128 diagonal blocks (device, one double per block), their maximum after the
     // last factorisation, and whether this handle applies iterative refinement (fr_ctx::refine)
     double* cest = nullptr;
@@ -333,6 +341,8 @@ int launch_sum_log_abs(fr_ctx* ctx, const double* v, int64_t n, double* out);
 // K8 (trsv.hip): b <- L^-1 b (fwd) or L^-T b with one right-hand side, one persistent launch
 int launch_trsv(fr_ctx* ctx, const fr_chol* c, double* b, bool fwd, int prof_cls);
 int ensure_status_word(fr_ctx* ctx);
+// K9 (trsm_narrow.hip): B (n x m, 2 <= m <= 16) <- L^-1 B / L^-T B, one persistent launch on the matrix cores
+int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* c, double* B, int64_t m, int64_t ldb, bool fwd, int prof_cls);
 // FR_HIP_ERROR if a device-side wait timed out since the last check (call after a synchronisation)
 int check_status_word(fr_ctx* ctx);
 

@@ -1,0 +1,258 @@
+// trsm_narrow.hip -- K9: triangular solves with 2 .. 16 right-hand sides (predict / predict_variance / sample_at of a
+// handful of query points, mod.rs:235, 260-263, 342-345, 379) as ONE persistent launch per direction.
+//
+// Same organisation as the single-column solves of trsv.hip -- 128-row blocks dealt to the CUs, a block's owner streams its
+// row of 128 x 128 tiles while the solution blocks it depends on become available, closes with the explicit inverse of the
+// diagonal block, hands its solution block over -- with the products on the FP64 matrix core: a wave owns 16 rows of the
+// block and all 16 (padded) right-hand sides, one v_mfma_f64_16x16x4 accumulator, tile fragments straight from memory
+// (rows along the lanes: 128-byte segments), so there is no reduction across lanes or waves anywhere.
+//
+// The backward sweep runs the SAME kernel on a transposed copy of the factor: the strict upper triangle of the factor's
+// buffer is free (the reference leaves NaN there, algebra/mod.rs:67), so the off-diagonal 128 x 128 blocks of L^T are kept
+// in it (and the transposed inverse blocks next to the inverse blocks), rebuilt lazily after the factor changed
+// (~2 ms at n = 32768).  With it "L^T x = b" reads rows-along-lanes exactly like "L x = b".
+//
+// Hand-off of a solution block (128 x 16 doubles): write-through (sc1) stores -> every wave drains -> barrier -> flag;
+// the consumer polls the flag and reads the block with sc1 loads (cdna_hip_programming.md Guideline 16, R1).  Every
+// spin is bounded (handoff.hpp).
+#include "fr_internal.hpp"
+#include "handoff.hpp"
+
+namespace fr {
+
+typedef double d4n_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) double gdbl;
+
+constexpr int NB = 128;   // block
+constexpr int MR = 16;    // right-hand sides per launch (padded)
+constexpr int NTH = 512;  // 8 waves x 16 rows
+
+struct TrsmnArgs {
+    const double* A;    // factor buffer: lower triangle L; strict upper off-diagonal blocks hold L^T (backward)
+    int64_t ld, n;
+    const double* inv;  // inverse blocks (forward) or transposed inverse blocks (backward)
+    double* B;          // n x m right-hand sides in, solutions out
+    int64_t ldb;
+    int m;
+    double* xg;         // hand-off payload: block g at xg + g * NB * MR, [col][q]
+    int* flags;         // one per block
+    unsigned* status;
+    int nblk, G, bwd;
+};
+
+struct Frag {
+    const double* base;  // element (0, 0)
+    int64_t stride;      // column (k) stride
+    int mrows, kcols;    // valid extent
+};
+
+// 16 rows (of this wave) x 128 columns: the lane holds element (m = 16 w + l15, k = 4 u + lq), u = 0 .. 31
+__device__ __forceinline__ void load_frag(const Frag& f, int w, int l15, int lq, double (&buf)[32])
+{
+    // address = wave-uniform part (block, column group: scalar registers) + one 32-bit lane offset shared by all 32 loads
+    const unsigned lane_off = (unsigned)(16 * w + l15) + (unsigned)lq * (unsigned)f.stride;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) buf[u] = (f.base + (int64_t)(4 * u) * f.stride)[lane_off];
+    if (f.mrows < NB || f.kcols < NB) {  // last block only: zeros outside the valid extent (the addresses exist)
+        const bool mok = 16 * w + l15 < f.mrows;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) buf[u] = (mok && 4 * u + lq < f.kcols) ? buf[u] : 0.0;
+    }
+}
+
+__device__ __forceinline__ Frag item_frag(const TrsmnArgs& a, int blk, int other, bool inverse)
+{
+    Frag f;
+    const int64_t b0 = (int64_t)blk * NB;
+    const int64_t left = a.n - b0;
+    f.mrows = left < NB ? (int)left : NB;
+    if (inverse) {
+        f.base = a.inv + (int64_t)blk * (NB * NB);
+        f.stride = NB;
+        f.kcols = f.mrows;
+    } else {
+        const int64_t o0 = (int64_t)other * NB;
+        f.base = a.A + b0 + o0 * a.ld;  // forward: tile (blk, other) of L; backward: block (blk, other) of the upper copy
+        f.stride = a.ld;
+        const int64_t oleft = a.n - o0;
+        f.kcols = oleft < NB ? (int)oleft : NB;
+    }
+    return f;
+}
+
+// solution block `blk` -> xs ([col][q]); false after a timeout
+__device__ __forceinline__ bool fetch_block(const TrsmnArgs& a, int blk, double* xs, int t)
+{
+    if (!handoff_wait_ge(a.flags + blk, 1, a.status)) return false;  // (its agent-scope acquire is not needed for sc1 loads, harmless)
+    const double* src = a.xg + (int64_t)blk * (NB * MR);
+#pragma unroll
+    for (int i = 0; i < (NB * MR) / NTH; ++i)
+        xs[t + NTH * i] = __hip_atomic_load((gdbl*)(src + t + NTH * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return true;
+}
+
+__device__ __forceinline__ void mma_block(const double (&buf)[32], const double* xs, int l15, int lq, d4n_t& acc)
+{
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const double xf = xs[(4 * u + lq) * MR + l15];  // element (k = 4 u + lq, q = l15)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, buf[u], acc, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(NTH, 2) void trsm_narrow_kernel(const TrsmnArgs a)
+{
+    __shared__ double xs[2][NB * MR];
+    __shared__ double tv[NB * MR];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int last = a.nblk - 1;
+#pragma nounroll
+    for (int bi = blockIdx.x; bi < a.nblk; bi += a.G) {
+        const int blk = a.bwd ? last - bi : bi;
+        const int cnt = a.bwd ? last - blk : blk;  // tiles; item q uses the solution block dep(q)
+        const int64_t b0 = (int64_t)blk * NB;
+        const int64_t row = b0 + 16 * w + l15;
+        double bv[4];  // this lane's right-hand side entries: (row, q = lq + 4 i)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = (row < a.n && lq + 4 * i < a.m) ? a.B[row + (int64_t)(lq + 4 * i) * a.ldb] : 0.0;
+        d4n_t acc = {0.0, 0.0, 0.0, 0.0};
+        double F0[32], F1[32];
+        // items 0 .. cnt - 1: tiles, item cnt: the inverse block; two register buffers, the next item always in flight
+        load_frag(item_frag(a, blk, a.bwd ? last : 0, cnt == 0), w, l15, lq, F0);
+#pragma nounroll
+        for (int q = 0; q < cnt; q += 2) {
+            load_frag(item_frag(a, blk, a.bwd ? last - q - 1 : q + 1, q + 1 >= cnt), w, l15, lq, F1);
+            if (!fetch_block(a, a.bwd ? last - q : q, xs[0], t)) return;
+            mma_block(F0, xs[0], l15, lq, acc);
+            if (q + 1 >= cnt) break;
+            load_frag(item_frag(a, blk, a.bwd ? last - q - 2 : q + 2, q + 2 >= cnt), w, l15, lq, F0);
+            if (!fetch_block(a, a.bwd ? last - q - 1 : q + 1, xs[1], t)) return;
+            mma_block(F1, xs[1], l15, lq, acc);
+        }
+        // t = b - acc, as the [col][q] operand of the closing product with the inverse block
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[(16 * w + l15) * MR + lq + 4 * i] = bv[i] - acc[i];
+        __syncthreads();
+        d4n_t x = {0.0, 0.0, 0.0, 0.0};
+        if (cnt & 1)
+            mma_block(F1, tv, l15, lq, x);  // an odd number of tiles leaves the inverse in the second buffer
+        else
+            mma_block(F0, tv, l15, lq, x);
+        // publish (write-through), then the caller's copy
+        double* dst = a.xg + (int64_t)blk * (NB * MR);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __hip_atomic_store((gdbl*)(dst + (16 * w + l15) * MR + lq + 4 * i), x[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store((hgi32*)(a.flags + blk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (row < a.n && lq + 4 * i < a.m) a.B[row + (int64_t)(lq + 4 * i) * a.ldb] = x[i];
+        __syncthreads();  // tv / xs are reused by the next block of this workgroup
+    }
+}
+
+// ---- the transposed copy ---------------------------------------------------------------------------------------------
+// upper off-diagonal blocks := transposes of the lower ones (the diagonal 128-blocks keep their zeroed upper triangle: the
+// refined solve leaves use them as plain operands); 64 x 64 LDS tiles, coalesced on both sides
+__global__ __launch_bounds__(256) void transpose_offdiag_kernel(double* A, int64_t n, int64_t ld)
+{
+    __shared__ double tile[64][65];
+    const int64_t bi = blockIdx.x, bj = blockIdx.y;  // 64-blocks: source (bi, bj), bi > bj
+    if (bj >= bi || (bi >> 1) == (bj >> 1)) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4) {
+        const int64_t r = bi * 64 + tx, cc = bj * 64 + c;
+        tile[c][tx] = (r < n && cc < n) ? A[r + cc * ld] : 0.0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        const int64_t r = bj * 64 + tx, cc = bi * 64 + c;  // element (r, cc) of the upper part = lower (cc, r)
+        if (r < n && cc < n) A[r + cc * ld] = tile[tx][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_inv_kernel(const double* __restrict__ inv, double* __restrict__ invt)
+{
+    __shared__ double tile[64][65];
+    const double* src = inv + (int64_t)blockIdx.z * (NB * NB);
+    double* dst = invt + (int64_t)blockIdx.z * (NB * NB);
+    const int bi = blockIdx.x, bj = blockIdx.y;  // 64-sub-blocks of the 128 x 128 block
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4) tile[c][tx] = src[(bi * 64 + tx) + (bj * 64 + c) * NB];
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) dst[(bj * 64 + tx) + (bi * 64 + c) * NB] = tile[tx][c];
+}
+
+static int ensure_transposed(fr_ctx* ctx, fr_chol* c)
+{
+    if (c->ut_gen == c->gen && c->dinvt) return FR_OK;
+    const int64_t nblk = (c->n + NB - 1) / NB;
+    const int64_t cap_blk = (c->capacity + NB - 1) / NB;
+    if (c->dinvt_cap < cap_blk) {
+        if (c->dinvt) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(c->dinvt);
+            c->dinvt = nullptr;
+            c->dinvt_cap = 0;
+        }
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->dinvt, sizeof(double) * (size_t)cap_blk * NB * NB));
+        c->dinvt_cap = cap_blk;
+    }
+    const int64_t nb64 = (c->n + 63) / 64;
+    if (nb64 > 65535) return set_err(ctx, FR_INVALID_ARGUMENT, "matrix too large for the transposed copy");
+    hipLaunchKernelGGL(transpose_offdiag_kernel, dim3((unsigned)nb64, (unsigned)nb64), dim3(256), 0, ctx->ls, c->A, c->n, c->ld_a);
+    hipLaunchKernelGGL(transpose_inv_kernel, dim3(2, 2, (unsigned)nblk), dim3(256), 0, ctx->ls, c->dinv, c->dinvt);
+    FR_HIP(ctx, hipGetLastError());
+    c->ut_gen = c->gen;
+    return FR_OK;
+}
+
+// B (n x m, device, 2 <= m <= 16) <- L^-1 B (fwd) or L^-T B.  One launch (+ a memset of the flags; the backward sweep also
+// builds the transposed copy when the factor changed since it was last built).
+int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int64_t ldb, bool fwd, int prof_cls)
+{
+    fr_chol* c = const_cast<fr_chol*>(cc);  // the transposed copy is a cache: logically const
+    const int64_t n = c->n;
+    if (n <= 0 || m <= 0) return FR_OK;
+    if (m > MR) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow solve: more than 16 right-hand sides");
+    const int nblk = (int)((n + NB - 1) / NB);
+    FR_TRY(ensure_status_word(ctx));
+    if (!fwd) FR_TRY(ensure_transposed(ctx, c));
+    const size_t bytes = sizeof(double) * (size_t)nblk * NB * MR + sizeof(int) * (size_t)nblk + 64;
+    if (ctx->trsmn_buf_cap < bytes) {
+        if (ctx->trsmn_buf) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(ctx->trsmn_buf);
+            ctx->trsmn_buf = nullptr;
+            ctx->trsmn_buf_cap = 0;
+        }
+        FR_HIP(ctx, dev_malloc(ctx, &ctx->trsmn_buf, bytes));
+        ctx->trsmn_buf_cap = bytes;
+    }
+    TrsmnArgs a;
+    a.A = c->A;
+    a.ld = c->ld_a;
+    a.n = n;
+    a.inv = fwd ? c->dinv : c->dinvt;
+    a.B = B;
+    a.ldb = ldb;
+    a.m = (int)m;
+    a.xg = (double*)ctx->trsmn_buf;
+    a.flags = (int*)((char*)ctx->trsmn_buf + sizeof(double) * (size_t)nblk * NB * MR);
+    a.status = ctx->dev_status;
+    a.nblk = nblk;
+    a.G = nblk < ctx->num_cus ? nblk : ctx->num_cus;
+    a.bwd = fwd ? 0 : 1;
+    FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)nblk, ctx->ls));
+    ProfScope ps(ctx, prof_cls, (double)n * (double)n * (double)m, 4.0 * (double)n * (double)n);
+    hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)a.G), dim3(NTH), 0, ctx->ls, a);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+}  // namespace fr

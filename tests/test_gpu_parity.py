@@ -551,3 +551,30 @@ def test_refinement_policy_and_forced_modes(ctx):
         chol.free()
     ctx.set_option("refine", -1)
     assert rel_err(Ls[0], Ls[2]) < 1e-13 and np.array_equal(Ls[0], Ls[1])
+
+
+@pytest.mark.parametrize("n,m", [(2, 2), (127, 3), (128, 16), (129, 7), (300, 2), (1000, 16), (2049, 5)])
+def test_narrow_persistent_solves_2_to_16_columns(ctx, n, m):
+    """2 .. 16 right-hand sides: one persistent matrix-core launch per direction (trsm_narrow.hip), the backward sweep on
+    the transposed copy kept in the strict upper triangle -- vs the oracle, vs the recursive path (option trsv = 0), after
+    add_rows (copy rebuilt) and with the factor's download unaffected by the copy."""
+    k = PD_KERNELS[1]
+    X = rand_inputs(n + 40, 3, 2000 + n)
+    B = np.asfortranarray(np.random.default_rng(n + m).standard_normal((n + 40, m)))
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X[:n], 0.1)
+    chol = ctx.cholesky_from_inputs(k, X[:n], 0.1)
+    z, w_ = chol.solve(B[:n]), chol.solve_lower(B[:n])
+    assert rel_err(z, O.chol_solve(L_o, B[:n])) < TOL
+    assert rel_err(w_, O.solve_lower(L_o, B[:n])[1]) < TOL
+    ctx.set_option("trsv", 0)
+    try:
+        assert rel_err(chol.solve(B[:n]), z) < 1e-11
+    finally:
+        ctx.set_option("trsv", 1)
+    assert np.array_equal(chol.solve(B[:n]), z)  # deterministic
+    L = chol.l()
+    assert rel_err(L, np.tril(L_o)) < TOL and np.all(np.triu(L, 1) == 0.0)
+    chol.add_rows(k, np.asfortranarray(X), 40, 0.1)
+    st, L1, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    assert rel_err(chol.solve(B), O.chol_solve(L1, B)) < TOL
+    chol.free()
