@@ -105,6 +105,31 @@ void ws_put(fr_ctx* ctx, void* p)
         }
 }
 
+// Pinned bounce buffer: pageable host memory is copied into it by the CPU and leaves it by DMA (a pageable hipMemcpy does
+// the same through a driver-internal buffer, 64 KiB at a time and synchronously).  Transfers larger than the cap go direct.
+constexpr size_t PINNED_MAX = (size_t)256 << 20;
+void* pinned_get(fr_ctx* ctx, size_t bytes)
+{
+    if (bytes == 0 || bytes > PINNED_MAX) return nullptr;
+    if (ctx->pinned_cap >= bytes) return ctx->pinned;
+    if (ctx->pinned) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_cap = 0;
+    }
+    size_t cap = (size_t)1 << 20;
+    while (cap < bytes) cap <<= 1;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ctx->pinned = p;
+    ctx->pinned_cap = cap;
+    return p;
+}
+
 static bool usable_in_place(const double* p, int64_t rows, int64_t ld)
 {
     return is_device_ptr(p) && ld >= (rows > 0 ? rows : 1);
@@ -133,6 +158,17 @@ int Staged::in(const double* src, int64_t r, int64_t c, int64_t ldsrc)
     if (!dev) return FR_OUT_OF_MEMORY;
     owns = true;
     const bool src_dev = is_device_ptr(src);
+    if (!src_dev) {
+        // host data: packed into the pinned bounce buffer by the CPU, then one DMA
+        double* pin = (double*)pinned_get(ctx, sizeof(double) * (size_t)r * (size_t)c);
+        if (pin) {
+            FR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the previous user of the bounce buffer
+            for (int64_t j = 0; j < c; ++j) memcpy(pin + j * r, src + j * ldsrc, sizeof(double) * (size_t)r);
+            FR_HIP(ctx, hipMemcpy2DAsync(dev, sizeof(double) * ld, pin, sizeof(double) * r, sizeof(double) * r, c,
+                                         hipMemcpyHostToDevice, ctx->stream));
+            return FR_OK;  // asynchronous: the caller's memory is already free, the bounce buffer is stream-ordered
+        }
+    }
     FR_HIP(ctx, hipMemcpy2DAsync(dev, sizeof(double) * ld, src, sizeof(double) * ldsrc, sizeof(double) * r, c,
                                  src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     // pageable host memory: make sure the runtime is done with the caller's buffer before we return to it
@@ -331,6 +367,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (ctx->trsv_gran) (void)hipFree(ctx->trsv_gran);
     if (ctx->syrk_ctr) (void)hipFree(ctx->syrk_ctr);
     if (ctx->trsmn_buf) (void)hipFree(ctx->trsmn_buf);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
@@ -498,6 +535,106 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         return FR_OK;
     }
     return set_err(ctx, FR_INVALID_ARGUMENT, "unknown option %s", name);
+}
+
+int fr_inputs_to_device(fr_ctx* ctx, int layout, const void* data, int64_t n, int64_t d, int64_t stride, double** out_dev,
+                        int64_t* out_ld)
+{
+    if (!ctx || !out_dev || !out_ld) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
+    *out_dev = nullptr;
+    *out_ld = 0;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    if (n < 0 || d < 0) return set_err(ctx, FR_SHAPE, "negative input shape");
+    if (layout == FR_LAYOUT_ROWPTRS && n > 0 && d == 0) return set_err(ctx, FR_SHAPE, "samples without features");
+    if (layout == FR_LAYOUT_COLMAJOR && stride < (n > 0 ? n : 1)) return set_err(ctx, FR_SHAPE, "column stride below the row count");
+    if (layout == FR_LAYOUT_ROWMAJOR && stride < (d > 0 ? d : 1)) return set_err(ctx, FR_SHAPE, "row stride below the feature count");
+    if (layout < 0 || layout > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "unknown input layout");
+    if (n > 0 && d > 0 && !data) return set_err(ctx, FR_INVALID_ARGUMENT, "null input data");
+    const int64_t ld = round_up(n > 0 ? n : 1, kAlign);
+    double* out = nullptr;
+    FR_HIP(ctx, dev_malloc(ctx, (void**)&out, sizeof(double) * (size_t)ld * (size_t)(d > 0 ? d : 1)));
+    int st = FR_OK;
+    if (n > 0 && d > 0) {
+        const bool dev_src = layout != FR_LAYOUT_ROWPTRS && is_device_ptr(data);
+        if (layout == FR_LAYOUT_COLMAJOR) {
+            const double* src = (const double*)data;
+            if (dev_src) {
+                if (hipMemcpy2DAsync(out, sizeof(double) * ld, src, sizeof(double) * stride, sizeof(double) * n, d,
+                                     hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                    st = set_err(ctx, FR_HIP_ERROR, "device copy failed");
+            } else {
+                double* pin = (double*)pinned_get(ctx, sizeof(double) * (size_t)n * (size_t)d);
+                (void)hipStreamSynchronize(ctx->stream);
+                if (pin) {
+                    for (int64_t j = 0; j < d; ++j) memcpy(pin + j * n, src + j * stride, sizeof(double) * (size_t)n);
+                    src = pin;
+                    stride = n;
+                }
+                if (hipMemcpy2DAsync(out, sizeof(double) * ld, src, sizeof(double) * stride, sizeof(double) * n, d,
+                                     hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    st = set_err(ctx, FR_HIP_ERROR, "upload failed");
+                if (!pin) (void)hipStreamSynchronize(ctx->stream);
+            }
+        } else {
+            // row-major: the samples reach the device as they are (d contiguous values each) and are transposed there
+            WsGuard tmpg(ctx);
+            const double* rm = (const double*)data;  // row-major n x d with row stride `stride` (device) ...
+            int64_t rstride = stride;
+            if (!dev_src) {
+                double* tmp = tmpg.get(sizeof(double) * (size_t)n * (size_t)d);
+                if (!tmp) {
+                    (void)hipFree(out);
+                    return FR_OUT_OF_MEMORY;
+                }
+                double* pin = (double*)pinned_get(ctx, sizeof(double) * (size_t)n * (size_t)d);
+                (void)hipStreamSynchronize(ctx->stream);
+                std::vector<double> pageable;
+                if (!pin) {
+                    pageable.resize((size_t)n * (size_t)d);
+                    pin = pageable.data();
+                }
+                if (layout == FR_LAYOUT_ROWPTRS) {
+                    const double* const* rows = (const double* const*)data;
+                    for (int64_t r = 0; r < n; ++r) {
+                        if (!rows[r]) {
+                            (void)hipFree(out);
+                            return set_err(ctx, FR_INVALID_ARGUMENT, "null sample pointer (row %lld)", (long long)r);
+                        }
+                        memcpy(pin + r * d, rows[r], sizeof(double) * (size_t)d);
+                    }
+                } else if (stride == d) {
+                    memcpy(pin, data, sizeof(double) * (size_t)n * (size_t)d);
+                } else {
+                    for (int64_t r = 0; r < n; ++r) memcpy(pin + r * d, (const double*)data + r * stride, sizeof(double) * (size_t)d);
+                }
+                if (hipMemcpyAsync(tmp, pin, sizeof(double) * (size_t)n * (size_t)d, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                    st = set_err(ctx, FR_HIP_ERROR, "upload failed");
+                if (!pageable.empty()) (void)hipStreamSynchronize(ctx->stream);
+                rm = tmp;
+                rstride = d;
+            }
+            // a row-major n x d matrix is a column-major d x n one with leading dimension rstride: transpose it
+            if (st == FR_OK) st = launch_transpose(ctx, rm, d, n, rstride, out, ld);
+            if (st == FR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = set_err(ctx, FR_HIP_ERROR, "staging failed");
+        }
+    }
+    if (st != FR_OK) {
+        (void)hipFree(out);
+        return st;
+    }
+    *out_dev = out;
+    *out_ld = ld;
+    return FR_OK;
+}
+
+void fr_device_free(fr_ctx* ctx, double* dev)
+{
+    if (!ctx || !dev) return;
+    FR_LOCK(ctx);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
 }
 
 int fr_ctx_profile_enable(fr_ctx* ctx, int enable)

@@ -103,6 +103,9 @@ struct fr_ctx {
     void* trsv_gran = nullptr;
     size_t trsv_gran_cap = 0;
     bool trsv_lds_set = false;
+    // pinned bounce buffer of the host <-> device staging (grow-only)
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
     // hand-off payload + flags of the multi-column persistent solves (trsm_narrow.hip), grow-only
     void* trsmn_buf = nullptr;
     size_t trsmn_buf_cap = 0;
@@ -183,6 +186,7 @@ bool is_device_ptr(const void* p);
 // workspace: returns nullptr on failure (error recorded in ctx)
 void* ws_get(fr_ctx* ctx, size_t bytes);
 void ws_put(fr_ctx* ctx, void* p);
+void* pinned_get(fr_ctx* ctx, size_t bytes);                    // the context's pinned bounce buffer, at least `bytes` (nullptr: none)
 size_t ws_trim(fr_ctx* ctx);                                   // frees the idle pool buffers, returns the bytes released
 hipError_t dev_malloc(fr_ctx* ctx, void** p, size_t bytes);    // hipMalloc, retried once after ws_trim
 

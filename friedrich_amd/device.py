@@ -25,11 +25,33 @@ def _is_torch(x):
     return hasattr(x, "data_ptr") and hasattr(x, "stride")
 
 
+class DeviceMatrix:
+    """a column-major n x d matrix in HBM produced by fr_inputs_to_device (the `Input` staging of conversion/mod.rs);
+    accepted wherever a data matrix is"""
+
+    def __init__(self, ctx, ptr, rows, cols, ld):
+        self.ctx, self.ptr, self.rows, self.cols, self.ld = ctx, ptr, rows, cols, ld
+
+    def free(self):
+        if self.ptr and getattr(self.ctx, "h", None):
+            self.ctx.lib.fr_device_free(self.ctx.h, ctypes.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class _Mat:
     """pointer + shape + ld view of a host/device matrix; keeps the backing object alive"""
 
     def __init__(self, obj, writable=False, vector=False):
-        if _is_torch(obj):
+        if isinstance(obj, DeviceMatrix):
+            self.rows, self.cols, self.ld = obj.rows, obj.cols, obj.ld
+            self.keep, self.ptr, self.host = obj, obj.ptr, None
+        elif _is_torch(obj):
             t = obj
             if t.dim() == 1:
                 if t.numel() > 1 and t.stride(0) != 1:
@@ -156,6 +178,31 @@ class Context:
     def comm_init_local(self, group_id, rank, world_size):
         """in-process transport (ranks = threads sharing one GPU); see fr_ctx_comm_init_local"""
         self.check(self.lib.fr_ctx_comm_init_local(self.h, int(group_id), int(rank), int(world_size)))
+
+    # src/conversion/mod.rs ------------------------------------------------------------------------
+    def inputs_to_device(self, data, layout="rowmajor"):
+        """Input::to_dmatrix + upload in one pass (pinned bounce buffer, device-side transpose of row-major samples).
+        data: 2-D numpy array in the named layout ("colmajor" | "rowmajor"), or a list of 1-D arrays ("rowptrs" = Vec<Vec<f64>>)"""
+        dev, ld = ctypes.c_void_p(), ctypes.c_int64()
+        if layout == "rowptrs":
+            rows = [np.ascontiguousarray(np.asarray(r, dtype=np.float64)) for r in data]
+            n, d = len(rows), (rows[0].shape[0] if rows else 0)
+            ptrs = (ctypes.c_void_p * max(n, 1))(*[r.ctypes.data for r in rows])
+            st = self.lib.fr_inputs_to_device(self.h, 2, ctypes.cast(ptrs, ctypes.c_void_p), n, d, 0, ctypes.byref(dev),
+                                              ctypes.byref(ld))
+        else:
+            a = np.asarray(data, dtype=np.float64)
+            n, d = a.shape
+            if layout == "rowmajor":
+                a = np.ascontiguousarray(a)
+                st = self.lib.fr_inputs_to_device(self.h, 1, ctypes.c_void_p(a.ctypes.data), n, d, max(d, 1), ctypes.byref(dev),
+                                                  ctypes.byref(ld))
+            else:
+                a = np.asfortranarray(a)
+                st = self.lib.fr_inputs_to_device(self.h, 0, ctypes.c_void_p(a.ctypes.data), n, d, max(n, 1), ctypes.byref(dev),
+                                                  ctypes.byref(ld))
+        self.check(st)
+        return DeviceMatrix(self, dev.value, n, d, ld.value)
 
     # src/algebra/mod.rs ---------------------------------------------------------------------------
     def gram(self, kernel, A, B, out=None):

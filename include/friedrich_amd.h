@@ -139,6 +139,24 @@ int fr_ctx_comm_info(const fr_ctx* ctx, int* rank, int* world_size);
  * No reference counterpart (friedrich is single-process); FR_OK when no communicator is attached. */
 int fr_ctx_comm_selftest(fr_ctx* ctx);
 
+/* ---- src/conversion/mod.rs: the `Input` trait --------------------------------------------------------- */
+/* Input::to_dmatrix / into_dmatrix (conversion/mod.rs:58-201) turn the caller's samples -- Vec<Vec<f64>> (one Vec per
+ * sample, :121-146), a row-major ndarray (:149-201), a single Vec<f64> sample (:95-118), a DMatrix (:65-92) -- into a
+ * column-major DMatrix by copying element by element on the host; the matrix would then be copied once more to the GPU.
+ * fr_inputs_to_device does both in one pass: the samples go through a pinned bounce buffer of the context (grow-only)
+ * straight to the device, and row-major data are transposed there.  *out_dev is a device-resident column-major n x d
+ * matrix with leading dimension *out_ld (a multiple of 64) that every entry point of this header accepts as a data pointer;
+ * release it with fr_device_free.  `data` may itself be a device pointer (FR_LAYOUT_COLMAJOR / FR_LAYOUT_ROWMAJOR). */
+typedef enum {
+    FR_LAYOUT_COLMAJOR = 0, /* const double*: element (r, c) at data[r + c * stride]   (DMatrix; stride >= n) */
+    FR_LAYOUT_ROWMAJOR = 1, /* const double*: element (r, c) at data[r * stride + c]   (ndarray standard layout, a single Vec<f64>
+                               sample with n = 1; stride >= d) */
+    FR_LAYOUT_ROWPTRS = 2   /* const double* const*: data[r] points to the d values of sample r (Vec<Vec<f64>>); stride unused */
+} fr_layout;
+int fr_inputs_to_device(fr_ctx* ctx, int layout, const void* data, int64_t n, int64_t d, int64_t stride, double** out_dev,
+                        int64_t* out_ld);
+void fr_device_free(fr_ctx* ctx, double* dev);
+
 /* ---- src/algebra/mod.rs --------------------------------------------------------------------------- */
 /* make_covariance_matrix (algebra/mod.rs:41-54): out[r,c] = k(A.row(r), B.row(c)), out is n1 x n2. */
 int fr_gram(fr_ctx* ctx, const fr_kprog* kernel, const double* A, int64_t n1, int64_t lda, const double* B,

@@ -578,3 +578,28 @@ def test_narrow_persistent_solves_2_to_16_columns(ctx, n, m):
     st, L1, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
     assert rel_err(chol.solve(B), O.chol_solve(L1, B)) < TOL
     chol.free()
+
+
+# ---- `Input` staging (conversion/mod.rs:58-201) ---------------------------------------------
+@pytest.mark.parametrize("n,d", [(1, 1), (1, 5), (333, 1), (1000, 7), (4100, 16)])
+def test_inputs_to_device_layouts(ctx, n, d):
+    """fr_inputs_to_device: Vec<Vec<f64>> (row pointers), row-major ndarray, column-major DMatrix -> the same device matrix;
+    a Gram matrix / factor / predict built from the staged inputs equals the oracle's on the host inputs."""
+    rng = np.random.default_rng(n * 31 + d)
+    Xr = np.ascontiguousarray(rng.random((n, d)))  # row-major samples
+    k = ("matern2", 0.9, 1.1)
+    want = O.make_covariance_matrix(k, Xr, Xr[: min(n, 50)])
+    staged = [ctx.inputs_to_device(Xr, "rowmajor"), ctx.inputs_to_device(np.asfortranarray(Xr), "colmajor"),
+              ctx.inputs_to_device([Xr[i] for i in range(n)], "rowptrs")]
+    head = ctx.inputs_to_device(Xr[: min(n, 50)], "rowmajor")
+    for s_ in staged:
+        assert (s_.rows, s_.cols) == (n, d) and s_.ld >= n and s_.ld % 64 == 0
+        assert rel_err(ctx.gram(k, s_, head), want) < TOL_GRAM
+    if n >= 300:
+        gp = O.OracleGP(O.ZeroPrior(), k, 0.1, None, Xr, np.sin(Xr.sum(axis=1)))
+        chol = ctx.cholesky_from_inputs(k, staged[0], 0.1)
+        assert rel_err(chol.l(), np.tril(gp.L)) < TOL
+        assert rel_err(chol.predict_mean(k, gp.y, head, None), gp.predict(Xr[: min(n, 50)])) < TOL
+        chol.free()
+    for s_ in staged + [head]:
+        s_.free()
