@@ -84,6 +84,7 @@ SIGNATURES = {
     "fr_ctx_comm_selftest": (_int, [_vp]),
     "fr_inputs_to_device": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _pp, _pi64]),
     "fr_device_free": (None, [_vp, _vp]),
+    "fr_linear_prior_fit": (_int, [_vp, _dp, _i64, _i64, _i64, _dp, _pdbl, _pdbl]),
     "fr_gram": (_int, [_vp, _kp, _dp, _i64, _i64, _dp, _i64, _i64, _i64, _dp, _i64]),
     "fr_chol_from_inputs": (_int, [_vp, _kp, _dp, _i64, _i64, _i64, _dbl, _int, _dbl, _i64, _pp]),
     "fr_chol_refactor": (_int, [_vp, _kp, _dbl, _int, _dbl]),

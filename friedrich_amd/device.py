@@ -204,6 +204,16 @@ class Context:
         self.check(st)
         return DeviceMatrix(self, dev.value, n, d, ld.value)
 
+    # src/parameters/prior.rs ----------------------------------------------------------------------
+    def linear_prior_fit(self, X, y):
+        """LinearPrior::fit (prior.rs:139-159) -> (weights [d], intercept)"""
+        x = _Mat(X)
+        yp, _, keep = _vecptr(y)
+        w = (ctypes.c_double * max(x.cols, 1))()
+        b = ctypes.c_double()
+        self.check(self.lib.fr_linear_prior_fit(self.h, x.ptr, x.rows, x.ld, x.cols, yp, w, ctypes.byref(b)))
+        return np.array(w[:x.cols]), b.value
+
     # src/algebra/mod.rs ---------------------------------------------------------------------------
     def gram(self, kernel, A, B, out=None):
         """make_covariance_matrix (algebra/mod.rs:41-54)"""

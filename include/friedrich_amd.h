@@ -250,6 +250,14 @@ int fr_gemm(fr_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t
 /* fit_bandwidth_mean (kernel.rs:94-113): mean Euclidean distance over the n(n-1)/2 row pairs */
 int fr_mean_pairwise_distance(fr_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t d, double* out);
 
+/* ---- src/parameters/prior.rs ------------------------------------------------------------------------ */
+/* LinearPrior::fit (prior.rs:139-159): least squares of [1 | X] w = y, where the reference runs nalgebra's SVD solve on
+ * the host.  Tall-skinny Householder QR on the device + the SVD of the (d + 1) x (d + 1) triangle on the host: the same
+ * singular-value solve (eps = 0) without forming the normal equations and without moving X.  out_weights: d values,
+ * *out_intercept: the constant term.  d <= 62 on the device (FR_UNSUPPORTED_KERNEL beyond: keep the nalgebra path). */
+int fr_linear_prior_fit(fr_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t d, const double* y,
+                        double* out_weights, double* out_intercept);
+
 /* ---- src/gaussian_process/optimizer.rs ------------------------------------------------------------- */
 /* The per-iteration reductions of gradient_marginal_likelihood (:24-60, scaled = 0) and
  * scaled_gradient_marginal_likelihood (:159-203, scaled = 1) without materialising K^-1 G_q products on

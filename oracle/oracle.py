@@ -416,8 +416,11 @@ class LinearPrior:  # prior.rs:108-160
 
     def fit(self, X, y):
         # :139-159 : SVD least squares on [1 | X]
+        # [nalgebra] SVD::solve(b, eps = 0): x = V diag(1 / sigma_i if sigma_i > eps else 0) U^T b
         A = np.hstack([np.ones((np.asarray(X).shape[0], 1)), np.asarray(X, dtype=np.float64)])
-        w = np.linalg.lstsq(A, np.asarray(y, dtype=np.float64), rcond=None)[0]
+        U, sv, Vt = np.linalg.svd(A, full_matrices=False)
+        inv = np.array([1.0 / v if v > 0.0 else 0.0 for v in sv])
+        w = Vt.T @ (inv * (U.T @ np.asarray(y, dtype=np.float64)))
         self.intercept = float(w[0])
         self.weights = w[1:].copy()
 

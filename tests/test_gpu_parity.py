@@ -603,3 +603,28 @@ def test_inputs_to_device_layouts(ctx, n, d):
         chol.free()
     for s_ in staged + [head]:
         s_.free()
+
+
+# ---- LinearPrior::fit (prior.rs:139-159) ------------------------------------------------------
+@pytest.mark.parametrize("n,d", [(4, 1), (5, 3), (300, 2), (257, 16), (5000, 8), (40000, 16)])
+def test_linear_prior_fit_matches_svd_least_squares(ctx, n, d):
+    """device TSQR + small SVD vs the oracle's restatement of the reference (nalgebra's SVD solve with eps = 0), including an
+    exactly rank-deficient design."""
+    rng = np.random.default_rng(n + d)
+    X = np.asfortranarray(rng.random((n, d)) * 3.0 - 1.0)
+    y = X @ rng.standard_normal(d) + 0.7 + 0.05 * rng.standard_normal(n)
+    prior = O.LinearPrior.default(d)
+    prior.fit(X, y)
+    w, b = ctx.linear_prior_fit(X, y)
+    assert abs(b - prior.intercept) < 1e-9 * (1.0 + abs(prior.intercept))
+    assert rel_err(w, prior.weights) < 1e-9
+    if d >= 2 and n > d + 2:
+        # a feature that is identically zero: its singular value is EXACTLY zero, the one case the reference's eps = 0
+        # treats as rank deficient (the direction is dropped).  (A duplicated feature has a singular value of rounding size,
+        # which nalgebra inverts: the reference's result is then rounding noise, nothing to compare with.)
+        X2 = np.asfortranarray(np.hstack([X, np.zeros((n, 1))]))
+        p2 = O.LinearPrior.default(d + 1)
+        p2.fit(X2, y)
+        w2, b2 = ctx.linear_prior_fit(X2, y)
+        assert w2[-1] == 0.0 and abs(p2.weights[-1]) < 1e-12
+        assert rel_err(w2, p2.weights) < 1e-9 and abs(b2 - p2.intercept) < 1e-9
