@@ -337,11 +337,17 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
     double* pbuf = nullptr;
     if (world > 1) {
         pbuf = pg.get(sizeof(double) * (size_t)(n * imin(nb, n) + ((nb + IB - 1) / IB) * INV_ELEMS));
+        // every allocation of this rank is behind it: agree with the peers BEFORE the first panel exchange, so that a rank
+        // that ran out of memory does not leave the others inside a broadcast that never completes
+        bool all_ok = true;
+        FR_TRY(comm_agree(ctx, pbuf != nullptr, &all_ok));
         if (!pbuf) return FR_OUT_OF_MEMORY;
+        if (!all_ok) return set_err(ctx, FR_OUT_OF_MEMORY, "a peer rank could not allocate its panel buffers: sharded factorisation abandoned on every rank");
     }
     hipStream_t S0 = ctx->stream, S1 = ctx->stream2;
     int st = FR_OK;
     auto fail = [&](int code) {
+        if (world > 1) comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
         ctx->ls = S0;
         (void)hipStreamSynchronize(S1);
         return code;

@@ -26,6 +26,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -49,6 +50,7 @@ static int rccl_load(fr_ctx* ctx)
     LOAD(GetUniqueId);
     LOAD(CommInitRank);
     LOAD(CommDestroy);
+    LOAD(CommAbort);
     LOAD(Broadcast);
     LOAD(AllGather);
     LOAD(GetErrorString);
@@ -182,6 +184,44 @@ int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_p
     return FR_OK;
 }
 
+// Every rank contributes ok (1) / failed (0); all learn whether EVERY rank is ok.  Used before the first panel exchange of a
+// sharded factorisation: a rank that could not allocate its buffers must not leave its peers waiting inside a broadcast
+// (RCCL collectives have no timeout).  Synchronises the launch stream.
+int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok)
+{
+    *all_ok = ok;
+    if (ctx->world <= 1) return FR_OK;
+    if (!ctx->agree_buf) FR_HIP(ctx, hipMalloc((void**)&ctx->agree_buf, sizeof(int64_t) * 65));
+    int64_t mine = ok ? 1 : 0;
+    FR_HIP(ctx, hipMemcpyAsync(ctx->agree_buf, &mine, sizeof(int64_t), hipMemcpyHostToDevice, ctx->ls));
+    FR_TRY(comm_allgather_i64(ctx, ctx->agree_buf, ctx->agree_buf + 1, 1));
+    std::vector<int64_t> h((size_t)ctx->world);
+    FR_HIP(ctx, hipMemcpyAsync(h.data(), ctx->agree_buf + 1, sizeof(int64_t) * h.size(), hipMemcpyDeviceToHost, ctx->ls));
+    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    for (int64_t v : h)
+        if (v != 1) *all_ok = false;
+    return FR_OK;
+}
+
+// A rank that fails on the host side in the middle of a sharded factorisation tears its communicator down instead of
+// leaving through a normal return: its peers' pending collectives then end in an error (RCCL) / a broken barrier (local
+// transport) rather than waiting forever.  The context cannot take part in collectives afterwards.
+void comm_abort(fr_ctx* ctx)
+{
+    if (ctx->comm && g_rccl.CommAbort) {
+        (void)g_rccl.CommAbort((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+        ctx->world = 1;
+        ctx->rank = 0;
+    }
+    if (ctx->local) {
+        LocalGroup* g = ((LocalComm*)ctx->local)->g;
+        std::lock_guard<std::mutex> lk(g->m);
+        g->broken = true;
+        g->cv.notify_all();
+    }
+}
+
 }  // namespace fr
 
 using namespace fr;
@@ -193,6 +233,10 @@ void fr_comm_destroy_internal(fr_ctx* ctx)
     if (ctx->comm && g_rccl.CommDestroy) {
         g_rccl.CommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
+    }
+    if (ctx->agree_buf) {
+        (void)hipFree(ctx->agree_buf);
+        ctx->agree_buf = nullptr;
     }
     if (ctx->local) {
         LocalComm* lc = (LocalComm*)ctx->local;

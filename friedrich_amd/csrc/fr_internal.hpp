@@ -111,6 +111,7 @@ struct fr_ctx {
     size_t trsmn_buf_cap = 0;
     // RCCL
     void* comm = nullptr;   // ncclComm_t
+    int64_t* agree_buf = nullptr;  // 1 + world slots of the status agreement (comm_agree)
     void* local = nullptr;  // in-process ("local") communicator: ranks are host threads sharing one device
     int rank = 0;
     int world = 1;
@@ -354,6 +355,8 @@ int check_status_word(fr_ctx* ctx);
 int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root);
 int comm_allgather_i64(fr_ctx* ctx, const int64_t* send, int64_t* recv, size_t count_per_rank);
 int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_per_rank);
+int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok);  // collective: does EVERY rank report ok?  (synchronises)
+void comm_abort(fr_ctx* ctx);                        // failing rank: tear the communicator down so that peers do not wait forever
 
 // ---- blocked algorithms (chol.hip) ------------------------------------------------------------------
 // in-place Cholesky of the lower triangle of the n x n block at A (rows/cols offset col0 for bookkeeping)
