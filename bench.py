@@ -30,7 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_NB = 1024  # block size of the run profiles/r02/pmc_traffic.json was collected with
+PMC_NB = 1024  # block size of the run profiles/r02/fit32k_counters.json was collected with
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; scripts/mfma_f64_peak measures 77.0-77.6 on the box
 
 
@@ -65,12 +65,22 @@ def strong_cpu_line(n):
     rng = np.random.default_rng(0)
     Q = rng.standard_normal((n, 64))
     A = Q @ Q.T + n * np.eye(n)
-    sl.cholesky(A[:512, :512], lower=True)
-    t0 = time.perf_counter()
-    sl.cholesky(A, lower=True, overwrite_a=True, check_finite=False)
-    dt = time.perf_counter() - t0
-    return {"what": f"scipy.linalg.cholesky (LAPACK dpotrf, all host threads) of a {n} x {n} matrix", "seconds": dt,
-            "GFLOP/s": n ** 3 / 3.0 / dt / 1e9}
+    threads = min(os.cpu_count() or 1, 64)  # one thread per physical core of a socket: more only adds contention at this size
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=threads)
+    except Exception:
+        limit, threads = None, os.cpu_count() or 1
+    try:
+        sl.cholesky(A[:1024, :1024], lower=True)
+        t0 = time.perf_counter()
+        sl.cholesky(A, lower=True, overwrite_a=True, check_finite=False)
+        dt = time.perf_counter() - t0
+    finally:
+        if limit is not None:
+            limit.restore_original_limits()
+    return {"what": f"scipy.linalg.cholesky (LAPACK dpotrf, {threads} threads) of a {n} x {n} matrix", "seconds": dt,
+            "GFLOP/s": n ** 3 / 3.0 / dt / 1e9, "threads": threads}
 
 
 def cpu_baseline(n, d, m, cfg):
@@ -109,7 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--d", type=int, default=16)
-    ap.add_argument("--m", type=int, default=5120)
+    ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block; 0 = the library's choice (1024 on one GPU at this size, 512 sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=5120)
@@ -265,11 +275,11 @@ def main():
         # PMC counters cannot be read from inside the process: the figure is the committed rocprofv3 --pmc summary of the
         # same workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction); null for any other size
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02", "fit32k_counters.json")
         if os.path.exists(pmc_path) and (n, d, nb_eff, world) == (32768, 16, PMC_NB, 1):
             with open(pmc_path) as f:
-                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]
-            traffic_src = "profiles/r02/pmc_traffic.json"
+                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: regenerate (scripts/profile_r02.sh) whenever gemm_f64.hip / gemm_tile.hpp change
+            traffic_src = "profiles/r02/fit32k_counters.json"
         out = {
             "metric": "gp_fit_predict_gflops",
             "value": total_flops / (ms_per_step * 1e-3) / 1e9,

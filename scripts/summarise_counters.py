@@ -11,7 +11,7 @@ prefix, out_path, desc = sys.argv[1], sys.argv[2], sys.argv[3]
 
 
 def newest(pat):
-    fs = glob.glob(pat)
+    fs = glob.glob(pat) or glob.glob(pat.replace("/runc/", "/**/"), recursive=True) or glob.glob(pat.replace("/runc/", "/"))
     fs.sort(key=os.path.getmtime)
     return fs[-1]
 
@@ -41,6 +41,19 @@ for k, a in agg.items():
         e["write_GB"] = round(a["WRITE_SIZE"] * 1024 / 1e9, 3)
     if "fetch_GB" in e and "write_GB" in e:
         e["fabric_TB_per_s"] = round((e["fetch_GB"] + e["write_GB"]) / (tot / 1e9) / 1e3, 3)
+    sq = {k2: v for k2, v in a.items() if k2.startswith("SQ_")}
+    if sq:
+        e["sq"] = sq
+        if sq.get("SQ_BUSY_CYCLES") and sq.get("SQ_ACTIVE_INST_VALU"):
+            # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles summed over waves; per-wave VALU-issue share:
+            if sq.get("SQ_WAVE_CYCLES"):
+                e["valu_active_share_of_wave_cycles"] = round(sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], 3)
+            if sq.get("SQ_WAIT_INST_ANY") and sq.get("SQ_WAVE_CYCLES"):
+                e["wait_inst_share_of_wave_cycles"] = round(sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"], 3)
+    if "fetch_GB" in e and "write_GB" in e:
+        e["fetch_bytes_per_launch"] = e["fetch_GB"] * 1e9 / calls
+        e["write_bytes_per_launch"] = e["write_GB"] * 1e9 / calls
+        e["total_bytes_per_launch"] = (e["fetch_GB"] + e["write_GB"]) * 1e9 / calls
     if a.get("SQ_INSTS_VALU_MFMA_MOPS_F64"):
         fl = a["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512
         e["mfma_TFLOP_per_s"] = round(fl / (tot / 1e9) / 1e12, 2)
