@@ -346,6 +346,10 @@ int fr_ctx_create(fr_ctx** out, int device)
         fr_ctx_destroy(ctx);
         return FR_HIP_ERROR;
     }
+    if (hipMalloc((void**)&ctx->yield_word, 64) != hipSuccess || hipMemset(ctx->yield_word, 0, 64) != hipSuccess) {
+        fr_ctx_destroy(ctx);
+        return FR_HIP_ERROR;
+    }
     *out = ctx;
     return FR_OK;
 }
@@ -368,6 +372,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (ctx->syrk_ctr) (void)hipFree(ctx->syrk_ctr);
     if (ctx->trsmn_buf) (void)hipFree(ctx->trsmn_buf);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->yield_word) (void)hipFree(ctx->yield_word);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
@@ -495,6 +500,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "panel_fused")) {
         if (value < 0 || value > 3) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_fused must be 0, 1, 2 (or the probe value 3)");
         ctx->panel_fused = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "k4_yield")) {
+        ctx->k4_yield = value != 0;
         return FR_OK;
     }
     if (!strcmp(name, "refine")) {

@@ -83,6 +83,9 @@ struct fr_ctx {
     int64_t prof_launches[FR_PROF_COUNT] = {0};
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
+    // cooperative yield: GEMM waves sleep while the diagonal-block kernel works on their CU (gemm_tile.hpp)
+    int64_t k4_yield = 0;  // measured: K4 153 -> 106 us at N = 16384, but the extra load in the pinned K-loop costs the GEMMs 12 - 35 %
+    unsigned* yield_word = nullptr;  // device
     int64_t syrk_dynamic = 0;   // trailing update: tiles pulled from per-XCD work lists by resident workgroups (gemm_f64.hip)
     unsigned* syrk_ctr = nullptr;
     int64_t syrk_dynamic_tiles = 3;

@@ -25,7 +25,7 @@
 
 namespace fr {
 
-template <bool A_KMAJ, bool B_KMAJ>
+template <bool A_KMAJ, bool B_KMAJ, bool YIELD = false>
 __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
 {
 
@@ -88,7 +88,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
     }
     const int64_t m0 = tm * BM, n0 = tn * BN;
     if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) return;
-    gemm_f64_tile<A_KMAJ, B_KMAJ>(g, lds, m0, n0);
+    gemm_f64_tile<A_KMAJ, B_KMAJ, YIELD>(g, lds, m0, n0);
 }
 
 // Two kernel symbols over the same body: the lower-mode launch is the trailing SYRK update of the factorisation (the
@@ -110,6 +110,25 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g
 {
     __shared__ double lds[4 * TILE_ELEMS];
     gemm_f64_body<false, false>(g, lds);
+}
+
+// the same two kernels with the cooperative yield compiled in (gemm_tile.hpp): launched when a yield word is attached
+__global__ __launch_bounds__(256, 2) void syrk_lower_yield_f64_kernel(const GemmArgs g)
+{
+    __shared__ double lds[4 * TILE_ELEMS];
+    gemm_f64_body<false, false, true>(g, lds);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nn_yield_f64_kernel(const GemmArgs g0)
+{
+    __shared__ double lds[4 * TILE_ELEMS];
+    GemmArgs g = g0;
+    const int64_t bz = blockIdx.y;
+    g.A += bz * g.batch_a;
+    g.B += bz * g.batch_b;
+    g.Cin += bz * g.batch_c;
+    g.D += bz * g.batch_d;
+    gemm_f64_body<false, false, true>(g, lds);
 }
 
 // The same trailing update with the tiles pulled from work lists instead of dealt statically: 2 workgroups per CU stay
@@ -286,6 +305,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     }
     const double nbatch = d.batch > 1 ? (double)d.batch : 1.0;
     ProfScope ps(ctx, d.prof_cls, flops * nbatch, bytes * nbatch);
+    g.yield_word = (ctx->k4_yield && d.batch <= 1) ? ctx->yield_word : nullptr;
     g.batch_a = d.batch_a;
     g.batch_b = d.batch_b;
     g.batch_c = d.batch_c;
@@ -302,8 +322,12 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         const int per = (int)ctx->syrk_dynamic_tiles;
         const int64_t wgs = (ntiles + per - 1) / per;
         hipLaunchKernelGGL(syrk_lower_dyn_kernel, dim3((unsigned)(wgs + wgs / 8 + 8)), block, 0, ctx->ls, g, ctx->syrk_ctr, per);
-    } else if (d.lower && !d.a_kmajor && !d.b_kmajor)
+    } else if (d.lower && !d.a_kmajor && !d.b_kmajor && g.yield_word)
+        hipLaunchKernelGGL(syrk_lower_yield_f64_kernel, grid, block, 0, ctx->ls, g);
+    else if (d.lower && !d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL(syrk_lower_f64_kernel, grid, block, 0, ctx->ls, g);
+    else if (!d.a_kmajor && !d.b_kmajor && g.yield_word)
+        hipLaunchKernelGGL(gemm_nn_yield_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && d.b_kmajor)

@@ -34,6 +34,9 @@ struct GemmArgs {
     int64_t own_nb, own_col0;
     // batch: blockIdx.y selects a problem; operands advance by these strides (elements)
     int64_t batch_a, batch_b, batch_c, batch_d;
+    // cooperative yield (see cu_key / yield_if_asked): word that names the CU on which a diagonal-block kernel wants to
+    // run undisturbed, or NULL
+    const unsigned* yield_word;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile
@@ -98,9 +101,34 @@ __device__ __forceinline__ void store_tile(double* __restrict__ S, int t, const 
     }
 }
 
+// ---- cooperative yield ---------------------------------------------------------------------------------------------------
+// The diagonal-block kernel (potf2.hip) is a chain of dependent f64 operations; sharing its CU with a GEMM workgroup makes
+// every one of them queue behind the neighbour's MFMAs (55 us alone, 150 - 265 us in situ), and it cannot have a CU to
+// itself (a workgroup that only fits an empty CU is starved by the trailing update's queue; one that holds a CU costs the
+// other kernels an eighth of an engine: DESIGN.md section 5).  So the NEIGHBOUR steps aside: the diagonal-block kernel
+// publishes the identity of its CU in a global word, every GEMM wave looks at the word once per K-step (a load issued at the
+// top of the step, consumed at its end: no stall) and sleeps while the word names its own CU.  One tile of the trailing
+// update finishes ~60 us late; the pivot chain gets the CU's issue slots.
+__device__ __forceinline__ unsigned cu_key()
+{
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    return ((xcc & 0xfu) << 16) | (hw & 0xff00u) | 1u;  // (XCC, SE / SH / CU fields of HW_ID): unique per CU (scripts/hwid_probe.hip)
+}
+
+__device__ __forceinline__ void yield_if_asked(const unsigned* word, unsigned seen, unsigned mine)
+{
+    if (seen != mine) return;
+    for (int spins = 0; spins < 4000; ++spins) {  // bounded: ~2 ms
+        __builtin_amdgcn_s_sleep(20);
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine) break;
+    }
+}
+
 // One 128 x 128 result tile at (m0, n0): the whole K-loop and the epilogue.  Called by the GEMM kernels (one tile per
 // workgroup) and by the fused panel kernel (panel.hip: a workgroup walks through the tile products of its row tile).
-template <bool A_KMAJ, bool B_KMAJ>
+template <bool A_KMAJ, bool B_KMAJ, bool YIELD = false>
 __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, const int64_t m0, const int64_t n0)
 {
 
@@ -116,6 +144,9 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
 
+    // YIELD: compile-time, so that the plain instantiation keeps its pinned instruction schedule byte for byte
+    const unsigned* ywp = YIELD ? g.yield_word : nullptr;
+    const unsigned ykey = YIELD ? cu_key() : 0u;
     const int64_t nk = (g.K + BK - 1) / BK;
     const int64_t nk_full = g.K / BK;  // K-steps that need no k predicate
     const bool a_fast = (m0 + BM) <= g.M, b_fast = (n0 + BN) <= g.N;
@@ -154,6 +185,8 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, co
             pb += more ? step_b : 0;
             load_tile_fast<A_KMAJ>(pa, g.lda, ra);
             load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+            unsigned yseen = 0u;
+            if constexpr (YIELD) yseen = __hip_atomic_load(ywp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double* As = lds + cur * 2 * TILE_ELEMS;
             const double* Bs = As + TILE_ELEMS;
 #pragma unroll
@@ -194,6 +227,7 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, co
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             }
+            if constexpr (YIELD) yield_if_asked(ywp, yseen, ykey);
             __syncthreads();
             cur ^= 1;
         }

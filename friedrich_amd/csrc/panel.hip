@@ -59,6 +59,7 @@ __device__ __forceinline__ void tile_product(double* lds, int64_t M, int64_t N, 
     g.beta = beta;
     g.lower = 0;
     g.own_world = 1;
+    g.yield_word = nullptr;
     gemm_f64_tile<false, false>(g, lds, 0, 0);
 }
 

@@ -665,10 +665,25 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
 
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
-                                                   int64_t* __restrict__ info, double* __restrict__ cest)
+                                                   int64_t* __restrict__ info, double* __restrict__ cest,
+                                                   unsigned* __restrict__ yield_word)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    // ask the GEMM workgroup that shares this CU to step aside for the length of the pivot chain (gemm_tile.hpp)
+    unsigned key = 0;
+    if (yield_word && threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        key = ((xcc & 0xfu) << 16) | (hw & 0xff00u) | 1u;
+        __hip_atomic_store(yield_word, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
+    if (yield_word && threadIdx.x == 0) {
+        // (only if the word is still ours: a later diagonal-block kernel of another stream may have taken it over)
+        unsigned expect = key;
+        (void)__hip_atomic_compare_exchange_strong(yield_word, &expect, 0u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- the diagonal-block SERVER of the fused panel factorisation (panel.hip) ----------------------------------------------
@@ -766,7 +781,7 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
     }
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
     hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv,
-                       info, cest);
+                       info, cest, ctx->k4_yield ? ctx->yield_word : nullptr);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
