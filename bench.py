@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--d", type=int, default=16)
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block; 0 = the library's choice (1024 on one GPU at this size, 512 sharded)")
+    ap.add_argument("--panel-split", type=int, default=0, help="N > 1: 1 = split variant of the panel step (scatter, per-rank solves, all-gather); 0 = one broadcast per panel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=5120)
     args = ap.parse_args()
@@ -154,6 +155,7 @@ def main():
 
     ctx = Context(local_rank)
     ctx.set_option("nb", args.nb)
+    ctx.set_option("panel_split", args.panel_split)
     nb_eff = args.nb if args.nb > 0 else (1024 if (world == 1 and args.n >= 24576) else 512)
     if use_dist:
         ids = [ctx.comm_unique_id() if rank == 0 else None]
@@ -296,7 +298,7 @@ def main():
             "config": {
                 "workload": f"GP fit (Gram + Cholesky) + predict, N={n} d={d} RBF, m={m} queries, friedrich default hyper-parameters",
                 "n": n, "d": d, "m": m, "kernel": "squared_exp", "nb": nb_eff,
-                "parallelism": "1 GPU" if world == 1 else f"block-cyclic column panels over {world} GPUs (RCCL broadcast), queries sharded",
+                "parallelism": "1 GPU" if world == 1 else f"block-cyclic column panels over {world} GPUs (RCCL " + ("scatter + all-gather per panel" if args.panel_split else "broadcast per panel") + "), queries sharded",
             },
             "fit_ms": float(np.mean(fit_ms)),
             "predict_ms": float(np.mean(pred_ms)),

@@ -275,6 +275,60 @@ static int exchange_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t
     return FR_OK;
 }
 
+// The split variant of a panel step (option panel_split): the owner factors the kb x kb DIAGONAL block only and
+// broadcasts it with its inverse blocks (2.5 MB at kb = 512); the still unsolved rows below it are scattered in W equal
+// slices (each over its own xGMI link), every rank solves its slice against the diagonal block -- the serial part of the
+// step shrinks from "the whole panel on one GPU" to "the diagonal block on one GPU" -- and one all-gather, which moves
+// 1 / W of the panel over every link of every GPU, returns the slices to everybody.  buf: head (kb * kb + inverses) followed by
+// W slices of slice_rows x kb (leading dimension slice_rows).
+static int split_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode, double sub,
+                       double* dinv, int64_t* info, double* T, double* buf, int64_t slice_rows, int owner)
+{
+    const int W = ctx->world, me = ctx->rank;
+    const int64_t nblk = (kb + IB - 1) / IB;
+    const int64_t head_count = round_up(kb * kb + nblk * INV_ELEMS, kAlign);
+    const int64_t row0 = k + kb, below = n - row0;
+    double* head = buf;
+    double* slices = buf + head_count;
+    double* dblk = dinv + (k / IB) * INV_ELEMS;
+    auto rows_of = [&](int q) { return imax(0, imin(slice_rows, below - (int64_t)q * slice_rows)); };
+    if (me == owner) {
+        FR_TRY(factor_panel(ctx, A, ld, k + kb, k, kb, col0, mode, sub, dinv, info, T));  // rows k .. k + kb only
+        FR_TRY(launch_copy(ctx, A + k + k * ld, ld, head, kb, kb, kb));
+        FR_HIP(ctx, hipMemcpyAsync(head + kb * kb, dblk, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, ctx->ls));
+        for (int q = 0; q < W; ++q)
+            if (rows_of(q) > 0)
+                FR_TRY(launch_copy(ctx, A + row0 + (int64_t)q * slice_rows + k * ld, ld, slices + (int64_t)q * slice_rows * kb,
+                                   slice_rows, rows_of(q), kb));
+    }
+    FR_TRY(comm_bcast(ctx, head, (size_t)head_count, owner));
+    if (me != owner) {
+        FR_TRY(launch_copy(ctx, head, kb, A + k + k * ld, ld, kb, kb));
+        FR_HIP(ctx, hipMemcpyAsync(dblk, head + kb * kb, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, ctx->ls));
+    }
+    if (below <= 0) return FR_OK;
+    FR_TRY(comm_scatter(ctx, slices, (size_t)(slice_rows * kb), owner));
+    const int64_t mine = rows_of(me);
+    if (mine > 0) {
+        // left-looking over the 128-column sub-panels: S_s <- (S_s - S_{<s} L[s, <s]^T) W_s^T
+        double* S = slices + (int64_t)me * slice_rows * kb;
+        for (int64_t s = 0; s < nblk; ++s) {
+            const int64_t c0 = s * IB, cs = imin(IB, kb - c0);
+            if (s > 0)
+                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, mine, cs, c0, S, slice_rows, false, A + (k + c0) + k * ld, ld, false, -1.0, 1.0,
+                            S + c0 * slice_rows, slice_rows));
+            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, mine, cs, cs, S + c0 * slice_rows, slice_rows, false, dblk + s * INV_ELEMS, IB, false, 1.0,
+                        0.0, S + c0 * slice_rows, slice_rows));
+        }
+    }
+    FR_TRY(comm_allgather(ctx, slices + (int64_t)me * slice_rows * kb, slices, (size_t)(slice_rows * kb)));
+    for (int q = 0; q < W; ++q)
+        if (rows_of(q) > 0)
+            FR_TRY(launch_copy(ctx, slices + (int64_t)q * slice_rows * kb, slice_rows, A + row0 + (int64_t)q * slice_rows + k * ld, ld,
+                               rows_of(q), kb));
+    return FR_OK;
+}
+
 // In-place blocked Cholesky of the n x n lower triangle at A.  dinv receives the inverses of the diagonal
 // 128-blocks (block i of this sub-matrix at dinv + i*INV_ELEMS).
 //
@@ -335,8 +389,15 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         return FR_OK;
     }
     double* pbuf = nullptr;
+    int64_t split_rows = 0;
+    const bool split = world > 1 && ctx->panel_split != 0;
     if (world > 1) {
-        pbuf = pg.get(sizeof(double) * (size_t)(n * imin(nb, n) + ((nb + IB - 1) / IB) * INV_ELEMS));
+        // (split variant: head + W slices of whole 128-row blocks)
+        split_rows = round_up((n + world - 1) / world, IB);
+        const int64_t kbm = imin(nb, n);
+        const int64_t split_elems = round_up(kbm * kbm + ((kbm + IB - 1) / IB) * INV_ELEMS, kAlign) + (int64_t)world * split_rows * kbm;
+        const int64_t plain_elems = n * kbm + ((nb + IB - 1) / IB) * INV_ELEMS;
+        pbuf = pg.get(sizeof(double) * (size_t)imax(split_elems, plain_elems));
         // every allocation of this rank is behind it: agree with the peers BEFORE the first panel exchange, so that a rank
         // that ran out of memory does not leave the others inside a broadcast that never completes
         bool all_ok = true;
@@ -358,8 +419,12 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
     ctx->ls = S1;
     {
         const int64_t kb0 = imin(nb, n);
-        if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, fz);
-        if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
+        if (split) {
+            st = split_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(0, nb, world));
+        } else {
+            if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, fz);
+            if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
+        }
         if (st != FR_OK) return fail(st);
     }
     if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
@@ -382,8 +447,12 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess)
             return fail(FR_HIP_ERROR);
         ctx->ls = S1;
-        if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, fz);
-        if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
+        if (split) {
+            st = split_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(k + kb, nb, world));
+        } else {
+            if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, fz);
+            if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
+        }
         if (st != FR_OK) return fail(st);
         if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
         ctx->ls = S0;

@@ -29,6 +29,10 @@ struct RcclApi {
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -53,6 +57,10 @@ static int rccl_load(fr_ctx* ctx)
     LOAD(CommAbort);
     LOAD(Broadcast);
     LOAD(AllGather);
+    LOAD(Send);
+    LOAD(Recv);
+    LOAD(GroupStart);
+    LOAD(GroupEnd);
     LOAD(GetErrorString);
 #undef LOAD
     g_rccl.handle = h;
@@ -141,7 +149,7 @@ static int local_allgather(fr_ctx* ctx, const void* send, void* recv, size_t byt
     const void* srcs[64];
     if (!local_barrier(g, ctx->rank, send, srcs)) return set_err(ctx, FR_RCCL_ERROR, "local allgather: barrier timed out");
     for (int r = 0; r < g->world; ++r)
-        if (bytes_per_rank > 0)
+        if (bytes_per_rank > 0 && (const char*)srcs[r] != (const char*)recv + (size_t)r * bytes_per_rank)  // (in place: own slice already there)
             FR_HIP(ctx, hipMemcpyAsync((char*)recv + (size_t)r * bytes_per_rank, srcs[r], bytes_per_rank,
                                        hipMemcpyDeviceToDevice, ctx->ls));
     FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
@@ -149,7 +157,41 @@ static int local_allgather(fr_ctx* ctx, const void* send, void* recv, size_t byt
     return FR_OK;
 }
 
+static int local_scatter(fr_ctx* ctx, char* buf, size_t bytes_per_rank, int root)
+{
+    LocalGroup* g = ((LocalComm*)ctx->local)->g;
+    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    const void* all[64];
+    if (!local_barrier(g, ctx->rank, buf, all)) return set_err(ctx, FR_RCCL_ERROR, "local scatter: barrier timed out");
+    if (ctx->rank != root && bytes_per_rank > 0) {
+        const size_t off = (size_t)ctx->rank * bytes_per_rank;
+        FR_HIP(ctx, hipMemcpyAsync(buf + off, (const char*)all[root] + off, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->ls));
+        FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    }
+    if (!local_barrier(g, ctx->rank, nullptr)) return set_err(ctx, FR_RCCL_ERROR, "local scatter: barrier timed out");
+    return FR_OK;
+}
+
 // ---- dispatch ----------------------------------------------------------------------------------------
+// Scatter: slice r (count doubles at buf + r * count) of the ROOT's buffer lands in the same place of rank r's buffer.
+// RCCL: one grouped set of point-to-point sends from the root, each over its own xGMI link.
+int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root)
+{
+    if (ctx->world <= 1 || count_per_rank == 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count_per_rank * (ctx->world - 1));
+    if (ctx->local) return local_scatter(ctx, (char*)buf, 8 * count_per_rank, root);
+    FR_NCCL(ctx, g_rccl.GroupStart());
+    if (ctx->rank == root) {
+        for (int r = 0; r < ctx->world; ++r)
+            if (r != root)
+                FR_NCCL(ctx, g_rccl.Send(buf + (size_t)r * count_per_rank, count_per_rank, ncclDouble, r, (ncclComm_t)ctx->comm, ctx->ls));
+    } else {
+        FR_NCCL(ctx, g_rccl.Recv(buf + (size_t)ctx->rank * count_per_rank, count_per_rank, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->ls));
+    }
+    FR_NCCL(ctx, g_rccl.GroupEnd());
+    return FR_OK;
+}
+
 int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root)
 {
     if (ctx->world <= 1) return FR_OK;

@@ -502,6 +502,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->panel_fused = value;
         return FR_OK;
     }
+    if (!strcmp(name, "panel_split")) {
+        ctx->panel_split = value != 0;
+        return FR_OK;
+    }
     if (!strcmp(name, "k4_yield")) {
         ctx->k4_yield = value != 0;
         return FR_OK;

@@ -84,6 +84,9 @@ struct fr_ctx {
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
     // cooperative yield: GEMM waves sleep while the diagonal-block kernel works on their CU (gemm_tile.hpp)
+    // sharded factorisation: 0 (default) the owner solves the whole panel and broadcasts it; 1: the owner factors the
+    // nb x nb diagonal block only, the rows below are scattered, every rank solves its share, one all-gather returns them
+    int64_t panel_split = 0;
     int64_t k4_yield = 0;  // measured: K4 153 -> 106 us at N = 16384, but the extra load in the pinned K-loop costs the GEMMs 12 - 35 %
     unsigned* yield_word = nullptr;  // device
     int64_t syrk_dynamic = 0;   // trailing update: tiles pulled from per-XCD work lists by resident workgroups (gemm_f64.hip)
@@ -358,6 +361,7 @@ int check_status_word(fr_ctx* ctx);
 int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root);
 int comm_allgather_i64(fr_ctx* ctx, const int64_t* send, int64_t* recv, size_t count_per_rank);
 int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_per_rank);
+int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root);  // slice r of the root's buffer -> rank r (same offset)
 int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok);  // collective: does EVERY rank report ok?  (synchronises)
 void comm_abort(fr_ctx* ctx);                        // failing rank: tear the communicator down so that peers do not wait forever
 

@@ -35,3 +35,15 @@ def panel_schedule(n, nb, world):
             j += nb
         yield {"k": k, "kb": kb, "owner": owner_of(k, nb, world), "updates": updates}
         k += kb
+
+
+def split_slices(n, k, kb, world, block=128):
+    """option panel_split: the rows below the diagonal block of the panel at k, cut into `world` slices of whole 128-row
+    blocks -> (slice_rows, [(first row, rows) per rank])  (mirrors split_panel in chol.hip)"""
+    slice_rows = -(-(-(-n // world)) // block) * block
+    below0 = k + kb
+    out = []
+    for r in range(world):
+        lo = below0 + r * slice_rows
+        out.append((lo, max(0, min(slice_rows, n - lo))))
+    return slice_rows, out

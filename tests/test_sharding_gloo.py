@@ -10,6 +10,66 @@ import pytest
 from conftest import ROOT, rand_inputs, rel_err
 
 
+def _worker_split(rank, world, port, n, nb, out_dir):
+    """the split variant (option panel_split): diagonal block by the owner + broadcast, scatter of the rows below, every
+    rank solves its slice, all-gather"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scipy.linalg as sl
+    import torch
+    import torch.distributed as dist
+
+    from friedrich_amd import sharding
+    from oracle import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k = ("matern2", 0.7, 1.2)
+    X = rand_inputs(n, 3, 42)
+    A = np.full((n, n), np.nan)
+    for j in range(0, n, nb):
+        if sharding.owner_of(j, nb, world) == rank:
+            w = min(nb, n - j)
+            A[j:, j:j + w] = O.make_covariance_matrix(k, X[j:], X[j:j + w])
+            A[j:j + w, j:j + w] += 0.01 * np.eye(w)
+    for step in sharding.panel_schedule(n, nb, world):
+        kk, kb, owner = step["k"], step["kb"], step["owner"]
+        head = np.zeros((kb, kb))
+        if rank == owner:
+            head = sl.cholesky(A[kk:kk + kb, kk:kk + kb], lower=True)
+        t = torch.from_numpy(np.ascontiguousarray(head))
+        dist.broadcast(t, src=owner)
+        L11 = t.numpy()
+        A[kk:kk + kb, kk:kk + kb] = L11
+        slice_rows, slices = sharding.split_slices(n, kk, kb, world)
+        # scatter: the owner holds the updated, unsolved rows below
+        bufs = []
+        for r, (lo, rows) in enumerate(slices):
+            b = np.zeros((slice_rows, kb))
+            if rank == owner and rows > 0:
+                b[:rows] = A[lo:lo + rows, kk:kk + kb]
+            bufs.append(torch.from_numpy(b))
+        mine = torch.zeros((slice_rows, kb), dtype=torch.float64)
+        dist.scatter(mine, bufs if rank == owner else None, src=owner)
+        lo, rows = slices[rank]
+        solved = np.zeros((slice_rows, kb))
+        if rows > 0:
+            solved[:rows] = sl.solve_triangular(L11, mine.numpy()[:rows].T, lower=True).T
+        gathered = [torch.zeros((slice_rows, kb), dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(solved))
+        for r, (lo, rows) in enumerate(slices):
+            if rows > 0:
+                A[lo:lo + rows, kk:kk + kb] = gathered[r].numpy()[:rows]
+        P = A[kk + kb:, kk:kk + kb]
+        for j in step["updates"][rank]:
+            w = min(nb, n - j)
+            A[j:, j:j + w] -= P[j - kk - kb:] @ P[j - kk - kb:j - kk - kb + w].T
+    np.save(os.path.join(out_dir, f"L{rank}.npy"), np.tril(A))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, n, nb, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -87,3 +147,29 @@ def test_schedule_covers_every_block_once():
             assert cols == list(range(s["k"] + s["kb"], n, nb))
             for r, cs in s["updates"].items():
                 assert all(sharding.owner_of(c, nb, world) == r for c in cs)
+
+
+@pytest.mark.parametrize("n,nb", [(300, 64), (257, 128)])
+def test_two_rank_split_panel_schedule(tmp_path, n, nb):
+    """the split variant of the panel step (scatter + per-rank solves + all-gather) over a 2-rank gloo group"""
+    import torch.multiprocessing as tmp_mp
+
+    from oracle import oracle as O
+
+    world = 2
+    port = 31500 + (os.getpid() % 2000) + n % 7
+    tmp_mp.spawn(_worker_split, args=(world, port, n, nb, str(tmp_path)), nprocs=world, join=True)
+    X = rand_inputs(n, 3, 42)
+    st, L_o, _ = O.make_cholesky_cov_matrix(("matern2", 0.7, 1.2), X, 0.1)
+    for r in range(world):
+        assert rel_err(np.load(tmp_path / f"L{r}.npy"), np.tril(L_o)) < 1e-11
+
+
+def test_split_slices_cover_the_rows_below_once():
+    from friedrich_amd import sharding
+
+    for n, k, kb, world in [(1000, 0, 128, 3), (4096, 512, 512, 8), (700, 640, 60, 4), (32768, 1024, 512, 8)]:
+        slice_rows, slices = sharding.split_slices(n, k, kb, world)
+        assert slice_rows % 128 == 0 and slice_rows * world >= n
+        rows = [r for lo, cnt in slices for r in range(lo, lo + cnt)]
+        assert rows == list(range(k + kb, n))
