@@ -683,6 +683,18 @@ static bool wide_solve(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m
     return ctx->leaf512 != 0 && n == c->n && n >= 2 * LB && m >= 2;
 }
 
+// The persistent matrix-core solve in column groups of 16 (trsm_narrow.hip) against the recursive GEMM formulation, by
+// measurement (scripts/narrow_batched_ab.py, forward solve): N = 32768: 3.5 vs 14.3 ms at 32 columns, 9.8 vs 12.2 at 128,
+// 18 vs 14.5 at 256;  N = 8192: 0.64 vs 3.1 ms at 32, 1.8 vs 2.8 at 256, 3.3 vs 3.0 at 512 (every group re-reads the
+// factor from L2 / Infinity Cache, the GEMMs amortise it over 128 columns but are a chain of ~100 launches).
+static bool use_column_groups(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m)
+{
+    if (n != c->n || !ctx->trsv || m < 2) return false;
+    if (m <= 16) return m <= ctx->narrow_max;
+    if (ctx->narrow_batched_max >= 0) return m <= ctx->narrow_batched_max;  // explicit setting
+    return m <= 128 || (m <= 512 && n <= 8192);
+}
+
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;
@@ -693,7 +705,7 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         return trsm_fwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, true, cls);
-    if (m <= 16 && m <= ctx->narrow_max && n == c->n && ctx->trsv) return launch_trsm_narrow(ctx, c, B, m, ldb, true, cls);
+    if (use_column_groups(ctx, c, n, m)) return launch_trsm_narrow(ctx, c, B, m, ldb, true, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, true);
     WsGuard w(ctx);
     double* tmp = nullptr;
@@ -715,7 +727,7 @@ int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         return trsm_bwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, false, cls);
-    if (m <= 16 && m <= ctx->narrow_max && n == c->n && ctx->trsv) return launch_trsm_narrow(ctx, c, B, m, ldb, false, cls);
+    if (use_column_groups(ctx, c, n, m)) return launch_trsm_narrow(ctx, c, B, m, ldb, false, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, false);
     WsGuard w(ctx);
     double* tmp = nullptr;

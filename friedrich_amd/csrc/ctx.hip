@@ -436,6 +436,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->narrow_max = value;
         return FR_OK;
     }
+    if (!strcmp(name, "narrow_batched_max")) {
+        if (value < -1 || value > 65536) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow_batched_max must be in [-1, 65536]");
+        ctx->narrow_batched_max = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "gemm_lower_probe")) {
         ctx->gemm_lower_probe = value != 0;
         return FR_OK;

@@ -57,6 +57,7 @@ struct fr_ctx {
     int64_t gemm_tile = 0;      // tile-order experiments (gemm_f64.hip)
     int64_t ld_pad = 0;         // probe: elements added to a factor's leading dimension when it is a multiple of 1024
     int64_t splitk = 1;         // GEMMs with few result tiles and a deep contraction are cut along K (gemm_f64.hip)
+    int64_t narrow_batched_max = -1;  // right-hand sides up to which the persistent solve runs in column groups of 16 (trsm_narrow.hip); -1: chosen from n and m (chol.hip)
     int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
     int64_t gemm_lower_probe = 0;  // probe: fr_gemm computes only the lower-triangular tile set of a square result
     bool potf2_lds_set = false;  // dynamic-LDS attribute of the diagonal-block kernel applied on this device

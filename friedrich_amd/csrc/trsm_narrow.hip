@@ -38,6 +38,7 @@ struct TrsmnArgs {
     int* flags;         // one per block
     unsigned* status;
     int nblk, G, bwd;
+    int ngroups;        // column groups of 16 right-hand sides (blockIdx.y); hand-off state per group
 };
 
 struct Frag {
@@ -101,14 +102,24 @@ __device__ __forceinline__ void mma_block(const double (&buf)[32], const double*
     }
 }
 
-__global__ __launch_bounds__(NTH, 2) void trsm_narrow_kernel(const TrsmnArgs a)
+__global__ __launch_bounds__(NTH, 2) void trsm_narrow_kernel(const TrsmnArgs a0)
 {
     __shared__ double xs[2][NB * MR];
     __shared__ double tv[NB * MR];
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
-    const int last = a.nblk - 1;
+    const int last = a0.nblk - 1;
+    // column group: 16 right-hand sides with their own solution blocks and flags -- the groups are independent chains that
+    // stream the same tiles (served from L2 / Infinity Cache after the first reader)
+    TrsmnArgs a = a0;
+    {
+        const int grp = blockIdx.y;
+        a.B += (int64_t)grp * MR * a.ldb;
+        a.m = a.m - grp * MR < MR ? a.m - grp * MR : MR;
+        a.xg += (int64_t)grp * a.nblk * (NB * MR);
+        a.flags += (int64_t)grp * a.nblk;
+    }
 #pragma nounroll
     for (int bi = blockIdx.x; bi < a.nblk; bi += a.G) {
         const int blk = a.bwd ? last - bi : bi;
@@ -212,18 +223,19 @@ static int ensure_transposed(fr_ctx* ctx, fr_chol* c)
     return FR_OK;
 }
 
-// B (n x m, device, 2 <= m <= 16) <- L^-1 B (fwd) or L^-T B.  One launch (+ a memset of the flags; the backward sweep also
+// B (n x m, device, m >= 2: column groups of 16) <- L^-1 B (fwd) or L^-T B.  One launch (+ a memset of the flags; the backward sweep also
 // builds the transposed copy when the factor changed since it was last built).
 int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int64_t ldb, bool fwd, int prof_cls)
 {
     fr_chol* c = const_cast<fr_chol*>(cc);  // the transposed copy is a cache: logically const
     const int64_t n = c->n;
     if (n <= 0 || m <= 0) return FR_OK;
-    if (m > MR) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow solve: more than 16 right-hand sides");
+    const int ngroups = (int)((m + MR - 1) / MR);
+    if (ngroups > 65535) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow solve: too many right-hand sides");
     const int nblk = (int)((n + NB - 1) / NB);
     FR_TRY(ensure_status_word(ctx));
     if (!fwd) FR_TRY(ensure_transposed(ctx, c));
-    const size_t bytes = sizeof(double) * (size_t)nblk * NB * MR + sizeof(int) * (size_t)nblk + 64;
+    const size_t bytes = (sizeof(double) * (size_t)nblk * NB * MR + sizeof(int) * (size_t)nblk) * (size_t)ngroups + 64;
     if (ctx->trsmn_buf_cap < bytes) {
         if (ctx->trsmn_buf) {
             (void)hipStreamSynchronize(ctx->stream);
@@ -243,14 +255,15 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     a.ldb = ldb;
     a.m = (int)m;
     a.xg = (double*)ctx->trsmn_buf;
-    a.flags = (int*)((char*)ctx->trsmn_buf + sizeof(double) * (size_t)nblk * NB * MR);
+    a.flags = (int*)((char*)ctx->trsmn_buf + sizeof(double) * (size_t)nblk * NB * MR * (size_t)ngroups);
+    a.ngroups = ngroups;
     a.status = ctx->dev_status;
     a.nblk = nblk;
     a.G = nblk < ctx->num_cus ? nblk : ctx->num_cus;
     a.bwd = fwd ? 0 : 1;
-    FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)nblk, ctx->ls));
+    FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)nblk * (size_t)ngroups, ctx->ls));
     ProfScope ps(ctx, prof_cls, (double)n * (double)n * (double)m, 4.0 * (double)n * (double)n);
-    hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)a.G), dim3(NTH), 0, ctx->ls, a);
+    hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

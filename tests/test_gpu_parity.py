@@ -553,9 +553,9 @@ def test_refinement_policy_and_forced_modes(ctx):
     assert rel_err(Ls[0], Ls[2]) < 1e-13 and np.array_equal(Ls[0], Ls[1])
 
 
-@pytest.mark.parametrize("n,m", [(2, 2), (127, 3), (128, 16), (129, 7), (300, 2), (1000, 16), (2049, 5)])
+@pytest.mark.parametrize("n,m", [(2, 2), (127, 3), (128, 16), (129, 7), (300, 2), (1000, 16), (2049, 5), (700, 17), (1300, 100), (900, 300)])
 def test_narrow_persistent_solves_2_to_16_columns(ctx, n, m):
-    """2 .. 16 right-hand sides: one persistent matrix-core launch per direction (trsm_narrow.hip), the backward sweep on
+    """2 .. 16 right-hand sides (and more, in column groups of 16): one persistent matrix-core launch per direction (trsm_narrow.hip), the backward sweep on
     the transposed copy kept in the strict upper triangle -- vs the oracle, vs the recursive path (option trsv = 0), after
     add_rows (copy rebuilt) and with the factor's download unaffected by the copy."""
     k = PD_KERNELS[1]
