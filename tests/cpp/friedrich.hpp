@@ -308,35 +308,17 @@ struct LinearPrior {  // :108-160
             for (int64_t r = 0; r < x.rows; ++r) out[(size_t)r] += x(r, c) * weights[(size_t)c];
         return out;
     }
-    // least squares on [1 | X] (the reference uses an SVD solve, :139-159; here: normal equations with a small
-    // Cholesky, O(n d^2) host work that is outside the dense n x n path)
+    // least squares on [1 | X] with the reference's SVD-solve numerics (:139-159): through the ABI (fr_linear_prior_fit:
+    // tall-skinny QR on the device + SVD of the small triangle)
     void fit(const DMatrix& x, const DVector& y)
     {
-        const int64_t n = x.rows, p = x.cols + 1;
-        std::vector<double> G((size_t)(p * p), 0.0), b((size_t)p, 0.0);
-        auto col = [&](int64_t r, int64_t c) { return c == 0 ? 1.0 : x(r, c - 1); };
-        for (int64_t r = 0; r < n; ++r)
-            for (int64_t i = 0; i < p; ++i) {
-                b[(size_t)i] += col(r, i) * y[(size_t)r];
-                for (int64_t j = 0; j <= i; ++j) G[(size_t)(i + j * p)] += col(r, i) * col(r, j);
-            }
-        for (int64_t j = 0; j < p; ++j) {  // in-place Cholesky of the p x p Gram matrix
-            for (int64_t k = 0; k < j; ++k)
-                for (int64_t i = j; i < p; ++i) G[(size_t)(i + j * p)] -= G[(size_t)(i + k * p)] * G[(size_t)(j + k * p)];
-            const double dj = std::sqrt(G[(size_t)(j + j * p)]);
-            if (!(dj > 0.0)) throw std::runtime_error("Linear prior fit : solve failed.");
-            for (int64_t i = j; i < p; ++i) G[(size_t)(i + j * p)] /= dj;
-        }
-        for (int64_t i = 0; i < p; ++i) {
-            for (int64_t k = 0; k < i; ++k) b[(size_t)i] -= G[(size_t)(i + k * p)] * b[(size_t)k];
-            b[(size_t)i] /= G[(size_t)(i + i * p)];
-        }
-        for (int64_t i = p - 1; i >= 0; --i) {
-            for (int64_t k = i + 1; k < p; ++k) b[(size_t)i] -= G[(size_t)(k + i * p)] * b[(size_t)k];
-            b[(size_t)i] /= G[(size_t)(i + i * p)];
-        }
-        intercept = b[0];
-        weights.assign(b.begin() + 1, b.end());
+        fr_ctx* ctx = nullptr;
+        if (fr_ctx_create(&ctx, -1) != FR_OK) throw std::runtime_error("Linear prior fit : no device.");
+        weights.assign((size_t)x.cols, 0.0);
+        const int st = fr_linear_prior_fit(ctx, x.data.data(), x.rows, x.rows > 0 ? x.rows : 1, x.cols, y.data(), weights.data(),
+                                           &intercept);
+        fr_ctx_destroy(ctx);
+        if (st != FR_OK) throw std::runtime_error("Linear prior fit : solve failed.");
     }
 };
 
