@@ -90,7 +90,7 @@ static int fused_start(fr_ctx* ctx, Fused& f, double* A, int64_t ld, int64_t n, 
 {
     f.on = false;
     const int64_t nblk = (n + IB - 1) / IB;
-    if (!ctx->panel_fused || !ctx->stream3 || mode == 3 || nblk < 2) return FR_OK;
+    if (!ctx->panel_fused || ctx->panel_fused == 4 || !ctx->stream3 || mode == 3 || nblk < 2) return FR_OK;
     if (dist && ctx->world > 1) return FR_OK;  // the experimental variants are single-GPU only
     FR_TRY(ensure_status_word(ctx));
     if (ctx->panel_flags_cap < (size_t)(9 * nblk)) {
@@ -203,6 +203,12 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
 {
     // experimental: row-tile kernels; the diagonal blocks are factored by the resident server
     if (f && f->on && ctx->panel_fused == 2) return launch_panel_tiles(ctx, A, ld, n, k, kb, dinv, f->ready, f->done, f->tdone);
+    // diagonal block first (per-block launches on its kb rows only), then ONE launch for all the rows below it: left-looking
+    // row tiles, no waiting (panel.hip)
+    if (ctx->panel_fused == 4 && kb > IB && n - (k + kb) >= IB && !ctx->refine_now && mode != 3) {
+        FR_TRY(factor_panel(ctx, A, ld, k + kb, k, kb, col0, mode, sub, dinv, info, T, f));
+        return launch_panel_rest(ctx, A, ld, n, k, kb, dinv);
+    }
     if (kb <= IB) {
         double* inv = dinv + (k / IB) * INV_ELEMS;
         if (f && f->on && ctx->panel_fused != 3) {

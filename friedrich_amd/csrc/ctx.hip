@@ -503,7 +503,7 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         return FR_OK;
     }
     if (!strcmp(name, "panel_fused")) {
-        if (value < 0 || value > 3) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_fused must be 0, 1, 2 (or the probe value 3)");
+        if (value < 0 || value > 4) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_fused must be 0 .. 4");
         ctx->panel_fused = value;
         return FR_OK;
     }

@@ -323,6 +323,8 @@ int launch_server_block(fr_ctx* ctx, int* ready4, const int* done, unsigned* sta
 int launch_panel_tiles(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv,
                        int* ready, int* done, int* tdone);
 
+int launch_panel_rest(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv);
+
 // small helpers (elementwise / reductions)
 int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v);
 int launch_blockdiag512(fr_ctx* ctx, const double* dinv128, double* w, int64_t nblocks);

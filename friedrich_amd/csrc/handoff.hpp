@@ -18,7 +18,9 @@ typedef __attribute__((address_space(1))) int hgi32;
 
 constexpr unsigned long long HANDOFF_TIMEOUT_TICKS = 500000000ull;  // 5 s of the 100 MHz wall clock
 
-// All threads of the workgroup call this; returns false (uniformly) after a timeout.
+// All threads of the workgroup call this; returns false (uniformly) after a timeout.  ACQUIRE = false: the payload was
+// stored write-through (sc1) and will be read with sc1 loads, which need no fence (Guideline 16, R1).
+template <bool ACQUIRE = true>
 __device__ __forceinline__ bool handoff_wait_ge(const int* flag, int target, unsigned* status)
 {
     int ok = 1;
@@ -41,7 +43,7 @@ __device__ __forceinline__ bool handoff_wait_ge(const int* flag, int target, uns
                 }
             }
         }
-        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (ACQUIRE && ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     return __builtin_amdgcn_readfirstlane(__syncthreads_and(ok)) != 0;  // uniform by construction: say so (scalar branch)
 }

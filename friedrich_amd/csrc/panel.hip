@@ -194,6 +194,30 @@ __global__ __launch_bounds__(256, 2) void panel_rest_kernel(const PanelArgs a)
     }
 }
 
+// The rows below the diagonal block alone (option panel_fused = 4: the diagonal block was factored by the per-block launches)
+int launch_panel_rest(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv)
+{
+    const int64_t T = (n - k + PTB - 1) / PTB;
+    const int nsb = (int)((kb + PTB - 1) / PTB);
+    if (T <= nsb) return FR_OK;
+    PanelArgs a;
+    a.A = A;
+    a.lda = lda;
+    a.n = n;
+    a.k = k;
+    a.kb = kb;
+    a.dinv = dinv;
+    a.ready = a.done = a.tdone = nullptr;
+    a.status = ctx->dev_status;
+    a.jb = (int)(k / PTB);
+    a.nsb = nsb;
+    const double rows = (double)(n - k - kb);
+    ProfScope ps(ctx, FR_PROF_GEMM_PANEL, rows * (double)kb * (double)kb, 8.0 * rows * (double)kb * 2.0);
+    hipLaunchKernelGGL(panel_rest_kernel, dim3((unsigned)(T - nsb)), dim3(256), 0, ctx->ls, a);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
 int launch_panel_tiles(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv, int* ready,
                        int* done, int* tdone)
 {

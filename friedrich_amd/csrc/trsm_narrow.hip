@@ -84,7 +84,7 @@ __device__ __forceinline__ Frag item_frag(const TrsmnArgs& a, int blk, int other
 // solution block `blk` -> xs ([col][q]); false after a timeout
 __device__ __forceinline__ bool fetch_block(const TrsmnArgs& a, int blk, double* xs, int t)
 {
-    if (!handoff_wait_ge(a.flags + blk, 1, a.status)) return false;  // (its agent-scope acquire is not needed for sc1 loads, harmless)
+    if (!handoff_wait_ge<false>(a.flags + blk, 1, a.status)) return false;  // no acquire fence: sc1 stores, sc1 loads
     const double* src = a.xg + (int64_t)blk * (NB * MR);
 #pragma unroll
     for (int i = 0; i < (NB * MR) / NTH; ++i)
