@@ -36,9 +36,10 @@ static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
 
 static int gemm(fr_ctx* ctx, int cls, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, bool a_kmajor,
                 const double* B, int64_t ldb, bool b_kmajor, double alpha, double beta, double* D, int64_t ldd,
-                bool lower = false)
+                bool lower = false, int place = 0)
 {
     GemmDesc g;
+    g.place = place;
     g.M = M;
     g.N = N;
     g.K = K;
@@ -257,6 +258,77 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
     return factor_panel(ctx, A, ld, n, k + kb1, kb - kb1, col0, mode, sub, dinv, info, T, f);
 }
 
+// The same factorisation with the panel chain cut down to what the NEXT diagonal block waits for (option panel_crit):
+// every product of the recursion is split by rows into the rows of the panel's own diagonal block (rows < dend: a handful
+// of tiles, launched on the panel stream, where the next diagonal-block kernel waits for them) and the bulk rows below
+// (launched on stream4, one step behind: nothing on the panel stream waits for them before the panel is finished).  With
+// ctx->reserve_now the critical launches run on the XCD the trailing update keeps off (gemm_f64.hip).
+static int factor_panel_cp(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t pk, int64_t pkb,
+                           int64_t col0, int mode, double sub, double* dinv, int64_t* info)
+{
+    const int64_t dend = pk + pkb;  // the panel is columns [pk, dend); rows below dend are bulk rows
+    const bool rest_kernel = ctx->panel_crit == 2;  // bulk rows: one left-looking launch per sub-panel (panel.hip)
+    hipStream_t S1 = ctx->stream2, SB = ctx->stream4;
+    const bool bulk = n > dend;
+    auto to_bulk = [&]() -> int {  // everything queued on the panel stream so far happens before what follows on stream4
+        FR_HIP(ctx, hipEventRecord(ctx->ev_cb, S1));
+        FR_HIP(ctx, hipStreamWaitEvent(SB, ctx->ev_cb, 0));
+        return FR_OK;
+    };
+    if (kb <= IB) {
+        double* inv = dinv + (k / IB) * INV_ELEMS;
+        ctx->ls = S1;
+        FR_TRY(factor_block128(ctx, A + k + k * ld, ld, kb, col0 + k, mode, sub, inv, info, nullptr));
+        const int64_t r0 = k + kb;
+        if (bulk) FR_TRY(to_bulk());
+        if (dend > r0)
+            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, dend - r0, kb, kb, A + r0 + k * ld, ld, false, inv, IB, false, 1.0, 0.0,
+                        A + r0 + k * ld, ld, false, 2));
+        if (bulk) {
+            ctx->ls = SB;
+            if (rest_kernel) {
+                const int sp = (int)((k - pk) / IB);
+                FR_TRY(launch_panel_rest_cols(ctx, A, ld, n, pk, pkb, dinv, sp, sp + 1));
+            } else {
+                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - dend, kb, kb, A + dend + k * ld, ld, false, inv, IB, false, 1.0, 0.0,
+                            A + dend + k * ld, ld, false, 3));
+            }
+            ctx->ls = S1;
+        }
+        return FR_OK;
+    }
+    const int64_t kb1 = ((kb / IB + 1) / 2) * IB;
+    FR_TRY(factor_panel_cp(ctx, A, ld, n, k, kb1, pk, pkb, col0, mode, sub, dinv, info));
+    const int64_t r0 = k + kb1;  // rows below the first half; the second half's own rows r0 .. k + kb are critical rows
+    const double* Q = A + r0 + k * ld;  // L(second-half rows, first-half columns): written by critical launches only
+    ctx->ls = S1;
+    if (bulk && !rest_kernel) FR_TRY(to_bulk());  // (Q is complete: its launches are already queued on the panel stream)
+    if (dend > r0)
+        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, dend - r0, kb - kb1, kb1, Q, ld, false, Q, ld, false, -1.0, 1.0, A + r0 + r0 * ld, ld,
+                    false, 2));
+    if (bulk && !rest_kernel) {
+        ctx->ls = SB;
+        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - dend, kb - kb1, kb1, A + dend + k * ld, ld, false, Q, ld, false, -1.0, 1.0,
+                    A + dend + r0 * ld, ld, false, 3));
+        ctx->ls = S1;
+    }
+    return factor_panel_cp(ctx, A, ld, n, k + kb1, kb - kb1, pk, pkb, col0, mode, sub, dinv, info);
+}
+
+// One panel of the look-ahead pipeline: the critical-path variant when it applies, and then the main stream is made to wait
+// for the bulk stream as well (the caller records ev_panel on the panel stream).
+static int factor_panel_la(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
+                           double sub, double* dinv, int64_t* info, double* T, const Fused* f, bool cp)
+{
+    if (!cp) return factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T, f);
+    FR_TRY(factor_panel_cp(ctx, A, ld, n, k, kb, k, kb, col0, mode, sub, dinv, info));
+    if (n > k + kb) {
+        FR_HIP(ctx, hipEventRecord(ctx->ev_bulk, ctx->stream4));
+        FR_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_bulk, 0));  // ev_panel (recorded next) then covers both
+    }
+    return FR_OK;
+}
+
 // Multi-GPU: block column b (width nb) of the matrix being factored is owned by rank b % world.
 static inline int owner_of(int64_t col, int64_t nb, int world) { return (int)((col / nb) % world); }
 
@@ -413,9 +485,18 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
     }
     hipStream_t S0 = ctx->stream, S1 = ctx->stream2;
     int st = FR_OK;
+    const bool cp = world == 1 && ctx->panel_crit && ctx->stream4 && !ctx->refine_now && mode != 3 &&
+                    !(fz && fz->on) && ctx->panel_fused == 0;
+    if (world == 1 && (ctx->xcd_reserve != 0 || ctx->xcd_reserve2 > 0) && ctx->claim_ring) {
+        // claim counters of the launches that keep off the panel stream's XCD (gemm_f64.hip): one pair per launch
+        FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 2 * kClaimSlots, S0));
+        ctx->claim_next = 0;
+    }
     auto fail = [&](int code) {
         if (world > 1) comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
         ctx->ls = S0;
+        ctx->reserve_now = 0;
+        if (ctx->stream4) (void)hipStreamSynchronize(ctx->stream4);
         (void)hipStreamSynchronize(S1);
         return code;
     };
@@ -428,7 +509,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (split) {
             st = split_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(0, nb, world));
         } else {
-            if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, fz);
+            if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel_la(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, fz, cp);
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
         }
         if (st != FR_OK) return fail(st);
@@ -442,6 +523,19 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (rest <= 0) break;
         const int64_t kb2 = imin(nb, rest);
         const double* P = A + (k + kb) + k * ld;
+        // once the panel chain is longer than the trailing update, the update's launches leave XCD 0 to it (gemm_f64.hip)
+        ctx->reserve_now = 0;
+        ++ctx->panel_epoch;
+        if (world == 1 && ctx->claim_ring && !ctx->syrk_dynamic) {
+            if (ctx->xcd_reserve < 0) {
+                // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
+                // own products are too large for one or two XCDs and every setting is neutral or worse
+                if (nb <= 512) ctx->reserve_now = rest <= 8192 ? 2 : (rest <= 12288 ? 1 : 0);
+            } else {
+                if (ctx->xcd_reserve > 0 && (ctx->xcd_reserve_rest == 0 || rest <= ctx->xcd_reserve_rest)) ctx->reserve_now = (int)ctx->xcd_reserve;
+                if (ctx->xcd_reserve2 > 0 && rest <= ctx->xcd_reserve_rest2) ctx->reserve_now = (int)ctx->xcd_reserve2;
+            }
+        }
         const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
         if (own_next) {
@@ -456,7 +550,8 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (split) {
             st = split_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(k + kb, nb, world));
         } else {
-            if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, fz);
+            if (own_next) st = factor_panel_la(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, fz, cp);
+            if (st == FR_OK && ctx->reserve_now) st = launch_release_xcds(ctx, ctx->panel_epoch);  // (on the panel stream)
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
         }
         if (st != FR_OK) return fail(st);
@@ -479,6 +574,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         }
     }
     ctx->ls = S0;
+    ctx->reserve_now = 0;
     return FR_OK;
 }
 

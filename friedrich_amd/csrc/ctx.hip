@@ -340,13 +340,17 @@ int fr_ctx_create(fr_ctx** out, int device)
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
     if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo) != hipSuccess ||  // resident for a whole fit: a busy HIGH-priority queue throttles the dispatch of every other queue (measured: +16 % on the trailing updates)
+        hipStreamCreateWithPriority(&ctx->stream4, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_cb, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_bulk, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_server, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_la, hipEventDisableTiming) != hipSuccess) {
         fr_ctx_destroy(ctx);
         return FR_HIP_ERROR;
     }
-    if (hipMalloc((void**)&ctx->yield_word, 64) != hipSuccess || hipMemset(ctx->yield_word, 0, 64) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->yield_word, 64) != hipSuccess || hipMemset(ctx->yield_word, 0, 64) != hipSuccess ||
+        hipMalloc((void**)&ctx->claim_ring, sizeof(unsigned) * 2 * kClaimSlots) != hipSuccess) {
         fr_ctx_destroy(ctx);
         return FR_HIP_ERROR;
     }
@@ -374,6 +378,13 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->yield_word) (void)hipFree(ctx->yield_word);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
+    if (ctx->stream4) {
+        (void)hipStreamSynchronize(ctx->stream4);
+        (void)hipStreamDestroy(ctx->stream4);
+    }
+    if (ctx->ev_cb) (void)hipEventDestroy(ctx->ev_cb);
+    if (ctx->ev_bulk) (void)hipEventDestroy(ctx->ev_bulk);
+    if (ctx->claim_ring) (void)hipFree(ctx->claim_ring);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
         (void)hipStreamDestroy(ctx->stream3);
@@ -509,6 +520,36 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     }
     if (!strcmp(name, "panel_split")) {
         ctx->panel_split = value != 0;
+        return FR_OK;
+    }
+    if (!strcmp(name, "xcd_reserve")) {
+        if (value < -1 || value > 4) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve must be in [-1, 4]");
+        ctx->xcd_reserve = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "xcd_reserve2")) {
+        if (value < 0 || value > 4) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve2 must be in [0, 4]");
+        ctx->xcd_reserve2 = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "xcd_reserve_rest2")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve_rest2 must be >= 0");
+        ctx->xcd_reserve_rest2 = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "xcd_reserve_rest")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve_rest must be >= 0");
+        ctx->xcd_reserve_rest = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "bulk_xcd_tiles")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "bulk_xcd_tiles must be >= 0");
+        ctx->bulk_xcd_tiles = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "panel_crit")) {
+        if (value < 0 || value > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_crit must be 0, 1 or 2");
+        ctx->panel_crit = value;
         return FR_OK;
     }
     if (!strcmp(name, "k4_yield")) {

@@ -88,6 +88,19 @@ struct fr_ctx {
     // sharded factorisation: 0 (default) the owner solves the whole panel and broadcasts it; 1: the owner factors the
     // nb x nb diagonal block only, the rows below are scattered, every rank solves its share, one all-gather returns them
     int64_t panel_split = 0;
+    // XCD reservation (gemm_f64.hip): the main stream's GEMM launches of a factorisation leave the first `xcd_reserve` XCDs
+    // to the panel stream (their workgroups there exit at once) while the trailing matrix has at most `xcd_reserve_rest` rows
+    int64_t xcd_reserve = -1;  // -1: chosen by the factorisation (single GPU, nb <= 512: 1 XCD below 12288 rows, 2 below 8192)
+    int64_t xcd_reserve_rest = 0;  // 0: whenever xcd_reserve > 0
+    int64_t xcd_reserve2 = 0, xcd_reserve_rest2 = 0;  // second tier: this many XCDs once the trailing matrix is this small
+    int reserve_now = 0;           // XCDs reserved right now (set by the factorisation around the launches it applies to)
+    unsigned panel_epoch = 0;      // number of the panel being factored on the panel stream (see claim_item)
+    unsigned* claim_ring = nullptr;  // device: {tile counter, retire counter} per reserved launch of a factorisation
+    int64_t claim_next = 0;
+    int64_t bulk_xcd_tiles = 0;    // bulk launches of at most this many tiles run ON the reserved XCD
+    int64_t panel_crit = 0;        // panel factorisation split into critical rows (panel stream) and bulk rows (stream4)
+    hipStream_t stream4 = nullptr;
+    hipEvent_t ev_cb = nullptr, ev_bulk = nullptr;
     int64_t k4_yield = 0;  // measured: K4 153 -> 106 us at N = 16384, but the extra load in the pinned K-loop costs the GEMMs 12 - 35 %
     unsigned* yield_word = nullptr;  // device
     int64_t syrk_dynamic = 0;   // trailing update: tiles pulled from per-XCD work lists by resident workgroups (gemm_f64.hip)
@@ -269,6 +282,8 @@ int kprog_check(fr_ctx* ctx, const fr_kprog* p);
 //   a_kmajor = false: element (m,k) of op(A) is A[m + k*lda]  ("N")      true: A[k + m*lda]  ("T")
 //   b_kmajor = true : element (k,n) of op(B) is B[k + n*ldb]  ("N")      false: B[n + k*ldb] ("T")
 //   lower = true: only tiles intersecting the lower triangle of the M x M result are computed (SYRK use)
+constexpr int64_t kClaimSlots = 4096;
+
 struct GemmDesc {
     int64_t M, N, K;
     const double* A;
@@ -289,8 +304,14 @@ struct GemmDesc {
     int64_t own_nb = 1, own_col0 = 0;
     // batched launch: `batch` independent problems of the same shape, operands `batch_*` elements apart
     int64_t batch = 1, batch_a = 0, batch_b = 0, batch_c = 0, batch_d = 0;
+    // XCD reservation (while ctx->reserve_now): 0 = keep off the panel stream's XCD unless launched on the panel stream,
+    // 2 = critical-path launch, ON the panel stream's XCD; 3 = bulk launch, on that XCD when it is small
+    int place = 0;
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
+int launch_release_xcds(fr_ctx* ctx, unsigned epoch);  // on ctx->ls: the chain of panel `epoch` is finished
+int claim_setup(fr_ctx* ctx, int place, int64_t items, const unsigned** xcc_word, unsigned** claim, unsigned* max_exit,
+                int64_t* grid);
 
 // K4: factor one diagonal block (nbk <= 128) and emit its explicit inverse (inv may be NULL).
 //   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows),
@@ -324,6 +345,8 @@ int launch_panel_tiles(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k
                        int* ready, int* done, int* tdone);
 
 int launch_panel_rest(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv);
+int launch_panel_rest_cols(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv, int s_lo,
+                           int s_hi);
 
 // small helpers (elementwise / reductions)
 int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v);

@@ -60,9 +60,23 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
         }
     } else {
         // plain order: each XCD gets a contiguous run of the tile list
-        const int64_t nblk = gridDim.x;
-        const int64_t q = nblk >> 3, r8 = nblk & 7;
-        const int64_t tlin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+        int64_t tlin;
+        if (g.place == 2) {
+            // launch of the panel stream: workgroup b of a stream's launch is dealt to XCD (X + b) % 8, X being where its
+            // single-workgroup launches (the diagonal-block kernel) run (scripts/xcc_single.hip) -- the workgroups with
+            // b % 8 < nres land on the XCDs the trailing update keeps off.  The others retire at once.
+            const int64_t x = b & 7;
+            if (x >= g.nres) return;
+            tlin = (b >> 3) * g.nres + x;
+            if (tlin >= g.ntiles) return;
+        } else if (g.place == 1 || g.place == 3) {
+            tlin = claim_item(g.place, g.nres, g.epoch, g.xcc_word, g.claim, g.max_exit, g.ntiles);  // gemm_tile.hpp
+            if (tlin < 0) return;
+        } else {
+            const int64_t nblk = gridDim.x;
+            const int64_t q = nblk >> 3, r8 = nblk & 7;
+            tlin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+        }
         if (g.lower == 2) {
             // lower triangle column by column (tm fastest), like the full mode: consecutive workgroups continue down the
             // same 128 columns of C (the next 1 KiB of every column) and share one B panel.  Column tn holds T - tn tiles.
@@ -191,6 +205,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __rest
 
 static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d);
 
+__global__ void release_xcds_kernel(unsigned* word, unsigned epoch)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int launch_release_xcds(fr_ctx* ctx, unsigned epoch)
+{
+    hipLaunchKernelGGL(release_xcds_kernel, dim3(1), dim3(64), 0, ctx->ls, ctx->yield_word + 5, epoch);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+// Host side of claim_item (gemm_tile.hpp): a counter pair from the factorisation's ring for one launch that keeps off (1) /
+// runs on (3) the panel stream's XCD.  Returns the placement to use (0: launch plainly) and the grid size.
+int claim_setup(fr_ctx* ctx, int place, int64_t items, const unsigned** xcc_word, unsigned** claim, unsigned* max_exit,
+                int64_t* grid)
+{
+    *xcc_word = nullptr;
+    *claim = nullptr;
+    *max_exit = 0;
+    *grid = items;
+    if (!ctx->reserve_now || ctx->ls == ctx->stream2 || !ctx->claim_ring || ctx->claim_next >= kClaimSlots) return 0;
+    *xcc_word = ctx->yield_word + 4;
+    *claim = ctx->claim_ring + 2 * ctx->claim_next++;
+    const int64_t R = ctx->reserve_now;
+    *max_exit = (unsigned)((place == 3 ? items * (8 - R) / R : items * R / (8 - R)) + 16);
+    *grid = items + *max_exit;
+    return place;
+}
+
 // Few result tiles and a deep contraction (a 512-row block against 8192 columns: add_rows, narrow predicts): one tile's
 // K-loop is then the whole run time while most CUs idle.  The contraction is cut into slices computed as one batched
 // launch into a workspace, and a second small kernel adds them up (fixed order).  Main stream only (the workspace pool
@@ -282,10 +326,29 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     if (ctx->gemm_tile == 0 && d.lower) use_super = false;
     if (ctx->gemm_tile == 1) use_super = false;
     if (ctx->gemm_tile == 3 && !d.lower) use_super = false;
+    g.place = 0;
+    g.ntiles = ntiles;
+    g.xcc_word = nullptr;
+    g.claim = nullptr;
+    g.max_exit = 0;
+    g.nres = ctx->reserve_now;
+    g.epoch = ctx->panel_epoch;
+    if (ctx->reserve_now && d.batch <= 1 && !ctx->syrk_dynamic && d.own_world <= 1) {
+        if (ctx->ls == ctx->stream2) {
+            if (!d.lower) g.place = 2;
+        } else {
+            int64_t grid = 0;
+            g.place = claim_setup(ctx, (d.place == 3 && !d.lower && ntiles <= ctx->bulk_xcd_tiles) ? 3 : 1, ntiles, &g.xcc_word,
+                                  &g.claim, &g.max_exit, &grid);
+        }
+        if (g.place) use_super = false;
+    }
     if (use_super)
         ntiles = g.per_xcd * 8 * 64;
     else
         g.nsuper = 0;
+    if (g.place == 2) ntiles = 8 * ((g.ntiles + g.nres - 1) / g.nres);
+    if (g.place == 1 || g.place == 3) ntiles = g.ntiles + g.max_exit;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
     double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
     if (d.own_world > 1) {

@@ -37,6 +37,15 @@ struct GemmArgs {
     // cooperative yield (see cu_key / yield_if_asked): word that names the CU on which a diagonal-block kernel wants to
     // run undisturbed, or NULL
     const unsigned* yield_word;
+    // XCD reservation (gemm_f64.hip): place 1 = keep off the XCD named by *xcc_word (tiles claimed from claim[0], at most
+    // max_exit workgroups retire through claim[1]); place 2 = only the workgroups with blockIdx.x % 8 == 0 work
+    int place;
+    int nres;  // number of reserved XCDs: the one named by *xcc_word and the nres - 1 after it
+    unsigned epoch;  // the reservation holds until xcc_word[1] (last panel whose chain is finished) reaches this panel number
+    int64_t ntiles;
+    const unsigned* xcc_word;  // 1 + XCC_ID of the XCD the diagonal-block kernels run on (0: not known yet)
+    unsigned* claim;
+    unsigned max_exit;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile
@@ -124,6 +133,42 @@ __device__ __forceinline__ void yield_if_asked(const unsigned* word, unsigned se
         __builtin_amdgcn_s_sleep(20);
         if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine) break;
     }
+}
+
+// ---- XCD reservation -----------------------------------------------------------------------------------------------------
+// While the panel chain bounds a factorisation, the XCD on which the panel stream's diagonal-block kernel runs is left to
+// it (a dependent f64 operation of the pivot chain costs 7 cycles on a CU of its own and 54 - 85 next to a GEMM workgroup's
+// MFMAs).  Single-workgroup launches of one stream always land on the same XCD (scripts/xcc_single.hip); the
+// diagonal-block kernel publishes which (xcc_word = 1 + XCC_ID); a launch of that stream deals workgroup b to XCD
+// (that one + b) % 8, so `nres` XCDs can be set aside for the panel stream: its launches use the workgroups with b % 8 <
+// nres only (place 2, a pure function of b), everybody else keeps off the nres XCDs from the published one on.  place 1: a workgroup dealt to that XCD retires at once
+// (its slot is free again within a microsecond, so the dispatcher's round over the engines never waits there); place 3:
+// the opposite, only the workgroups on that XCD work.  Correct whatever the dispatcher does: work items are CLAIMED (one
+// atomic on claim[0]) and at most max_exit workgroups may retire without one (claim[1]) -- the grid holds n + max_exit
+// workgroups.  Returns the claimed item or -1.
+__device__ __forceinline__ long long claim_item(int place, int nres, unsigned epoch, const unsigned* xcc_word, unsigned* claim,
+                                                unsigned max_exit, int64_t n)
+{
+    __shared__ long long claimed;
+    if (threadIdx.x == 0) {
+        unsigned phys;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(phys));
+        const unsigned word = __hip_atomic_load(xcc_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the panel whose chain the reservation protects is finished (its stream said so): the XCDs are everybody's again
+        const unsigned released = __hip_atomic_load(xcc_word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool held = (int)(released - epoch) < 0;
+        const bool on = held && word != 0u && ((phys - (word - 1u)) & 7u) < (unsigned)nres;
+        bool retire = false;
+        if (on == (place == 1)) retire = __hip_atomic_fetch_add(claim + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < max_exit;
+        long long tl = -1;
+        if (!retire) {
+            const unsigned i = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int64_t)i < n) tl = (long long)i;
+        }
+        claimed = tl;
+    }
+    __syncthreads();
+    return claimed;
 }
 
 // One 128 x 128 result tile at (m0, n0): the whole K-loop and the epilogue.  Called by the GEMM kernels (one tile per

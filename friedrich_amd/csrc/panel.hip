@@ -38,6 +38,15 @@ struct PanelArgs {
     unsigned* status;
     int jb;   // k / 128: first diagonal block of the panel
     int nsb;  // sub-panels
+    int s_lo, s_hi;  // rest kernel: the sub-panels [s_lo, s_hi) of this launch
+    // XCD reservation (gemm_tile.hpp, claim_item): place 0 = row tile blockIdx.x, 1 = row tiles claimed by the workgroups
+    // that do not sit on the panel stream's XCD
+    int place, nres;
+    unsigned epoch;
+    const unsigned* xcc_word;
+    unsigned* claim;
+    unsigned max_exit;
+    int64_t ntiles;
 };
 
 __device__ __forceinline__ void tile_product(double* lds, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
@@ -176,12 +185,17 @@ __global__ __launch_bounds__(256, 2) void panel_diag_kernel(const PanelArgs a)
 __global__ __launch_bounds__(256, 2) void panel_rest_kernel(const PanelArgs a)
 {
     __shared__ double lds[4 * TILE_ELEMS];
-    const int t = a.nsb + (int)blockIdx.x;
+    long long item = blockIdx.x;
+    if (a.place) {
+        item = claim_item(a.place, a.nres, a.epoch, a.xcc_word, a.claim, a.max_exit, a.ntiles);
+        if (item < 0) return;
+    }
+    const int t = a.nsb + (int)item;
     const int64_t row0 = a.k + (int64_t)PTB * t;
     const int64_t rows = (a.n - row0) < PTB ? (a.n - row0) : PTB;
     // ops 2 s (update of sub-panel s by sub-panels < s) and 2 s + 1 (solve): ONE call site of the tile product
 #pragma nounroll
-    for (int op = 1; op < 2 * a.nsb; ++op) {
+    for (int op = (a.s_lo == 0 ? 1 : 2 * a.s_lo); op < 2 * a.s_hi; ++op) {
         const int s = op >> 1;
         const bool solve = (op & 1) != 0;
         const int64_t c0 = a.k + (int64_t)PTB * s;
@@ -211,9 +225,47 @@ int launch_panel_rest(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k,
     a.status = ctx->dev_status;
     a.jb = (int)(k / PTB);
     a.nsb = nsb;
+    a.s_lo = 0;
+    a.s_hi = nsb;
+    a.place = 0;
     const double rows = (double)(n - k - kb);
     ProfScope ps(ctx, FR_PROF_GEMM_PANEL, rows * (double)kb * (double)kb, 8.0 * rows * (double)kb * 2.0);
     hipLaunchKernelGGL(panel_rest_kernel, dim3((unsigned)(T - nsb)), dim3(256), 0, ctx->ls, a);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+// Sub-panels [s_lo, s_hi) of the rows below the panel's diagonal block, for the critical-path schedule (chol.hip,
+// factor_panel_cp): sub-panel s needs the diagonal blocks <= s factored and L(diagonal-block rows, sub-panels < s) final.
+int launch_panel_rest_cols(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv, int s_lo,
+                           int s_hi)
+{
+    const int64_t T = (n - k + PTB - 1) / PTB;
+    const int nsb = (int)((kb + PTB - 1) / PTB);
+    if (T <= nsb || s_hi <= s_lo) return FR_OK;
+    PanelArgs a;
+    a.A = A;
+    a.lda = lda;
+    a.n = n;
+    a.k = k;
+    a.kb = kb;
+    a.dinv = dinv;
+    a.ready = a.done = a.tdone = nullptr;
+    a.status = ctx->dev_status;
+    a.jb = (int)(k / PTB);
+    a.nsb = nsb;
+    a.s_lo = s_lo;
+    a.s_hi = s_hi;
+    a.ntiles = T - nsb;
+    int64_t grid = a.ntiles;
+    a.place = claim_setup(ctx, 1, a.ntiles, &a.xcc_word, &a.claim, &a.max_exit, &grid);
+    a.nres = ctx->reserve_now;
+    a.epoch = ctx->panel_epoch;
+    const double rows = (double)(n - k - kb);
+    double fl = 0.0;
+    for (int s = s_lo; s < s_hi; ++s) fl += 2.0 * rows * 128.0 * 128.0 * (double)(s + 1);
+    ProfScope ps(ctx, FR_PROF_GEMM_PANEL, fl, 8.0 * rows * 128.0 * (double)(s_hi + 1));
+    hipLaunchKernelGGL(panel_rest_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
@@ -235,6 +287,9 @@ int launch_panel_tiles(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k
     a.status = ctx->dev_status;
     a.jb = (int)(k / PTB);
     a.nsb = (int)((kb + PTB - 1) / PTB);
+    a.s_lo = 0;
+    a.s_hi = a.nsb;
+    a.place = 0;
     const int64_t T = (n - k + PTB - 1) / PTB;
     const double rows = (double)(n - k);
     ProfScope ps(ctx, FR_PROF_GEMM_PANEL, rows * (double)kb * (double)kb, 8.0 * rows * (double)kb * 2.0);

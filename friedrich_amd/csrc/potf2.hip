@@ -666,9 +666,15 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
                                                    int64_t* __restrict__ info, double* __restrict__ cest,
-                                                   unsigned* __restrict__ yield_word)
+                                                   unsigned* __restrict__ yield_word, unsigned* __restrict__ xcc_word)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (xcc_word && threadIdx.x == 0) {
+        // tell the trailing update which XCD to leave alone (gemm_f64.hip, option xcd_reserve)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_store(xcc_word, (xcc & 7u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ask the GEMM workgroup that shares this CU to step aside for the length of the pivot chain (gemm_tile.hpp)
     unsigned key = 0;
     if (yield_word && threadIdx.x == 0) {
@@ -781,7 +787,8 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
     }
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
     hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv,
-                       info, cest, ctx->k4_yield ? ctx->yield_word : nullptr);
+                       info, cest, ctx->k4_yield ? ctx->yield_word : nullptr,
+                       (ctx->xcd_reserve != 0 || ctx->xcd_reserve2 > 0) ? ctx->yield_word + 4 : nullptr);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
