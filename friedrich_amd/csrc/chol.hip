@@ -315,11 +315,66 @@ static int factor_panel_cp(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_
     return factor_panel_cp(ctx, A, ld, n, k + kb1, kb - kb1, pk, pkb, col0, mode, sub, dinv, info);
 }
 
+// Chain-bound panels (option panel_rl, with at least two XCDs set aside): right-looking by 128-column blocks, and the chain
+// between two diagonal-block kernels is ONE single-workgroup launch (panel_step_kernel: the next diagonal row tile's solve
+// and its own rank-128 update).  Everything else runs beside the chain on stream4, on the helper XCDs (place 5):
+//   T(j): L[i, j] = A[i, j] W_j^T for the rows from block j + 2 on      -- after the diagonal-block kernel of block j
+//   U(j): A[i, c] -= L[i, j] L[c, j]^T, rows from block j + 2 on, columns of the panel's blocks > j  -- after step(j + 1)
+// and step(j + 2) waits for U(j).  Chain per block: diagonal-block kernel + one step, ~60 + ~40 us.
+static int factor_panel_rl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
+                           double sub, double* dinv, int64_t* info)
+{
+    hipStream_t S1 = ctx->stream2, SB = ctx->stream4;
+    const int64_t nblk = (kb + IB - 1) / IB;
+    const int64_t pend = k + kb;
+    auto chain_to_helpers = [&]() -> int {
+        FR_HIP(ctx, hipEventRecord(ctx->ev_cb, S1));
+        FR_HIP(ctx, hipStreamWaitEvent(SB, ctx->ev_cb, 0));
+        return FR_OK;
+    };
+    for (int64_t j = 0; j < nblk; ++j) {
+        const int64_t c = k + j * IB, cb = imin(IB, pend - c);
+        double* inv = dinv + (c / IB) * INV_ELEMS;
+        ctx->ls = S1;
+        if (j > 0) {
+            if (j > 1) FR_HIP(ctx, hipStreamWaitEvent(S1, ctx->ev_u, 0));  // U(j - 2): the last update of row tile j from outside
+            FR_TRY(launch_panel_step(ctx, A, ld, n, c, c - IB, IB, inv - INV_ELEMS));
+            // U(j - 1) needs L[j, j - 1]
+            FR_TRY(chain_to_helpers());
+            const int64_t r2 = c + IB;  // rows from block j + 1 on
+            if (n > r2) {
+                ctx->ls = SB;
+                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - r2, pend - c, IB, A + r2 + (c - IB) * ld, ld, false, A + c + (c - IB) * ld, ld,
+                            false, -1.0, 1.0, A + r2 + c * ld, ld, false, 5));
+                FR_HIP(ctx, hipEventRecord(ctx->ev_u, SB));
+                ctx->ls = S1;
+            }
+        }
+        FR_TRY(factor_block128(ctx, A + c + c * ld, ld, cb, col0 + c, mode, sub, inv, info, nullptr));
+        // T(j): the rows from block j + 2 on (row tile j + 1 is the next step's); the last block: every row below it
+        const int64_t r2 = (j + 1 < nblk) ? c + 2 * IB : c + cb;
+        if (n > r2) {
+            FR_TRY(chain_to_helpers());
+            ctx->ls = SB;
+            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - r2, cb, cb, A + r2 + c * ld, ld, false, inv, IB, false, 1.0, 0.0, A + r2 + c * ld, ld,
+                        false, 5));
+            ctx->ls = S1;
+        }
+    }
+    // the panel is finished when the helpers are
+    FR_HIP(ctx, hipEventRecord(ctx->ev_bulk, SB));
+    FR_HIP(ctx, hipStreamWaitEvent(S1, ctx->ev_bulk, 0));
+    return FR_OK;
+}
+
 // One panel of the look-ahead pipeline: the critical-path variant when it applies, and then the main stream is made to wait
 // for the bulk stream as well (the caller records ev_panel on the panel stream).
 static int factor_panel_la(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
                            double sub, double* dinv, int64_t* info, double* T, const Fused* f, bool cp)
 {
+    if (ctx->panel_rl && ctx->reserve_now >= 2 && ctx->stream4 && !ctx->refine_now && mode != 3 && !(f && f->on) &&
+        ctx->panel_fused == 0 && kb > IB)
+        return factor_panel_rl(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info);
     if (!cp) return factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T, f);
     FR_TRY(factor_panel_cp(ctx, A, ld, n, k, kb, k, kb, col0, mode, sub, dinv, info));
     if (n > k + kb) {

@@ -343,6 +343,7 @@ int fr_ctx_create(fr_ctx** out, int device)
         hipStreamCreateWithPriority(&ctx->stream4, hipStreamNonBlocking, hi) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_cb, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_bulk, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_u, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_server, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_la, hipEventDisableTiming) != hipSuccess) {
@@ -350,7 +351,8 @@ int fr_ctx_create(fr_ctx** out, int device)
         return FR_HIP_ERROR;
     }
     if (hipMalloc((void**)&ctx->yield_word, 64) != hipSuccess || hipMemset(ctx->yield_word, 0, 64) != hipSuccess ||
-        hipMalloc((void**)&ctx->claim_ring, sizeof(unsigned) * 2 * kClaimSlots) != hipSuccess) {
+        hipMalloc((void**)&ctx->claim_ring, sizeof(unsigned) * 2 * kClaimSlots) != hipSuccess ||
+        hipMalloc((void**)&ctx->step_flags, 64) != hipSuccess || hipMemset(ctx->step_flags, 0, 64) != hipSuccess) {
         fr_ctx_destroy(ctx);
         return FR_HIP_ERROR;
     }
@@ -384,7 +386,9 @@ void fr_ctx_destroy(fr_ctx* ctx)
     }
     if (ctx->ev_cb) (void)hipEventDestroy(ctx->ev_cb);
     if (ctx->ev_bulk) (void)hipEventDestroy(ctx->ev_bulk);
+    if (ctx->ev_u) (void)hipEventDestroy(ctx->ev_u);
     if (ctx->claim_ring) (void)hipFree(ctx->claim_ring);
+    if (ctx->step_flags) (void)hipFree(ctx->step_flags);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
         (void)hipStreamDestroy(ctx->stream3);
@@ -545,6 +549,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "bulk_xcd_tiles")) {
         if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "bulk_xcd_tiles must be >= 0");
         ctx->bulk_xcd_tiles = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "panel_rl")) {
+        if (value < 0 || value > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_rl must be 0, 1 or 2");
+        ctx->panel_rl = value;
         return FR_OK;
     }
     if (!strcmp(name, "panel_crit")) {

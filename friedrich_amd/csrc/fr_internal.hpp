@@ -98,6 +98,10 @@ struct fr_ctx {
     unsigned* claim_ring = nullptr;  // device: {tile counter, retire counter} per reserved launch of a factorisation
     int64_t claim_next = 0;
     int64_t bulk_xcd_tiles = 0;    // bulk launches of at most this many tiles run ON the reserved XCD
+    int* step_flags = nullptr;     // device: the four slice flags of panel_step4_kernel (monotonic target step_epoch)
+    int step_epoch = 0;
+    int64_t panel_rl = 0;          // chain-bound panels: per-block right-looking schedule (chol.hip, factor_panel_rl)
+    hipEvent_t ev_u = nullptr;
     int64_t panel_crit = 0;        // panel factorisation split into critical rows (panel stream) and bulk rows (stream4)
     hipStream_t stream4 = nullptr;
     hipEvent_t ev_cb = nullptr, ev_bulk = nullptr;
@@ -345,6 +349,7 @@ int launch_panel_tiles(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k
                        int* ready, int* done, int* tdone);
 
 int launch_panel_rest(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv);
+int launch_panel_step(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t cols, const double* W);
 int launch_panel_rest_cols(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv, int s_lo,
                            int s_hi);
 

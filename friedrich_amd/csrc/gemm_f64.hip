@@ -69,7 +69,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
             if (x >= g.nres) return;
             tlin = (b >> 3) * g.nres + x;
             if (tlin >= g.ntiles) return;
-        } else if (g.place == 1 || g.place == 3) {
+        } else if (g.place == 1 || g.place == 3 || g.place == 5) {
             tlin = claim_item(g.place, g.nres, g.epoch, g.xcc_word, g.claim, g.max_exit, g.ntiles);  // gemm_tile.hpp
             if (tlin < 0) return;
         } else {
@@ -230,7 +230,9 @@ int claim_setup(fr_ctx* ctx, int place, int64_t items, const unsigned** xcc_word
     *xcc_word = ctx->yield_word + 4;
     *claim = ctx->claim_ring + 2 * ctx->claim_next++;
     const int64_t R = ctx->reserve_now;
-    *max_exit = (unsigned)((place == 3 ? items * (8 - R) / R : items * R / (8 - R)) + 16);
+    const int64_t on = place == 3 ? R : (place == 5 ? R - 1 : 8 - R);  // XCDs whose workgroups take items
+    if (on <= 0) return 0;
+    *max_exit = (unsigned)(items * (8 - on) / on + 16);
     *grid = items + *max_exit;
     return place;
 }
@@ -338,7 +340,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
             if (!d.lower) g.place = 2;
         } else {
             int64_t grid = 0;
-            g.place = claim_setup(ctx, (d.place == 3 && !d.lower && ntiles <= ctx->bulk_xcd_tiles) ? 3 : 1, ntiles, &g.xcc_word,
+            g.place = claim_setup(ctx, (d.place == 5 && !d.lower) ? 5 : ((d.place == 3 && !d.lower && ntiles <= ctx->bulk_xcd_tiles) ? 3 : 1), ntiles, &g.xcc_word,
                                   &g.claim, &g.max_exit, &grid);
         }
         if (g.place) use_super = false;
@@ -348,7 +350,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     else
         g.nsuper = 0;
     if (g.place == 2) ntiles = 8 * ((g.ntiles + g.nres - 1) / g.nres);
-    if (g.place == 1 || g.place == 3) ntiles = g.ntiles + g.max_exit;
+    if (g.place == 1 || g.place == 3 || g.place == 5) ntiles = g.ntiles + g.max_exit;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
     double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
     if (d.own_world > 1) {

@@ -157,9 +157,17 @@ __device__ __forceinline__ long long claim_item(int place, int nres, unsigned ep
         // the panel whose chain the reservation protects is finished (its stream said so): the XCDs are everybody's again
         const unsigned released = __hip_atomic_load(xcc_word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool held = (int)(released - epoch) < 0;
-        const bool on = held && word != 0u && ((phys - (word - 1u)) & 7u) < (unsigned)nres;
+        const bool known = word != 0u;
+        const unsigned dist = (phys - (word - 1u)) & 7u;  // 0: the XCD of the diagonal-block kernels
+        bool want;  // should this workgroup take an item?
+        if (place == 1)
+            want = !(held && known && dist < (unsigned)nres);  // trailing update: keep off the reserved XCDs
+        else if (place == 3)
+            want = known && dist < (unsigned)nres;  // on the reserved XCDs
+        else
+            want = known && dist >= 1u && dist < (unsigned)nres;  // place 5, helpers of the panel chain: reserved, but not the chain's own
         bool retire = false;
-        if (on == (place == 1)) retire = __hip_atomic_fetch_add(claim + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < max_exit;
+        if (!want) retire = __hip_atomic_fetch_add(claim + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < max_exit;
         long long tl = -1;
         if (!retire) {
             const unsigned i = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -270,6 +270,62 @@ int launch_panel_rest_cols(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64
     return FR_OK;
 }
 
+// ---- the chain step between two diagonal-block kernels (chol.hip, factor_panel_rl): ONE workgroup takes row tile j of the
+// panel from "every update of the blocks before j - 1 applied" to "diagonal block (j, j) ready to be factored":
+//   L[j, j-1] = A[j, j-1] W_{j-1}^T (in place),   A[j, j] -= L[j, j-1] L[j, j-1]^T.
+// Two dependent 128^3 products on one CU (one call site: see panel_rest_kernel).
+__global__ __launch_bounds__(256, 2) void panel_step_kernel(double* A, int64_t lda, int64_t r0, int64_t c0, int rows, int cols,
+                                                            const double* __restrict__ W)
+{
+    __shared__ double lds[4 * TILE_ELEMS];
+    double* L = A + r0 + c0 * lda;
+#pragma nounroll
+    for (int op = 0; op < 2; ++op) {
+        const bool solve = op == 0;
+        tile_product(lds, rows, solve ? cols : rows, cols, L, lda, solve ? W : L, solve ? (int64_t)PTB : lda,
+                     solve ? L : A + r0 + r0 * lda, lda, solve ? 1.0 : -1.0, solve ? 0.0 : 1.0);
+        __syncthreads();
+    }
+}
+
+// The same step on FOUR workgroups (32-row slices of the row tile, MFMA fragments straight from L2: a slice product is a
+// quarter as deep as the 128 x 128 tile's): solve, hand the slice over (the update needs every row of L[j, j-1]), update.
+// Launched with 32 workgroups of which those with blockIdx.x % 8 == 0 work: the panel stream's own XCD (gemm_f64.hip).
+__global__ __launch_bounds__(256, 2) void panel_step4_kernel(double* A, int64_t lda, int64_t r0, int64_t c0, int rows, int cols,
+                                                             const double* __restrict__ W, int* flags, int target, unsigned* status)
+{
+    if (blockIdx.x & 7) return;
+    const int sl = (int)(blockIdx.x >> 3);
+    const int64_t row0 = r0 + (int64_t)SLH * sl;
+    int m = rows - SLH * sl;
+    m = m < 0 ? 0 : (m < SLH ? m : SLH);
+    double* L = A + row0 + c0 * lda;
+    if (m > 0) slice_product(m, cols, cols, L, lda, W, PTB, L, lda, 1.0, 0.0);
+    handoff_publish(flags + sl, target);
+    if (!handoff_wait_all_ge(flags, NSL, target, status)) return;
+    if (m > 0) {
+        int nc = SLH * (sl + 1);  // the lower part of the diagonal block only
+        nc = nc < rows ? nc : rows;
+        slice_product(m, nc, cols, L, lda, A + r0 + c0 * lda, lda, A + row0 + r0 * lda, lda, -1.0, 1.0);
+    }
+}
+
+int launch_panel_step(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t cols, const double* W)
+{
+    const int64_t rows = (n - r0) < PTB ? (n - r0) : PTB;
+    if (rows <= 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_GEMM_PANEL, 2.0 * (double)rows * (double)cols * (double)(cols + rows), 8.0 * 3.0 * 128.0 * 128.0);
+    if (ctx->panel_rl == 2 && ctx->step_flags) {
+        FR_TRY(ensure_status_word(ctx));
+        hipLaunchKernelGGL(panel_step4_kernel, dim3(8 * NSL), dim3(256), 0, ctx->ls, A, lda, r0, c0, (int)rows, (int)cols, W,
+                           ctx->step_flags, ++ctx->step_epoch, ctx->dev_status);
+    } else {
+        hipLaunchKernelGGL(panel_step_kernel, dim3(1), dim3(256), 0, ctx->ls, A, lda, r0, c0, (int)rows, (int)cols, W);
+    }
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
 int launch_panel_tiles(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv, int* ready,
                        int* done, int* tdone)
 {

@@ -1,6 +1,6 @@
 """Developer probe: fit time with XCDs set aside for the panel stream.
     xcd_reserve_ab.py <n,n,...> <crit:R1:rest1:R2:rest2,...>
-crit = option panel_crit, R1 XCDs while the trailing matrix has <= rest1 rows (0: always), R2 XCDs below rest2 rows."""
+crit = option panel_crit (10 + crit: option panel_rl as well), R1 XCDs while the trailing matrix has <= rest1 rows (0: always), R2 XCDs below rest2 rows."""
 import sys
 import time
 
@@ -20,7 +20,8 @@ for n in [int(a) for a in sys.argv[1].split(",")]:
     ref = chol.l() if n <= 8192 else None
     for rnd in range(2):
         for (crit, r, rest, r2, rest2) in variants:
-            ctx.set_option("panel_crit", crit)
+            ctx.set_option("panel_crit", crit % 10)
+            ctx.set_option("panel_rl", crit // 10)
             ctx.set_option("xcd_reserve", r)
             ctx.set_option("xcd_reserve_rest", rest)
             ctx.set_option("xcd_reserve2", r2)
@@ -35,6 +36,6 @@ for n in [int(a) for a in sys.argv[1].split(",")]:
                 extra = f"  max |dL| {float(np.max(np.abs(chol.l() - ref))):.1e}"
             if rnd == 1:
                 print(f"n={n} crit={crit} R1={r} rest1<={rest} R2={r2} rest2<={rest2}: fit min {1e3*min(ts):.2f} ms{extra}", flush=True)
-    for o in ("xcd_reserve", "xcd_reserve2", "panel_crit"):
+    for o in ("xcd_reserve", "xcd_reserve2", "panel_crit", "panel_rl"):
         ctx.set_option(o, 0)
     chol.free()

@@ -553,6 +553,44 @@ def test_refinement_policy_and_forced_modes(ctx):
     assert rel_err(Ls[0], Ls[2]) < 1e-13 and np.array_equal(Ls[0], Ls[1])
 
 
+@pytest.mark.parametrize("n", [1536, 2500, 3200])
+def test_xcd_reservation_and_panel_schedules(ctx, n):
+    """The look-ahead pipeline with XCDs set aside for the panel chain (gemm_f64.hip: trailing-update tiles CLAIMED by the
+    workgroups that do not sit on the panel stream's XCDs, panel launches on the b % 8 < R workgroups) and the panel
+    schedules built on it (critical / bulk rows, per-sub-panel rest launches, right-looking chain steps): every setting
+    gives the oracle's factor, the default (automatic reservation) and "off" bit for bit the same one."""
+    k = PD_KERNELS[0]
+    X = rand_inputs(n, 3, 77 + n)
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    L_o = np.tril(L_o)
+    chol = ctx.cholesky_from_inputs(k, X, 0.1)
+    L_auto = chol.l()
+    assert rel_err(L_auto, L_o) < TOL
+    settings = [  # (xcd_reserve, xcd_reserve2 / rest2, panel_crit, panel_rl)
+        (0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (4, 0, 0, 0), (1, 3, 0, 0), (1, 0, 1, 0), (2, 0, 2, 0), (3, 0, 0, 1), (2, 4, 0, 1), (3, 0, 0, 2), (2, 4, 0, 2)]
+    try:
+        for (r1, r2, crit, rl) in settings:
+            ctx.set_option("xcd_reserve", r1)
+            ctx.set_option("xcd_reserve_rest", 0)
+            ctx.set_option("xcd_reserve2", r2)
+            ctx.set_option("xcd_reserve_rest2", 2048)
+            ctx.set_option("panel_crit", crit)
+            ctx.set_option("panel_rl", rl)
+            for rep in range(2):  # (twice: the claim counters are recycled, the published XCD is known the second time)
+                chol.refactor(k, 0.1)
+                L = chol.l()
+                assert rel_err(L, L_o) < TOL, (r1, r2, crit, rl)
+                if crit != 2 and rl == 0:
+                    assert np.array_equal(L, L_auto), (r1, r2, crit, rl)  # same arithmetic, only placed differently
+                else:
+                    assert rel_err(L, L_auto) < 1e-12
+    finally:
+        for o, v in (("xcd_reserve", -1), ("xcd_reserve_rest", 0), ("xcd_reserve2", 0), ("xcd_reserve_rest2", 0), ("panel_crit", 0),
+                     ("panel_rl", 0)):
+            ctx.set_option(o, v)
+    chol.free()
+
+
 @pytest.mark.parametrize("n,m", [(2, 2), (127, 3), (128, 16), (129, 7), (300, 2), (1000, 16), (2049, 5), (700, 17), (1300, 100), (900, 300)])
 def test_narrow_persistent_solves_2_to_16_columns(ctx, n, m):
     """2 .. 16 right-hand sides (and more, in column groups of 16): one persistent matrix-core launch per direction (trsm_narrow.hip), the backward sweep on
