@@ -106,7 +106,12 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "trsv"          1 (default): solves with ONE right-hand side run as one persistent launch per direction
  *   "predict_assoc" 0 (default): predict as the reference associates it, prior + (K^-1 K*)^T y  (mod.rs:234-241,
  *                   two n x m triangular solves);  1: prior + K*^T (K^-1 y), the same value up to rounding with two
- *                   n x 1 solves instead */
+ *                   n x 1 solves instead
+ *   "xcd_reserve"   -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
+ *                   the panel stream's XCDs (1 XCD below 12288 trailing rows, 2 below 8192, nb <= 512 only: DESIGN.md
+ *                   section 5); 0: never; 1..4 with "xcd_reserve_rest" / "xcd_reserve2" / "xcd_reserve_rest2": explicit tiers
+ *   developer probes kept behind options (measured, not adopted): "panel_fused", "panel_crit",
+ *   "panel_rl", "syrk_dynamic", "k4_yield", "panel_split" (multi-GPU: section 6) */
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
 
 /* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline leg). */
