@@ -585,7 +585,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
             if (ctx->xcd_reserve < 0) {
                 // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
                 // own products are too large for one or two XCDs and every setting is neutral or worse
-                if (nb <= 512) ctx->reserve_now = rest <= 8192 ? 2 : (rest <= 12288 ? 1 : 0);
+                if (nb <= 512) ctx->reserve_now = rest <= 8192 ? 2 : (rest <= 16384 ? 1 : 0);  // (12288 .. 16384: the same to 1 %)
             } else {
                 if (ctx->xcd_reserve > 0 && (ctx->xcd_reserve_rest == 0 || rest <= ctx->xcd_reserve_rest)) ctx->reserve_now = (int)ctx->xcd_reserve;
                 if (ctx->xcd_reserve2 > 0 && rest <= ctx->xcd_reserve_rest2) ctx->reserve_now = (int)ctx->xcd_reserve2;

@@ -90,7 +90,7 @@ struct fr_ctx {
     int64_t panel_split = 0;
     // XCD reservation (gemm_f64.hip): the main stream's GEMM launches of a factorisation leave the first `xcd_reserve` XCDs
     // to the panel stream (their workgroups there exit at once) while the trailing matrix has at most `xcd_reserve_rest` rows
-    int64_t xcd_reserve = -1;  // -1: chosen by the factorisation (single GPU, nb <= 512: 1 XCD below 12288 rows, 2 below 8192)
+    int64_t xcd_reserve = -1;  // -1: chosen by the factorisation (single GPU, nb <= 512: 1 XCD below 16384 rows, 2 below 8192)
     int64_t xcd_reserve_rest = 0;  // 0: whenever xcd_reserve > 0
     int64_t xcd_reserve2 = 0, xcd_reserve_rest2 = 0;  // second tier: this many XCDs once the trailing matrix is this small
     int reserve_now = 0;           // XCDs reserved right now (set by the factorisation around the launches it applies to)

@@ -108,7 +108,7 @@ const char* fr_last_error(const fr_ctx* ctx);
  *                   two n x m triangular solves);  1: prior + K*^T (K^-1 y), the same value up to rounding with two
  *                   n x 1 solves instead
  *   "xcd_reserve"   -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
- *                   the panel stream's XCDs (1 XCD below 12288 trailing rows, 2 below 8192, nb <= 512 only: DESIGN.md
+ *                   the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, nb <= 512 only: DESIGN.md
  *                   section 5); 0: never; 1..4 with "xcd_reserve_rest" / "xcd_reserve2" / "xcd_reserve_rest2": explicit tiers
  *   developer probes kept behind options (measured, not adopted): "panel_fused", "panel_crit",
  *   "panel_rl", "syrk_dynamic", "k4_yield", "panel_split" (multi-GPU: section 6) */
