@@ -125,6 +125,7 @@ static int fused_start(fr_ctx* ctx, Fused& f, double* A, int64_t ld, int64_t n, 
     a.ready = f.ready;
     a.done = f.done;
     a.status = ctx->dev_status;
+    a.cest = (ctx->cur_cest && col0 == 0) ? ctx->cur_cest : nullptr;  // conditioning estimates, one per block (potf2.hip)
     a.dbg = nullptr;
     if (ctx->panel_debug && nblk <= 1024) {
         if (!ctx->panel_dbg) {

@@ -553,6 +553,32 @@ def test_refinement_policy_and_forced_modes(ctx):
     assert rel_err(Ls[0], Ls[2]) < 1e-13 and np.array_equal(Ls[0], Ls[1])
 
 
+@pytest.mark.parametrize("opt,val", [("panel_fused", 1), ("panel_fused", 2), ("panel_fused", 3), ("panel_fused", 4), ("syrk_dynamic", 1),
+                                     ("k4_yield", 1), ("lookahead", 0)])
+def test_probe_options_keep_the_factor(ctx, opt, val):
+    """The design probes kept behind options (resident diagonal-block server, fused row-tile panel
+    kernel, rest kernel, dynamically pulled trailing update, cooperative yield) stay correct: the oracle's factor, the same
+    conditioning estimate as the default path."""
+    k = PD_KERNELS[0]
+    n = 2700
+    X = rand_inputs(n, 3, 4242)
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    chol = ctx.cholesky_from_inputs(k, X, 0.1)
+    L_d = chol.l()
+    assert rel_err(L_d, np.tril(L_o)) < TOL
+    est_d = chol.conditioning()
+    ctx.set_option(opt, val)
+    try:
+        for rep in range(2):
+            chol.refactor(k, 0.1)
+            assert rel_err(chol.l(), L_d) < 1e-12
+            est = chol.conditioning()
+            assert est[1] == est_d[1] and abs(est[0] / est_d[0] - 1.0) < 1e-9
+    finally:
+        ctx.set_option(opt, 1 if opt == "lookahead" else 0)
+    chol.free()
+
+
 @pytest.mark.parametrize("n", [1536, 2500, 3200])
 def test_xcd_reservation_and_panel_schedules(ctx, n):
     """The look-ahead pipeline with XCDs set aside for the panel chain (gemm_f64.hip: trailing-update tiles CLAIMED by the
