@@ -560,8 +560,16 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
     FR_HIP(ctx, hipEventRecord(ctx->ev_la, S0));
     FR_HIP(ctx, hipStreamWaitEvent(S1, ctx->ev_la, 0));
     ctx->ls = S1;
+    // Panel width per step.  Fixed (nb) except on a single GPU with nb > 512 (the automatic choice at large n): nb columns while the
+    // trailing update dominates (each pass over the trailing matrix costs a read and a write of it whatever its depth), 512
+    // once the panel chain does -- from there on the factorisation is the one of an n = nb_switch_rows matrix, XCD
+    // reservation (nb <= 512) included.
+    auto width = [&](int64_t remaining) -> int64_t {
+        if (world == 1 && nb > 512 && ctx->nb_switch_rows > 0 && remaining <= ctx->nb_switch_rows) return imin(512, remaining);
+        return imin(nb, remaining);
+    };
+    const int64_t kb0 = width(n);
     {
-        const int64_t kb0 = imin(nb, n);
         if (split) {
             st = split_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(0, nb, world));
         } else {
@@ -571,13 +579,12 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (st != FR_OK) return fail(st);
     }
     if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
-    for (int64_t k = 0; k < n; k += nb) {
-        const int64_t kb = imin(nb, n - k);
+    for (int64_t k = 0, kb = kb0, kb_next = 0; k < n; k += kb, kb = kb_next) {
         const int64_t rest = n - (k + kb);
         ctx->ls = S0;
         if (hipStreamWaitEvent(S0, ctx->ev_panel, 0) != hipSuccess) return fail(FR_HIP_ERROR);
         if (rest <= 0) break;
-        const int64_t kb2 = imin(nb, rest);
+        const int64_t kb2 = kb_next = width(rest);
         const double* P = A + (k + kb) + k * ld;
         // once the panel chain is longer than the trailing update, the update's launches leave XCD 0 to it (gemm_f64.hip)
         ctx->reserve_now = 0;
@@ -586,7 +593,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
             if (ctx->xcd_reserve < 0) {
                 // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
                 // own products are too large for one or two XCDs and every setting is neutral or worse
-                if (nb <= 512) ctx->reserve_now = rest <= 8192 ? 2 : (rest <= 16384 ? 1 : 0);  // (12288 .. 16384: the same to 1 %)
+                if (kb2 <= 512) ctx->reserve_now = rest <= 8192 ? 2 : (rest <= 16384 ? 1 : 0);  // (12288 .. 16384: the same to 1 %)
             } else {
                 if (ctx->xcd_reserve > 0 && (ctx->xcd_reserve_rest == 0 || rest <= ctx->xcd_reserve_rest)) ctx->reserve_now = (int)ctx->xcd_reserve;
                 if (ctx->xcd_reserve2 > 0 && rest <= ctx->xcd_reserve_rest2) ctx->reserve_now = (int)ctx->xcd_reserve2;

@@ -551,6 +551,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->bulk_xcd_tiles = value;
         return FR_OK;
     }
+    if (!strcmp(name, "nb_switch_rows")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "nb_switch_rows must be >= 0");
+        ctx->nb_switch_rows = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "panel_rl")) {
         if (value < 0 || value > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_rl must be 0, 1 or 2");
         ctx->panel_rl = value;

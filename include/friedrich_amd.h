@@ -94,7 +94,8 @@ int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
 /* Tunables:
- *   "nb"            outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
+ *   "nb"            outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096];
+ *                   "nb_switch_rows" (16384): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
  *   "lookahead"     1 (default): factor the next panel on a second stream under the trailing update
  *   "gemm_tile"     tile-order experiments of the GEMM (0 = default; see gemm_f64.hip)
  *   "narrow_max"    16 (default): solves with at most this many right-hand sides use memory-bound kernels instead of the
