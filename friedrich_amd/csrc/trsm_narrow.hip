@@ -61,6 +61,23 @@ __device__ __forceinline__ void load_frag(const Frag& f, int w, int l15, int lq,
     }
 }
 
+// 16 rows (of this wave) x 64 columns (half H of a 128-column tile): the lane holds element (m = 16 w + l15,
+// k = 64 H + 4 u + lq), u = 0 .. 15.  Half tiles keep the two register buffers at 64 VGPRs together, so that two
+// workgroups fit a CU: the chains of different column groups (and the tiles of one) then overlap on every CU.
+__device__ __forceinline__ void load_half(const Frag& f, int H, int w, int l15, int lq, double (&buf)[16])
+{
+    // address = wave-uniform part (block, column group: scalar registers) + one 32-bit lane offset shared by all 16 loads
+    const unsigned lane_off = (unsigned)(16 * w + l15) + (unsigned)lq * (unsigned)f.stride;
+    const double* base = f.base + (int64_t)(64 * H) * f.stride;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) buf[u] = (base + (int64_t)(4 * u) * f.stride)[lane_off];
+    if (f.mrows < NB || f.kcols < NB) {  // last block only: zeros outside the valid extent (the addresses exist)
+        const bool mok = 16 * w + l15 < f.mrows;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) buf[u] = (mok && 64 * H + 4 * u + lq < f.kcols) ? buf[u] : 0.0;
+    }
+}
+
 __device__ __forceinline__ Frag item_frag(const TrsmnArgs& a, int blk, int other, bool inverse)
 {
     Frag f;
@@ -81,7 +98,8 @@ __device__ __forceinline__ Frag item_frag(const TrsmnArgs& a, int blk, int other
     return f;
 }
 
-// solution block `blk` -> xs ([col][q]); false after a timeout
+// solution block `blk` -> xs ([col][q]); false after a timeout.  ONE buffer: the barrier inside the wait also tells that
+// every wave is done with the block before.
 __device__ __forceinline__ bool fetch_block(const TrsmnArgs& a, int blk, double* xs, int t)
 {
     if (!handoff_wait_ge<false>(a.flags + blk, 1, a.status)) return false;  // no acquire fence: sc1 stores, sc1 loads
@@ -93,6 +111,85 @@ __device__ __forceinline__ bool fetch_block(const TrsmnArgs& a, int blk, double*
     return true;
 }
 
+__device__ __forceinline__ void mma_half(const double (&buf)[16], const double* xs, int H, int l15, int lq, d4n_t& acc)
+{
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const double xf = xs[(64 * H + 4 * u + lq) * MR + l15];  // element (k = 64 H + 4 u + lq, q = l15)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, buf[u], acc, 0, 0, 0);
+    }
+}
+
+// The kernel for TWO OR MORE column groups (m > 16): half-tile register buffers, one LDS buffer -- 128 VGPRs and 16 KiB, so two
+// workgroups share a CU and the chains of different groups (each a sequence of dependent hand-offs, ~10 us apiece) run side
+// by side.  Measured against the kernel below on the same solves: 8 x add_samples(512) at 4096 .. 8192 rows 18.3 -> 14.9 ms,
+// sample_at(256) 4.0 -> 3.3 ms; with ONE group the deeper prefetch of the kernel below wins (predict of 16 points at
+// N = 32768: 4.7 vs 5.5 ms).
+__global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArgs a0)
+{
+    __shared__ double xs[NB * MR];  // a solution block while it is multiplied; then t = b - sum for the closing product
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int last = a0.nblk - 1;
+    // column group: 16 right-hand sides with their own solution blocks and flags -- the groups are independent chains that
+    // stream the same tiles (served from L2 / Infinity Cache after the first reader)
+    TrsmnArgs a = a0;
+    {
+        const int grp = blockIdx.y;
+        a.B += (int64_t)grp * MR * a.ldb;
+        a.m = a.m - grp * MR < MR ? a.m - grp * MR : MR;
+        a.xg += (int64_t)grp * a.nblk * (NB * MR);
+        a.flags += (int64_t)grp * a.nblk;
+    }
+#pragma nounroll
+    for (int bi = blockIdx.x; bi < a.nblk; bi += a.G) {
+        const int blk = a.bwd ? last - bi : bi;
+        const int cnt = a.bwd ? last - blk : blk;  // tiles; item q uses the solution block dep(q); item cnt: the inverse block
+        const int64_t b0 = (int64_t)blk * NB;
+        const int64_t row = b0 + 16 * w + l15;
+        // the accumulator starts at -b (this lane's right-hand side entries (row, q = lq + 4 i)): after the tiles it holds
+        // -(b - sum L x), and no copy of b lives across the loop
+        d4n_t acc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (row < a.n && lq + 4 * i < a.m) ? -a.B[row + (int64_t)(lq + 4 * i) * a.ldb] : 0.0;
+        double H0[16], H1[16];  // first / second half of the current item; the next half is always in flight
+        load_half(item_frag(a, blk, a.bwd ? last : 0, cnt == 0), 0, w, l15, lq, H0);
+#pragma nounroll
+        for (int q = 0; q <= cnt; ++q) {
+            const Frag f = item_frag(a, blk, a.bwd ? last - q : q, q >= cnt);
+            load_half(f, 1, w, l15, lq, H1);
+            if (q < cnt) {
+                if (!fetch_block(a, a.bwd ? last - q : q, xs, t)) return;
+            } else {
+                // t = b - sum = -acc, the [col][q] operand of the closing product with the inverse block (same buffer: every
+                // wave is done with the last solution block first)
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xs[(16 * w + l15) * MR + lq + 4 * i] = -acc[i];
+                acc = d4n_t{0.0, 0.0, 0.0, 0.0};
+                __syncthreads();
+            }
+            mma_half(H0, xs, 0, l15, lq, acc);
+            if (q < cnt) load_half(item_frag(a, blk, a.bwd ? last - q - 1 : q + 1, q + 1 >= cnt), 0, w, l15, lq, H0);
+            mma_half(H1, xs, 1, l15, lq, acc);
+        }
+        // publish (write-through), then the caller's copy
+        double* dst = a.xg + (int64_t)blk * (NB * MR);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __hip_atomic_store((gdbl*)(dst + (16 * w + l15) * MR + lq + 4 * i), acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store((hgi32*)(a.flags + blk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (row < a.n && lq + 4 * i < a.m) a.B[row + (int64_t)(lq + 4 * i) * a.ldb] = acc[i];
+        __syncthreads();  // xs is reused by the next block of this workgroup
+    }
+}
+
+// ---- one column group (m <= 16): whole-tile register buffers, the next tile always in flight
 __device__ __forceinline__ void mma_block(const double (&buf)[32], const double* xs, int l15, int lq, d4n_t& acc)
 {
 #pragma unroll
@@ -259,11 +356,14 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     a.ngroups = ngroups;
     a.status = ctx->dev_status;
     a.nblk = nblk;
-    a.G = nblk < ctx->num_cus ? nblk : ctx->num_cus;
+    a.G = nblk < ctx->num_cus ? nblk : ctx->num_cus;  // (two workgroups fit a CU: two column groups' chains side by side)
     a.bwd = fwd ? 0 : 1;
     FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)nblk * (size_t)ngroups, ctx->ls));
     ProfScope ps(ctx, prof_cls, (double)n * (double)n * (double)m, 4.0 * (double)n * (double)n);
-    hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
+    if (ngroups >= 2)
+        hipLaunchKernelGGL(trsm_narrow_half_kernel, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
+    else
+        hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
