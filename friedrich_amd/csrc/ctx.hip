@@ -551,6 +551,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->bulk_xcd_tiles = value;
         return FR_OK;
     }
+    if (!strcmp(name, "narrow_pair_min")) {
+        if (value < -1) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow_pair_min must be >= -1");
+        ctx->narrow_pair_min = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "nb_switch_rows")) {
         if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "nb_switch_rows must be >= 0");
         ctx->nb_switch_rows = value;

@@ -111,35 +111,30 @@ __device__ __forceinline__ bool fetch_block(const TrsmnArgs& a, int blk, double*
     return true;
 }
 
-__device__ __forceinline__ void mma_half(const double (&buf)[16], const double* xs, int H, int l15, int lq, d4n_t& acc)
-{
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const double xf = xs[(64 * H + 4 * u + lq) * MR + l15];  // element (k = 64 H + 4 u + lq, q = l15)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, buf[u], acc, 0, 0, 0);
-    }
-}
-
 // The kernel for TWO OR MORE column groups (m > 16): half-tile register buffers, one LDS buffer -- 128 VGPRs and 16 KiB, so two
 // workgroups share a CU and the chains of different groups (each a sequence of dependent hand-offs, ~10 us apiece) run side
 // by side.  Measured against the kernel below on the same solves: 8 x add_samples(512) at 4096 .. 8192 rows 18.3 -> 14.9 ms,
 // sample_at(256) 4.0 -> 3.3 ms; with ONE group the deeper prefetch of the kernel below wins (predict of 16 points at
-// N = 32768: 4.7 vs 5.5 ms).
+// N = 32768: 4.7 vs 5.5 ms).  NQ = 2: a group is two MFMA tiles of 16 right-hand sides fed by the same factor fragments (half the
+// passes over the factor, half the workgroups); LDS rows are then padded by 16 doubles, so that the four k-rows a fragment
+// read touches start 32 banks apart.
+template <int NQ>
 __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArgs a0)
 {
-    __shared__ double xs[NB * MR];  // a solution block while it is multiplied; then t = b - sum for the closing product
+    constexpr int MRT = 16 * NQ, S = MRT + (NQ > 1 ? 16 : 0);
+    __shared__ double xs[NB * S];  // a solution block while it is multiplied; then t = b - sum for the closing product
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int last = a0.nblk - 1;
-    // column group: 16 right-hand sides with their own solution blocks and flags -- the groups are independent chains that
+    // column group: 16 NQ right-hand sides with their own solution blocks and flags -- the groups are independent chains that
     // stream the same tiles (served from L2 / Infinity Cache after the first reader)
     TrsmnArgs a = a0;
     {
         const int grp = blockIdx.y;
-        a.B += (int64_t)grp * MR * a.ldb;
-        a.m = a.m - grp * MR < MR ? a.m - grp * MR : MR;
-        a.xg += (int64_t)grp * a.nblk * (NB * MR);
+        a.B += (int64_t)grp * MRT * a.ldb;
+        a.m = a.m - grp * MRT < MRT ? a.m - grp * MRT : MRT;
+        a.xg += (int64_t)grp * a.nblk * (NB * MRT);
         a.flags += (int64_t)grp * a.nblk;
     }
 #pragma nounroll
@@ -148,11 +143,16 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArg
         const int cnt = a.bwd ? last - blk : blk;  // tiles; item q uses the solution block dep(q); item cnt: the inverse block
         const int64_t b0 = (int64_t)blk * NB;
         const int64_t row = b0 + 16 * w + l15;
-        // the accumulator starts at -b (this lane's right-hand side entries (row, q = lq + 4 i)): after the tiles it holds
-        // -(b - sum L x), and no copy of b lives across the loop
-        d4n_t acc;
+        // the accumulators start at -b (this lane's right-hand side entries (row, q = 16 j + lq + 4 i)): after the tiles they
+        // hold -(b - sum L x), and no copy of b lives across the loop
+        d4n_t acc[NQ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = (row < a.n && lq + 4 * i < a.m) ? -a.B[row + (int64_t)(lq + 4 * i) * a.ldb] : 0.0;
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 16 * j + lq + 4 * i;
+                acc[j][i] = (row < a.n && q < a.m) ? -a.B[row + (int64_t)q * a.ldb] : 0.0;
+            }
         double H0[16], H1[16];  // first / second half of the current item; the next half is always in flight
         load_half(item_frag(a, blk, a.bwd ? last : 0, cnt == 0), 0, w, l15, lq, H0);
 #pragma nounroll
@@ -160,31 +160,60 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArg
             const Frag f = item_frag(a, blk, a.bwd ? last - q : q, q >= cnt);
             load_half(f, 1, w, l15, lq, H1);
             if (q < cnt) {
-                if (!fetch_block(a, a.bwd ? last - q : q, xs, t)) return;
+                // solution block dep(q) -> xs; the barrier inside the wait also tells that every wave is done with the block before
+                const int dep = a.bwd ? last - q : q;
+                if (!handoff_wait_ge<false>(a.flags + dep, 1, a.status)) return;  // no acquire fence: sc1 stores, sc1 loads
+                const double* src = a.xg + (int64_t)dep * (NB * MRT);
+#pragma unroll
+                for (int i = 0; i < (NB * MRT) / NTH; ++i) {
+                    const int e = t + NTH * i;
+                    xs[(e / MRT) * S + (e % MRT)] = __hip_atomic_load((gdbl*)(src + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
             } else {
                 // t = b - sum = -acc, the [col][q] operand of the closing product with the inverse block (same buffer: every
                 // wave is done with the last solution block first)
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xs[(16 * w + l15) * MR + lq + 4 * i] = -acc[i];
-                acc = d4n_t{0.0, 0.0, 0.0, 0.0};
+                for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xs[(16 * w + l15) * S + 16 * j + lq + 4 * i] = -acc[j][i];
+                        acc[j][i] = 0.0;
+                    }
                 __syncthreads();
             }
-            mma_half(H0, xs, 0, l15, lq, acc);
-            if (q < cnt) load_half(item_frag(a, blk, a.bwd ? last - q - 1 : q + 1, q + 1 >= cnt), 0, w, l15, lq, H0);
-            mma_half(H1, xs, 1, l15, lq, acc);
+#pragma unroll
+            for (int H = 0; H < 2; ++H) {
+                if (H == 1 && q < cnt) load_half(item_frag(a, blk, a.bwd ? last - q - 1 : q + 1, q + 1 >= cnt), 0, w, l15, lq, H0);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const double xf = xs[(64 * H + 4 * u + lq) * S + 16 * j + l15];  // element (k = 64 H + 4 u + lq, q = 16 j + l15)
+                        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, H == 0 ? H0[u] : H1[u], acc[j], 0, 0, 0);
+                    }
+                }
+            }
         }
         // publish (write-through), then the caller's copy
-        double* dst = a.xg + (int64_t)blk * (NB * MR);
+        double* dst = a.xg + (int64_t)blk * (NB * MRT);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __hip_atomic_store((gdbl*)(dst + (16 * w + l15) * MR + lq + 4 * i), acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __hip_atomic_store((gdbl*)(dst + (16 * w + l15) * MRT + 16 * j + lq + 4 * i), acc[j][i], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) __hip_atomic_store((hgi32*)(a.flags + blk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (row < a.n && lq + 4 * i < a.m) a.B[row + (int64_t)(lq + 4 * i) * a.ldb] = acc[i];
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 16 * j + lq + 4 * i;
+                if (row < a.n && q < a.m) a.B[row + (int64_t)q * a.ldb] = acc[j][i];
+            }
         __syncthreads();  // xs is reused by the next block of this workgroup
     }
 }
@@ -327,12 +356,19 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     fr_chol* c = const_cast<fr_chol*>(cc);  // the transposed copy is a cache: logically const
     const int64_t n = c->n;
     if (n <= 0 || m <= 0) return FR_OK;
-    const int ngroups = (int)((m + MR - 1) / MR);
+    // right-hand sides per column group: 16; 32 (the half-tile kernel with two MFMA tiles per workgroup) from narrow_pair_min
+    // right-hand sides on
+    // (measured, scripts/narrow_pair_ab.py: pairs pay from 128 right-hand sides on against a factor of 16384+ rows -- n = 32768:
+    // m = 128 / 256 / 512 forward solve 8.1 / 14.7 / 27.8 -> 7.7 / 12.7 / 22.9 ms -- and cost up to 60 % on smaller solves)
+    const int64_t pair_min = ctx->narrow_pair_min >= 0 ? ctx->narrow_pair_min : (n >= 12288 ? 128 : 0);
+    const int nq = (pair_min > 0 && m >= pair_min) ? 2 : 1;
+    const int MRT = 16 * nq;
+    const int ngroups = (int)((m + MRT - 1) / MRT);
     if (ngroups > 65535) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow solve: too many right-hand sides");
     const int nblk = (int)((n + NB - 1) / NB);
     FR_TRY(ensure_status_word(ctx));
     if (!fwd) FR_TRY(ensure_transposed(ctx, c));
-    const size_t bytes = (sizeof(double) * (size_t)nblk * NB * MR + sizeof(int) * (size_t)nblk) * (size_t)ngroups + 64;
+    const size_t bytes = (sizeof(double) * (size_t)nblk * NB * MRT + sizeof(int) * (size_t)nblk) * (size_t)ngroups + 64;
     if (ctx->trsmn_buf_cap < bytes) {
         if (ctx->trsmn_buf) {
             (void)hipStreamSynchronize(ctx->stream);
@@ -352,7 +388,7 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     a.ldb = ldb;
     a.m = (int)m;
     a.xg = (double*)ctx->trsmn_buf;
-    a.flags = (int*)((char*)ctx->trsmn_buf + sizeof(double) * (size_t)nblk * NB * MR * (size_t)ngroups);
+    a.flags = (int*)((char*)ctx->trsmn_buf + sizeof(double) * (size_t)nblk * NB * MRT * (size_t)ngroups);
     a.ngroups = ngroups;
     a.status = ctx->dev_status;
     a.nblk = nblk;
@@ -360,8 +396,10 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     a.bwd = fwd ? 0 : 1;
     FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)nblk * (size_t)ngroups, ctx->ls));
     ProfScope ps(ctx, prof_cls, (double)n * (double)n * (double)m, 4.0 * (double)n * (double)n);
-    if (ngroups >= 2)
-        hipLaunchKernelGGL(trsm_narrow_half_kernel, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
+    if (nq == 2)
+        hipLaunchKernelGGL(trsm_narrow_half_kernel<2>, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
+    else if (ngroups >= 2)
+        hipLaunchKernelGGL(trsm_narrow_half_kernel<1>, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     else
         hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
