@@ -12,7 +12,8 @@
 // in it (and the transposed inverse blocks next to the inverse blocks), rebuilt lazily after the factor changed
 // (~2 ms at n = 32768).  With it "L^T x = b" reads rows-along-lanes exactly like "L x = b".
 //
-// Hand-off of a solution block (128 x 16 doubles): write-through (sc1) stores -> every wave drains -> barrier -> flag;
+// Hand-off of a solution block (128 x 16 doubles): write-through (sc1) stores -> every wave drains -> barrier -> flag
+// (tagged 8-byte granules as in trsv.hip, measured on this payload of 16 KiB: 2.43 -> 3.83 ms per direction at n = 32768);
 // the consumer polls the flag and reads the block with sc1 loads (cdna_hip_programming.md Guideline 16, R1).  Every
 // spin is bounded (handoff.hpp).
 #include "fr_internal.hpp"
