@@ -543,7 +543,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
     int st = FR_OK;
     const bool cp = world == 1 && ctx->panel_crit && ctx->stream4 && !ctx->refine_now && mode != 3 &&
                     !(fz && fz->on) && ctx->panel_fused == 0;
-    if (world == 1 && (ctx->xcd_reserve != 0 || ctx->xcd_reserve2 > 0) && ctx->claim_ring) {
+    if (world == 1 && (ctx->xcd_reserve != 0 || ctx->xcd_reserve2 > 0 || ctx->la_merge) && ctx->claim_ring) {
         // claim counters of the launches that keep off the panel stream's XCD (gemm_f64.hip): one pair per launch
         FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 2 * kClaimSlots, S0));
         ctx->claim_next = 0;
@@ -600,6 +600,37 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
             }
         }
         const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
+        // Merged variant (option la_merge): look-ahead update and trailing update are ONE lower-mode launch over all `rest`
+        // rows, its tiles claimed column by column so that the next panel's columns come first; those tiles count themselves
+        // done and the panel stream waits for the count instead of for a separate launch (gemm_f64.hip).
+        // (measured in one process, fit at N = 32768: 194.4 / 195.4 -> 192.4 / 192.3 ms; at N <= 16384, where the panel chain waits
+        // for these tiles, +1 ... +3 %: the count-and-wait hand-off is slower than the launch boundary it replaces -- so only
+        // while more than la_merge rows remain)
+        const bool merge = world == 1 && ctx->la_merge > 0 && rest > ctx->la_merge && ctx->claim_ring &&
+                           ctx->claim_next + 2 < kClaimSlots && !ctx->syrk_dynamic;
+        if (merge) {
+            unsigned* la_ctr = ctx->claim_ring + 2 * ctx->claim_next++;
+            GemmDesc g;
+            g.M = rest; g.N = rest; g.K = kb;
+            g.A = P; g.lda = ld; g.a_kmajor = false;
+            g.B = P; g.ldb = ld; g.b_kmajor = false;
+            g.D = A + (k + kb) + (k + kb) * ld; g.ldd = ld;
+            g.Cin = g.D; g.ldcin = ld;
+            g.alpha = -1.0; g.beta = 1.0; g.lower = true; g.prof_cls = FR_PROF_SYRK;
+            g.la_cols = kb2; g.la_ctr = la_ctr;
+            st = launch_gemm(ctx, g);
+            if (st != FR_OK) return fail(st);
+            const int64_t Tt = (rest + IB - 1) / IB, lat = (kb2 + IB - 1) / IB;
+            const int64_t target = lat * Tt - lat * (lat - 1) / 2;  // tiles of the first `lat` tile columns of the lower triangle
+            ctx->ls = S1;
+            st = launch_wait_counter(ctx, la_ctr, (unsigned)target);
+            if (st == FR_OK) st = factor_panel_la(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, fz, cp);
+            if (st == FR_OK && ctx->reserve_now) st = launch_release_xcds(ctx, ctx->panel_epoch);
+            if (st != FR_OK) return fail(st);
+            if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
+            ctx->ls = S0;
+            continue;
+        }
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
         if (own_next) {
             // (profile class: panel -- the SYRK class times exactly the syrk_lower_f64_kernel launches)

@@ -101,6 +101,7 @@ struct fr_ctx {
     int* step_flags = nullptr;     // device: the four slice flags of panel_step4_kernel (monotonic target step_epoch)
     int step_epoch = 0;
     int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0: never, -1: by size)
+    int64_t la_merge = 16384;      // look-ahead update and trailing update as ONE launch while more than this many rows remain (0: never)
     int64_t nb_switch_rows = 16384;  // automatic nb = 1024: panels of 512 columns once at most this many rows remain (0: never)
     int64_t panel_rl = 0;          // chain-bound panels: per-block right-looking schedule (chol.hip, factor_panel_rl)
     hipEvent_t ev_u = nullptr;
@@ -313,11 +314,16 @@ struct GemmDesc {
     // XCD reservation (while ctx->reserve_now): 0 = keep off the panel stream's XCD unless launched on the panel stream,
     // 2 = critical-path launch, ON the panel stream's XCD; 3 = bulk launch, on that XCD when it is small
     int place = 0;
+    // lower mode, merged look-ahead: the first la_cols columns are the next panel's; their tiles are computed first and counted
+    // on *la_ctr (device word, zero before the launch)
+    int64_t la_cols = 0;
+    unsigned* la_ctr = nullptr;
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 int launch_release_xcds(fr_ctx* ctx, unsigned epoch);  // on ctx->ls: the chain of panel `epoch` is finished
 int claim_setup(fr_ctx* ctx, int place, int64_t items, const unsigned** xcc_word, unsigned** claim, unsigned* max_exit,
-                int64_t* grid);
+                int64_t* grid, bool force = false);
+int launch_wait_counter(fr_ctx* ctx, const unsigned* ctr, unsigned target);  // on ctx->ls
 
 // K4: factor one diagonal block (nbk <= 128) and emit its explicit inverse (inv may be NULL).
 //   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows),

@@ -77,7 +77,17 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
             const int64_t q = nblk >> 3, r8 = nblk & 7;
             tlin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
         }
-        if (g.lower == 2) {
+        // merged look-ahead: the first la_tiles tile columns come first (column by column), then the triangle of the remaining
+        // rows and columns row by row, exactly as the separate trailing update would run
+        const int64_t n_la = g.la_tiles * g.tiles_m - g.la_tiles * (g.la_tiles - 1) / 2;
+        if (g.lower == 2 && g.la_tiles > 0 && tlin >= n_la) {
+            const int64_t tl2 = tlin - n_la;
+            int64_t row = (int64_t)((sqrt(8.0 * (double)tl2 + 1.0) - 1.0) * 0.5);
+            while (row * (row + 1) / 2 > tl2) --row;
+            while ((row + 1) * (row + 2) / 2 <= tl2) ++row;
+            tm = g.la_tiles + row;
+            tn = g.la_tiles + (tl2 - row * (row + 1) / 2);
+        } else if (g.lower == 2) {
             // lower triangle column by column (tm fastest), like the full mode: consecutive workgroups continue down the
             // same 128 columns of C (the next 1 KiB of every column) and share one B panel.  Column tn holds T - tn tiles.
             const int64_t T = g.tiles_m;
@@ -103,6 +113,16 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
     const int64_t m0 = tm * BM, n0 = tn * BN;
     if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) return;
     gemm_f64_tile<A_KMAJ, B_KMAJ, YIELD>(g, lds, m0, n0);
+    if (g.la_ctr && tn < g.la_tiles) {
+        // a tile of the next panel's columns: tell the panel stream (every wave drains its stores, then ONE release + count)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(g.la_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Two kernel symbols over the same body: the lower-mode launch is the trailing SYRK update of the factorisation (the
@@ -217,16 +237,48 @@ int launch_release_xcds(fr_ctx* ctx, unsigned epoch)
     return FR_OK;
 }
 
+// The panel stream's side of the merged look-ahead: one wave that returns when `target` tiles have counted themselves done.
+__global__ void wait_counter_kernel(const unsigned* ctr, unsigned target, unsigned* status)
+{
+    if (threadIdx.x != 0) return;
+    unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v < target) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(8);
+            v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v >= target) break;
+            if ((++spins & 63u) == 0) {
+                const bool dead = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                if (dead || wall_clock64() - t0 > 500000000ull) {  // 5 s of the 100 MHz clock
+                    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+int launch_wait_counter(fr_ctx* ctx, const unsigned* ctr, unsigned target)
+{
+    FR_TRY(ensure_status_word(ctx));
+    hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, ctx->ls, ctr, target, ctx->dev_status);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
 // Host side of claim_item (gemm_tile.hpp): a counter pair from the factorisation's ring for one launch that keeps off (1) /
 // runs on (3) the panel stream's XCD.  Returns the placement to use (0: launch plainly) and the grid size.
 int claim_setup(fr_ctx* ctx, int place, int64_t items, const unsigned** xcc_word, unsigned** claim, unsigned* max_exit,
-                int64_t* grid)
+                int64_t* grid, bool force)
 {
     *xcc_word = nullptr;
     *claim = nullptr;
     *max_exit = 0;
     *grid = items;
-    if (!ctx->reserve_now || ctx->ls == ctx->stream2 || !ctx->claim_ring || ctx->claim_next >= kClaimSlots) return 0;
+    if ((!ctx->reserve_now && !force) || ctx->ls == ctx->stream2 || !ctx->claim_ring || ctx->claim_next >= kClaimSlots) return 0;
     *xcc_word = ctx->yield_word + 4;
     *claim = ctx->claim_ring + 2 * ctx->claim_next++;
     const int64_t R = ctx->reserve_now;
@@ -335,15 +387,24 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.max_exit = 0;
     g.nres = ctx->reserve_now;
     g.epoch = ctx->panel_epoch;
-    if (ctx->reserve_now && d.batch <= 1 && !ctx->syrk_dynamic && d.own_world <= 1) {
+    g.la_tiles = 0;
+    g.la_ctr = nullptr;
+    const bool merged = d.la_cols > 0 && d.lower && d.la_ctr;
+    if ((ctx->reserve_now || merged) && d.batch <= 1 && !ctx->syrk_dynamic && d.own_world <= 1) {
         if (ctx->ls == ctx->stream2) {
             if (!d.lower) g.place = 2;
         } else {
             int64_t grid = 0;
             g.place = claim_setup(ctx, (d.place == 5 && !d.lower) ? 5 : ((d.place == 3 && !d.lower && ntiles <= ctx->bulk_xcd_tiles) ? 3 : 1), ntiles, &g.xcc_word,
-                                  &g.claim, &g.max_exit, &grid);
+                                  &g.claim, &g.max_exit, &grid, merged);
         }
         if (g.place) use_super = false;
+    }
+    if (merged) {
+        if (g.place != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "merged look-ahead update needs a claim slot");
+        g.lower = 2;  // column by column: the claimed order starts with the next panel's columns
+        g.la_tiles = (d.la_cols + BN - 1) / BN;
+        g.la_ctr = d.la_ctr;
     }
     if (use_super)
         ntiles = g.per_xcd * 8 * 64;

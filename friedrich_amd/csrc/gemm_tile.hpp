@@ -46,6 +46,10 @@ struct GemmArgs {
     const unsigned* xcc_word;  // 1 + XCC_ID of the XCD the diagonal-block kernels run on (0: not known yet)
     unsigned* claim;
     unsigned max_exit;
+    // merged look-ahead (lower mode, column-major claimed order): the tiles of the first la_tiles tile columns count
+    // themselves done on *la_ctr (release), the panel stream waits for all of them (wait_counter_kernel)
+    int64_t la_tiles;
+    unsigned* la_ctr;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile
