@@ -1046,6 +1046,7 @@ static int merge_info(fr_chol* c)
     std::vector<int64_t> host((size_t)(len * W));
     FR_HIP(ctx, hipMemcpyAsync(host.data(), all, sizeof(int64_t) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FR_TRY(check_status_word(ctx));  // a bounded device-side wait of the factorisation (hand-offs, counted tiles) gave up
     int64_t fail = -1;
     std::vector<int64_t> subst;
     for (int r = 0; r < W; ++r) {
