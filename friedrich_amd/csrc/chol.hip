@@ -1016,6 +1016,7 @@ int chol_fetch_info(fr_chol* c)
     int64_t head[3] = {0, 0, 0};
     FR_HIP(ctx, hipMemcpyAsync(head, c->info, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FR_TRY(check_status_word(ctx));  // a bounded device-side wait of the factorisation (hand-offs, counted tiles) gave up
     c->fail_col = head[0] - 1;
     c->n_subst = head[1];
     if (c->n_subst < 0 || c->n_subst > c->n) {
