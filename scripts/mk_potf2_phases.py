@@ -1,22 +1,32 @@
 """Developer tool: per-phase s_memtime instrumentation of the diagonal-block kernel (writes scripts/potf2_bench_phases.hip).
 Wave 0 stamps: start | block loaded | after each F_b | after each stage's last barrier | inverse stored."""
 src = open('friedrich_amd/csrc/potf2.hip').read()
-kern = src[src.index("constexpr int PB = 128;"):src.index("int launch_potf2(")]
-kern = kern.replace("int64_t* __restrict__ info)\n{\n    extern __shared__", "int64_t* __restrict__ info, long long* ts)\n{\n    if (threadIdx.x == 0) ts[0] = __builtin_amdgcn_s_memtime();\n    extern __shared__")
-kern = kern.replace("    if (w == 0) {\n        for (int b = 0; b < nblk; ++b) {", "    if (w == 0) {\n        if (lane == 0) ts[1] = __builtin_amdgcn_s_memtime();\n        for (int b = 0; b < nblk; ++b) {")
-four = "            lds_barrier();\n            lds_barrier();\n            lds_barrier();\n"
-assert kern.count(four) == 1
-kern = kern.replace(four, "            if (lane == 0) ts[2 + 2 * b] = __builtin_amdgcn_s_memtime();\n" + four + "            if (lane == 0) ts[3 + 2 * b] = __builtin_amdgcn_s_memtime();\n")
-# update-wave stamps: after each of the 4 barriers of a stage (8-space indent inside the update branch)
+kern = src[src.index("constexpr int PB = 128;"):src.index("// ---- the diagonal-block SERVER")]
+# potf2_block: one more argument, stamps by wave 0 and by update wave 0
+kern = kern.replace("int64_t* __restrict__ info, double* __restrict__ cest = nullptr)\n{",
+                    "int64_t* __restrict__ info, double* __restrict__ cest = nullptr, long long* ts = nullptr)\n{\n    if (ts && threadIdx.x == 0) ts[0] = __builtin_amdgcn_s_memtime();", 1)
+assert "long long* ts = nullptr" in kern
+k0 = "    if (w == 0) {\n"
+assert kern.count(k0) == 1
+kern = kern.replace(k0, k0 + "        if (ts && lane == 0) ts[1] = __builtin_amdgcn_s_memtime();\n", 1)
+three = "            lds_barrier();\n            lds_barrier();\n            lds_barrier();\n"
+assert kern.count(three) == 1
+kern = kern.replace(three, "            if (ts && lane == 0) ts[2 + 2 * b] = __builtin_amdgcn_s_memtime();\n" + three +
+                    "            if (ts && lane == 0) ts[3 + 2 * b] = __builtin_amdgcn_s_memtime();\n")
+# update-wave stamps: after each of the 3 barriers of a stage (8-space indent inside the update branch, before the inverse's store)
 head, tail = kern.split("    const int u = w - 1;\n", 1)
-parts = tail.split("        lds_barrier();\n")
+body, rest = tail.split("    // ---- store the inverse", 1)
+parts = body.split("        lds_barrier();\n")
 assert len(parts) == 4, len(parts)
-tail = parts[0]
+body = parts[0]
 for idx in range(3):
-    tail += "        lds_barrier();\n        if (w == 1 && lane == 0) ts[16 + 8 * b + %d] = __builtin_amdgcn_s_memtime();\n" % idx + parts[idx + 1]
-kern = head + "    const int u = w - 1;\n" + tail
-i = kern.rindex("}")
-kern = kern[:i] + "    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n}\n"
+    body += "        lds_barrier();\n        if (ts && w == 1 && lane == 0) ts[16 + 8 * b + %d] = __builtin_amdgcn_s_memtime();\n" % idx + parts[idx + 1]
+kern = head + "    const int u = w - 1;\n" + body + "    // ---- store the inverse" + rest
+# the kernel wrapper passes the stamp buffer on and stamps the end
+kern = kern.replace("unsigned* __restrict__ yield_word, unsigned* __restrict__ xcc_word)\n{", "unsigned* __restrict__ yield_word, unsigned* __restrict__ xcc_word, long long* ts)\n{", 1)
+call = "    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);\n"
+assert kern.count(call) == 1
+kern = kern.replace(call, "    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest, ts);\n    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n", 1)
 prog = '''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -24,6 +34,8 @@ prog = '''#include <hip/hip_runtime.h>
 #include <cmath>
 #include <unistd.h>
 #include "friedrich_amd.h"
+#include "fr_internal.hpp"
+#include "handoff.hpp"
 namespace fr {
 ''' + kern + '''}
 int main(int argc, char** argv){
@@ -42,10 +54,10 @@ int main(int argc, char** argv){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
     if (noise) { for (int g = 0; g < 6; ++g) fr_gemm(ctx, 0, 1, NM, NM, NK, -1.0, NA, NM, NA, NM, 1.0, NC, NM); usleep(6000); }
     hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,hs);
-    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,ts); (void)hipEventRecord(e1,hs); (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,(double*)nullptr,(unsigned*)nullptr,(unsigned*)nullptr,ts); (void)hipEventRecord(e1,hs); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms,e0,e1);
     long long t[64]; (void)hipMemcpy(t,ts,8*64,hipMemcpyDeviceToHost);
-    if (rep==2) { printf("event %.1f us; ticks (10 ns): load %lld", ms*1e3, t[1]-t[0]);
+    if (rep==2) { printf("event %.1f us; shader-clock cycles: load %lld", ms*1e3, t[1]-t[0]);
       long long prev=t[1]; for(int b=0;b<4;++b){ printf(" | F%d %lld upd %lld", b, t[2+2*b]-prev, t[3+2*b]-t[2+2*b]); prev=t[3+2*b]; }
       printf(" | store %lld | total %lld\\n", t[10]-prev, t[10]-t[0]);
       for(int b=0;b<4;++b){ printf("  stage %d (update wave 0): P2 products %lld | P3 %lld\\n", b, t[16+8*b+1]-t[16+8*b], t[16+8*b+2]-t[16+8*b+1]); } }
