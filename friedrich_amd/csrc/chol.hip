@@ -606,7 +606,9 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         // (measured in one process, fit at N = 32768: 194.4 / 195.4 -> 192.4 / 192.3 ms; at N <= 16384, where the panel chain waits
         // for these tiles, +1 ... +3 %: the count-and-wait hand-off is slower than the launch boundary it replaces -- so only
         // while more than la_merge rows remain)
-        const bool merge = world == 1 && ctx->la_merge > 0 && rest > ctx->la_merge && ctx->claim_ring &&
+        // ... and no more than la_merge_max: above ~40000 rows the claimed tile order costs the trailing update more than the
+        // launch it saves (N = 40960 / 49152 / 65536 with the merge at every size: -0.4 / +0.6 / +1.1 %)
+        const bool merge = world == 1 && ctx->la_merge > 0 && rest > ctx->la_merge && rest <= ctx->la_merge_max && ctx->claim_ring &&
                            ctx->claim_next + 2 < kClaimSlots && !ctx->syrk_dynamic;
         if (merge) {
             unsigned* la_ctr = ctx->claim_ring + 2 * ctx->claim_next++;
