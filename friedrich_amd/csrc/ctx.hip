@@ -556,6 +556,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->narrow_pair_min = value;
         return FR_OK;
     }
+    if (!strcmp(name, "la_merge_claimed")) {
+        ctx->la_merge_claimed = value != 0;
+        return FR_OK;
+    }
     if (!strcmp(name, "la_merge_max")) {
         if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "la_merge_max must be >= 0");
         ctx->la_merge_max = value;

@@ -102,6 +102,8 @@ struct fr_ctx {
     int step_epoch = 0;
     int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0: never, -1: by size)
     int64_t la_merge_max = 36864;
+    int64_t la_merge_claimed = 1;  // merged launches claim their tiles (0: static order, next panel's tiles first, then per-XCD runs:
+                                   // measured neutral at every size, the claimed order -0.6 ... -0.8 % at N = 24576 ... 32768)
     int64_t la_merge = 16384;      // look-ahead update and trailing update as ONE launch while more than this many rows remain (0: never)
     int64_t nb_switch_rows = 16384;  // automatic nb = 1024: panels of 512 columns once at most this many rows remain (0: never)
     int64_t panel_rl = 0;          // chain-bound panels: per-block right-looking schedule (chol.hip, factor_panel_rl)

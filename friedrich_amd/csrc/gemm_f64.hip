@@ -72,6 +72,21 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
         } else if (g.place == 1 || g.place == 3 || g.place == 5) {
             tlin = claim_item(g.place, g.nres, g.epoch, g.xcc_word, g.claim, g.max_exit, g.ntiles);  // gemm_tile.hpp
             if (tlin < 0) return;
+        } else if (g.lower == 2 && g.la_tiles > 0) {
+            // merged look-ahead, static order: the next panel's tiles first, dealt one by one over the XCDs (workgroups
+            // [0, LA8)), then the remaining triangle in the plain order's per-XCD runs (a pure function of blockIdx.x)
+            const int64_t n_la0 = g.la_tiles * g.tiles_m - g.la_tiles * (g.la_tiles - 1) / 2;
+            const int64_t LA8 = (n_la0 + 7) & ~(int64_t)7;
+            if (b < LA8) {
+                if (b >= n_la0) return;
+                tlin = b;
+            } else {
+                const int64_t nblk = g.ntiles - n_la0;
+                const int64_t q = nblk >> 3, r8 = nblk & 7;
+                const int64_t slot = (b - LA8) >> 3;
+                if (slot >= q + (xcd < r8 ? 1 : 0)) return;
+                tlin = n_la0 + (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+            }
         } else {
             const int64_t nblk = gridDim.x;
             const int64_t q = nblk >> 3, r8 = nblk & 7;
@@ -390,7 +405,8 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.la_tiles = 0;
     g.la_ctr = nullptr;
     const bool merged = d.la_cols > 0 && d.lower && d.la_ctr;
-    if ((ctx->reserve_now || merged) && d.batch <= 1 && !ctx->syrk_dynamic && d.own_world <= 1) {
+    const bool merged_static = merged && !ctx->reserve_now && ctx->la_merge_claimed == 0;
+    if ((ctx->reserve_now || (merged && !merged_static)) && d.batch <= 1 && !ctx->syrk_dynamic && d.own_world <= 1) {
         if (ctx->ls == ctx->stream2) {
             if (!d.lower) g.place = 2;
         } else {
@@ -401,15 +417,21 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         if (g.place) use_super = false;
     }
     if (merged) {
-        if (g.place != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "merged look-ahead update needs a claim slot");
-        g.lower = 2;  // column by column: the claimed order starts with the next panel's columns
+        if (!merged_static && g.place != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "merged look-ahead update needs a claim slot");
+        g.lower = 2;  // the order (claimed, or static: see the kernel) starts with the next panel's columns
         g.la_tiles = (d.la_cols + BN - 1) / BN;
         g.la_ctr = d.la_ctr;
+        use_super = false;
     }
     if (use_super)
         ntiles = g.per_xcd * 8 * 64;
     else
         g.nsuper = 0;
+    if (merged_static) {
+        const int64_t n_la0 = g.la_tiles * g.tiles_m - g.la_tiles * (g.la_tiles - 1) / 2;
+        const int64_t rest_tiles = g.ntiles - n_la0;
+        ntiles = ((n_la0 + 7) & ~(int64_t)7) + 8 * ((rest_tiles + 7) / 8);
+    }
     if (g.place == 2) ntiles = 8 * ((g.ntiles + g.nres - 1) / g.nres);
     if (g.place == 1 || g.place == 3 || g.place == 5) ntiles = g.ntiles + g.max_exit;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
