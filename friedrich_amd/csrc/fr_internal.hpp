@@ -104,7 +104,10 @@ struct fr_ctx {
     int64_t la_merge_max = 36864;
     int64_t la_merge_claimed = 1;  // merged launches claim their tiles (0: static order, next panel's tiles first, then per-XCD runs:
                                    // measured neutral at every size, the claimed order -0.6 ... -0.8 % at N = 24576 ... 32768)
-    int64_t la_merge = 16384;      // look-ahead update and trailing update as ONE launch while more than this many rows remain (0: never)
+    int64_t la_merge = 0;          // > 0: look-ahead update and trailing update as ONE launch while more than this many rows remain.
+                                   // OFF by default: the panel stream then WAITS IN A KERNEL for tiles of a concurrently running launch, which
+                                   // never arrives when a tool serialises kernel execution (rocprofv3 --pmc does: the wait times out, the
+                                   // fit reports FR_HIP_ERROR) -- not worth the 0.6 ... 1.3 % it gains at N = 24576 ... 32768
     int64_t nb_switch_rows = 16384;  // automatic nb = 1024: panels of 512 columns once at most this many rows remain (0: never)
     int64_t panel_rl = 0;          // chain-bound panels: per-block right-looking schedule (chol.hip, factor_panel_rl)
     hipEvent_t ev_u = nullptr;

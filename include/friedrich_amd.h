@@ -111,8 +111,10 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "xcd_reserve"   -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
  *                   the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, nb <= 512 only: DESIGN.md
  *                   section 5); 0: never; 1..4 with "xcd_reserve_rest" / "xcd_reserve2" / "xcd_reserve_rest2": explicit tiers
- *   "la_merge"      16384 (default): while more than this many rows (and at most "la_merge_max", 36864) remain, look-ahead update and trailing update of a
- *                   single-GPU factorisation are one launch (the next panel's tiles first, counted; 0: always separate)
+ *   "la_merge"      0 (default: off); e.g. 16384: while more than this many rows (and at most "la_merge_max", 36864) remain,
+ *                   look-ahead update and trailing update of a single-GPU factorisation are one launch (the next panel's
+ *                   tiles first, counted; -0.6 ... -1.3 % at N = 24576 ... 32768).  Needs kernels of two streams to run
+ *                   concurrently: under tools that serialise kernel execution (rocprofv3 --pmc) its in-kernel wait times out
  *   developer probes kept behind options (measured, not adopted): "panel_fused", "panel_crit",
  *   "panel_rl", "syrk_dynamic", "k4_yield", "panel_split" (multi-GPU: section 6) */
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);

@@ -554,7 +554,7 @@ def test_refinement_policy_and_forced_modes(ctx):
 
 
 @pytest.mark.parametrize("opt,val", [("panel_fused", 1), ("panel_fused", 2), ("panel_fused", 3), ("panel_fused", 4), ("syrk_dynamic", 1),
-                                     ("k4_yield", 1), ("lookahead", 0), ("nb", 1024), ("la_merge", 1), ("la_merge", 0)])
+                                     ("k4_yield", 1), ("lookahead", 0), ("nb", 1024), ("la_merge", 1)])
 def test_probe_options_keep_the_factor(ctx, opt, val):
     """The design probes kept behind options (resident diagonal-block server, fused row-tile panel
     kernel, rest kernel, dynamically pulled trailing update, cooperative yield) stay correct: the oracle's factor, the same
@@ -577,7 +577,7 @@ def test_probe_options_keep_the_factor(ctx, opt, val):
             est = chol.conditioning()
             assert est[1] == est_d[1] and abs(est[0] / est_d[0] - 1.0) < 1e-9
     finally:
-        ctx.set_option(opt, {"lookahead": 1, "la_merge": 16384}.get(opt, 0))
+        ctx.set_option(opt, 1 if opt == "lookahead" else 0)
         ctx.set_option("nb_switch_rows", 16384)
     chol.free()
 
