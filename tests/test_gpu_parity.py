@@ -553,6 +553,32 @@ def test_refinement_policy_and_forced_modes(ctx):
     assert rel_err(Ls[0], Ls[2]) < 1e-13 and np.array_equal(Ls[0], Ls[1])
 
 
+def test_degenerate_sizes(ctx):
+    """One training row, one query, no query at all, a row-append of zero rows, a single right-hand side of length 1: the
+    launches that would be empty are skipped, the answers are the oracle's (mod.rs:234-241, 260-263; algebra/mod.rs:97-126)."""
+    k = PD_KERNELS[0]
+    X = rand_inputs(3, 2, 11)
+    y = np.array([0.3, -1.2, 0.8])
+    for n in (1, 2, 3):
+        st, L_o, _ = O.make_cholesky_cov_matrix(k, X[:n], 0.2)
+        chol = ctx.cholesky_from_inputs(k, np.asfortranarray(X[:n]), 0.2, capacity_hint=4)
+        assert rel_err(chol.l(), np.tril(L_o)) < TOL
+        Xq = rand_inputs(2, 2, 12)
+        gp = O.OracleGP(O.ConstantPrior(0.0), k, 0.2, None, X[:n], y[:n])
+        assert rel_err(chol.predict_mean(k, y[:n], Xq), gp.predict(Xq)) < TOL
+        assert rel_err(chol.predict_variance(k, Xq[:1]), gp.predict_variance(Xq[:1])) < TOL
+        assert chol.predict_mean(k, y[:n], Xq[:0]).shape == (0,) and chol.predict_variance(k, Xq[:0]).shape == (0,)
+        chol.add_rows(k, np.asfortranarray(X[:n]), 0, 0.2)  # nothing to add
+        assert chol.info()["n"] == n and rel_err(chol.l(), np.tril(L_o)) < TOL
+        b = np.asfortranarray(np.arange(1.0, n + 1.0).reshape(n, 1))
+        assert rel_err(chol.solve(b), O.chol_solve(L_o, b)) < TOL
+        if n < 3:
+            chol.add_rows(k, np.asfortranarray(X[:n + 1]), 1, 0.2)
+            st2, L2, _ = O.make_cholesky_cov_matrix(k, X[:n + 1], 0.2)
+            assert rel_err(chol.l(), np.tril(L2)) < TOL
+        chol.free()
+
+
 @pytest.mark.parametrize("opt,val", [("panel_fused", 1), ("panel_fused", 2), ("panel_fused", 3), ("panel_fused", 4), ("syrk_dynamic", 1),
                                      ("k4_yield", 1), ("lookahead", 0), ("nb", 1024), ("la_merge", 1)])
 def test_probe_options_keep_the_factor(ctx, opt, val):
