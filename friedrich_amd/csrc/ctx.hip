@@ -560,6 +560,18 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->la_merge_claimed = value != 0;
         return FR_OK;
     }
+    if (!strcmp(name, "splitk_tiles")) {
+        ctx->splitk_tiles = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "splitk_mink")) {
+        ctx->splitk_mink = value < 256 ? 256 : value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "splitk_target")) {
+        ctx->splitk_target = value < 1 ? 1 : value;
+        return FR_OK;
+    }
     if (!strcmp(name, "la_merge_max")) {
         if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "la_merge_max must be >= 0");
         ctx->la_merge_max = value;

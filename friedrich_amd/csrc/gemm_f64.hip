@@ -304,17 +304,18 @@ int claim_setup(fr_ctx* ctx, int place, int64_t items, const unsigned** xcc_word
     return place;
 }
 
-// Few result tiles and a deep contraction (a 512-row block against 8192 columns: add_rows, narrow predicts): one tile's
-// K-loop is then the whole run time while most CUs idle.  The contraction is cut into slices computed as one batched
+// Few result tiles and a deep contraction (a 512-row block against 8192 columns: add_rows, narrow predicts; the lower levels
+// of the recursive wide solves): one tile's K-loop is then the whole run time while most CUs idle.  The contraction is cut into slices computed as one batched
 // launch into a workspace, and a second small kernel adds them up (fixed order).  Main stream only (the workspace pool
 // relies on stream order), single GPU ownership only.
 int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
 {
     if (d.M <= 0 || d.N <= 0) return FR_OK;
     const int64_t tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    if (d.batch <= 1 && d.own_world <= 1 && ctx->ls == ctx->stream && ctx->splitk != 0 && tiles <= 192 && d.K >= 2048 &&
+    if (d.batch <= 1 && d.own_world <= 1 && !d.la_ctr && ctx->ls == ctx->stream && ctx->splitk != 0 && tiles <= ctx->splitk_tiles &&
+        d.K >= ctx->splitk_mink &&
         d.M <= 65535 * 256) {
-        int64_t S = (384 + tiles - 1) / tiles;
+        int64_t S = (ctx->splitk_target + tiles - 1) / tiles;
         if (S > d.K / 256) S = d.K / 256;
         if (S > 32) S = 32;
         while (S > 1 && (d.K % S != 0 || (d.K / S) % BK != 0)) --S;
