@@ -560,6 +560,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->la_merge_claimed = value != 0;
         return FR_OK;
     }
+    if (!strcmp(name, "splitk_slice")) {
+        ctx->splitk_slice = value < 64 ? 64 : value;
+        return FR_OK;
+    }
     if (!strcmp(name, "splitk_tiles")) {
         ctx->splitk_tiles = value;
         return FR_OK;

@@ -105,7 +105,7 @@ struct fr_ctx {
     // splitk_mink are cut into ~splitk_target / tiles slices.  Round 1 used 192 / 2048 / 384; measured with 256 / 512 / 512
     // (scripts/splitk_ab.py): forward solve of 512 / 1024 / 2048 / 4096 columns at n = 32768: 18.7 / 26.6 / 41.6 / 70.6 ->
     // 14.0 / 22.1 / 37.6 / 68.3 ms, 1024 columns at n = 8192: 3.45 -> 2.48 ms, fits -1 %
-    int64_t splitk_tiles = 256, splitk_mink = 512, splitk_target = 512;
+    int64_t splitk_tiles = 256, splitk_mink = 512, splitk_target = 512, splitk_slice = 128;  // (slices of 128: another -8 ... -13 % on 512 ... 1024 columns)
     int64_t la_merge_max = 36864;
     int64_t la_merge_claimed = 1;  // merged launches claim their tiles (0: static order, next panel's tiles first, then per-XCD runs:
                                    // measured neutral at every size, the claimed order -0.6 ... -0.8 % at N = 24576 ... 32768)

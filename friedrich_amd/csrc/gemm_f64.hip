@@ -316,7 +316,7 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
         d.K >= ctx->splitk_mink &&
         d.M <= 65535 * 256) {
         int64_t S = (ctx->splitk_target + tiles - 1) / tiles;
-        if (S > d.K / 256) S = d.K / 256;
+        if (S > d.K / ctx->splitk_slice) S = d.K / ctx->splitk_slice;
         if (S > 32) S = 32;
         while (S > 1 && (d.K % S != 0 || (d.K / S) % BK != 0)) --S;
         if (S > 1) {
