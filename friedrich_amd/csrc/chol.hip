@@ -890,9 +890,10 @@ static bool use_column_groups(const fr_ctx* ctx, const fr_chol* c, int64_t n, in
     if (n != c->n || !ctx->trsv || m < 2) return false;
     if (m <= 16) return m <= ctx->narrow_max;
     if (ctx->narrow_batched_max >= 0) return m <= ctx->narrow_batched_max;  // explicit setting
-    // measured (scripts/narrow_batched_ab.py, narrow_pair_ab.py), forward solve at n = 8192 / 32768: m = 256: 1.4 / 12.7 ms in
-    // column groups against 2.8 / 14.5 ms on the GEMM path; m = 512: 2.3 / 22.9 against 3.0 / 18.7
-    return m <= 256 || (m <= 512 && n <= 8192);
+    // measured (scripts/narrow_batched_ab.py) after the split-K rule let the GEMM path's lower levels fill the chip: the column
+    // groups win up to m = 256 / 192 / 96 / 64 columns at n = 4096 / 8192 / 16384 / 32768 (e.g. n = 32768: m = 64 4.9 vs 6.4 ms,
+    // m = 128 7.7 vs 6.0 ms), i.e. while m n stays below about two million
+    return m <= 256 && m * n <= 2200000;
 }
 
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)

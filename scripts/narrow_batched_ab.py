@@ -6,14 +6,14 @@ sys.path.insert(0, ".")
 from friedrich_amd import synth
 from friedrich_amd.device import Context
 ctx = Context()
-for n in (8192, 32768):
+for n in (4096, 8192, 16384, 32768):
     d = 16
     X, y, Xq = synth.make_problem(n, d, cfg=4, m=1024)
     ls = ctx.mean_pairwise_distance(X)
     hp = synth.default_hyperparameters(X, y, ls)
     k = ("squared_exp", hp["ls"], hp["ampl"])
     chol = ctx.cholesky_from_inputs(k, X, hp["noise"], capacity_hint=n)
-    for m in (32, 64, 128, 256, 512):
+    for m in (32, 64, 96, 128, 192, 256, 384, 512):
         q = np.asfortranarray(Xq[:m])
         res = []
         for thr in (0, 1024):
