@@ -918,6 +918,56 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
     return trsm_fwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
 }
 
+// ---- W = L^-1 for the gradient of the marginal likelihood (K^-1 = W^T W, grad.hip) -------------------------------------------
+// The forward solve of the identity spends n^3 flops, two thirds of them on the structural zeros of W.  Recursively,
+//   L = [L11 0; L21 L22]  ->  W = [W11 0; -W22 (L21 W11) W22],
+// and the two products skip the zero halves of their triangular operand tile by tile (GemmArgs::tri): n^3 / 3 in all.
+// Below TRINV_BASE rows a block is inverted by the ordinary solve of its identity (512-row leaves and all).
+constexpr int64_t TRINV_BASE = 2048;
+
+static int trinv_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* W, int64_t ldw, double* T, double* tmp, int cls)
+{
+    if (n <= TRINV_BASE) {
+        FR_TRY(launch_set_identity(ctx, W, n, ldw));
+        return trsm_fwd_rec(ctx, c, row0, n, W, n, ldw, cls, tmp);
+    }
+    const int64_t n1 = (((n + LB - 1) / LB) / 2) * LB, n2 = n - n1;
+    FR_TRY(trinv_rec(ctx, c, row0, n1, W, ldw, T, tmp, cls));
+    FR_TRY(trinv_rec(ctx, c, row0 + n1, n2, W + n1 + n1 * ldw, ldw, T, tmp, cls));
+    const int64_t ldt = round_up(n2, kAlign);
+    GemmDesc g;
+    // T = L21 W11: W11 (k, n) is zero for k < n
+    g.M = n2; g.N = n1; g.K = n1;
+    g.A = c->A + (row0 + n1) + row0 * c->ld_a; g.lda = c->ld_a; g.a_kmajor = false;
+    g.B = W; g.ldb = ldw; g.b_kmajor = true;
+    g.Cin = T; g.ldcin = ldt; g.D = T; g.ldd = ldt;
+    g.alpha = 1.0; g.beta = 0.0; g.lower = false; g.prof_cls = cls; g.tri = 2; g.dynamic = true;
+    FR_TRY(launch_gemm(ctx, g));
+    // W21 = -W22 T: W22 (m, k) is zero for k > m
+    g.M = n2; g.N = n1; g.K = n2;
+    g.A = W + n1 + n1 * ldw; g.lda = ldw; g.a_kmajor = false;
+    g.B = T; g.ldb = ldt; g.b_kmajor = true;
+    g.Cin = W + n1; g.ldcin = ldw; g.D = W + n1; g.ldd = ldw;
+    g.alpha = -1.0; g.beta = 0.0; g.tri = 4;
+    return launch_gemm(ctx, g);
+}
+
+int chol_tri_inverse(fr_ctx* ctx, const fr_chol* c, double* W, int64_t ldw, double* T, int cls)
+{
+    const int64_t n = c->n;
+    if (n <= 0) return FR_OK;
+    if (c->refine || n <= TRINV_BASE || !ctx->tri_inverse) {  // (ill-conditioned handles keep the refined solve of the whole identity)
+        FR_TRY(launch_set_identity(ctx, W, n, ldw));
+        return trsm_lower_fwd(ctx, c, n, W, n, ldw, cls);
+    }
+    FR_HIP(ctx, hipMemsetAsync(W, 0, sizeof(double) * (size_t)ldw * (size_t)n, ctx->ls));
+    FR_TRY(ensure_inv512(ctx, c, cls));
+    WsGuard w(ctx);
+    double* tmp = w.get(sizeof(double) * (size_t)LB * (size_t)TRINV_BASE);
+    if (!tmp) return FR_OUT_OF_MEMORY;
+    return trinv_rec(ctx, c, 0, n, W, ldw, T, tmp, cls);
+}
+
 int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)
 {
     if (n <= 0 || m <= 0) return FR_OK;

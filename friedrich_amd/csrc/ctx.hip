@@ -352,6 +352,7 @@ int fr_ctx_create(fr_ctx** out, int device)
     }
     if (hipMalloc((void**)&ctx->yield_word, 64) != hipSuccess || hipMemset(ctx->yield_word, 0, 64) != hipSuccess ||
         hipMalloc((void**)&ctx->claim_ring, sizeof(unsigned) * 2 * kClaimSlots) != hipSuccess ||
+        hipMalloc((void**)&ctx->dyn_ring, sizeof(unsigned) * 2 * 256) != hipSuccess ||
         hipMalloc((void**)&ctx->step_flags, 64) != hipSuccess || hipMemset(ctx->step_flags, 0, 64) != hipSuccess) {
         fr_ctx_destroy(ctx);
         return FR_HIP_ERROR;
@@ -389,6 +390,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (ctx->ev_u) (void)hipEventDestroy(ctx->ev_u);
     if (ctx->claim_ring) (void)hipFree(ctx->claim_ring);
     if (ctx->step_flags) (void)hipFree(ctx->step_flags);
+    if (ctx->dyn_ring) (void)hipFree(ctx->dyn_ring);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
         (void)hipStreamDestroy(ctx->stream3);
@@ -574,6 +576,10 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     }
     if (!strcmp(name, "splitk_target")) {
         ctx->splitk_target = value < 1 ? 1 : value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "tri_inverse")) {
+        ctx->tri_inverse = value != 0;
         return FR_OK;
     }
     if (!strcmp(name, "la_merge_max")) {

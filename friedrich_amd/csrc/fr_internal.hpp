@@ -95,6 +95,9 @@ struct fr_ctx {
     int64_t xcd_reserve2 = 0, xcd_reserve_rest2 = 0;  // second tier: this many XCDs once the trailing matrix is this small
     int reserve_now = 0;           // XCDs reserved right now (set by the factorisation around the launches it applies to)
     unsigned panel_epoch = 0;      // number of the panel being factored on the panel stream (see claim_item)
+    int64_t tri_inverse = 1;       // gradient terms: L^-1 and W^T W skip the structural zeros (chol_tri_inverse); 0: dense products
+    unsigned* dyn_ring = nullptr;    // device: counter pairs of `dynamic` launches outside a factorisation, zeroed one by one
+    int64_t dyn_next = 0;
     unsigned* claim_ring = nullptr;  // device: {tile counter, retire counter} per reserved launch of a factorisation
     int64_t claim_next = 0;
     int64_t bulk_xcd_tiles = 0;    // bulk launches of at most this many tiles run ON the reserved XCD
@@ -329,6 +332,10 @@ struct GemmDesc {
     // on *la_ctr (device word, zero before the launch)
     int64_t la_cols = 0;
     unsigned* la_ctr = nullptr;
+    int tri = 0;  // triangular operands: see GemmArgs::tri (gemm_tile.hpp)
+    // tiles claimed in dispatch order instead of dealt per XCD: for launches whose tiles differ in length (tri), where equal
+    // tile counts per XCD are unequal work
+    bool dynamic = false;
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 int launch_release_xcds(fr_ctx* ctx, unsigned epoch);  // on ctx->ls: the chain of panel `epoch` is finished
@@ -421,6 +428,8 @@ int potrf_device(fr_ctx* ctx, fr_chol* c, int64_t j0, int64_t n, int mode, doubl
 // B (n x m, device) <- L^-1 B   /   B <- L^-T B
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int prof_cls);
 int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int prof_cls);
+// W (n x n, leading dimension ldw) <- L^-1, strict upper triangle exactly zero; T: scratch of at least (n / 2 + 512)^2 doubles
+int chol_tri_inverse(fr_ctx* ctx, const fr_chol* c, double* W, int64_t ldw, double* T, int prof_cls);
 int chol_alloc(fr_ctx* ctx, int64_t n, int64_t capacity, int64_t d, fr_chol** out);
 int chol_fetch_info(fr_chol* c);
 

@@ -127,7 +127,19 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
     }
     const int64_t m0 = tm * BM, n0 = tn * BN;
     if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) return;
-    gemm_f64_tile<A_KMAJ, B_KMAJ, YIELD>(g, lds, m0, n0);
+    GemmArgs gt = g;  // (ONE call site of the tile function: a second inlined copy would double the kernel)
+    if (g.tri) {
+        // triangular operand(s): skip the part of the contraction that only multiplies structural zeros
+        int64_t kbeg = 0, kend = g.K;
+        if ((g.tri & 1) && m0 > kbeg) kbeg = m0;
+        if ((g.tri & 2) && n0 > kbeg) kbeg = n0;
+        if ((g.tri & 4) && m0 + BM < kend) kend = m0 + BM;
+        if (kbeg > kend) kbeg = kend;
+        gt.A += kbeg * (A_KMAJ ? 1 : g.lda);
+        gt.B += kbeg * (B_KMAJ ? 1 : g.ldb);
+        gt.K = kend - kbeg;
+    }
+    gemm_f64_tile<A_KMAJ, B_KMAJ, YIELD>(gt, lds, m0, n0);
     if (g.la_ctr && tn < g.la_tiles) {
         // a tile of the next panel's columns: tell the panel stream (every wave drains its stores, then ONE release + count)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -314,7 +326,7 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
     const int64_t tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     // (lower mode -- the trailing updates of a factorisation -- keeps round 1's rule: its launches stay syrk_lower_f64_kernel
     // launches, which is what the profile class and the rocprofv3 summaries count)
-    if (d.batch <= 1 && d.own_world <= 1 && !d.la_ctr && ctx->ls == ctx->stream && ctx->splitk != 0 &&
+    if (d.batch <= 1 && d.own_world <= 1 && !d.la_ctr && !d.tri && ctx->ls == ctx->stream && ctx->splitk != 0 &&
         tiles <= (d.lower ? 192 : ctx->splitk_tiles) && d.K >= (d.lower ? 2048 : ctx->splitk_mink) &&
         d.M <= 65535 * 256) {
         int64_t S = (ctx->splitk_target + tiles - 1) / tiles;
@@ -407,6 +419,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.epoch = ctx->panel_epoch;
     g.la_tiles = 0;
     g.la_ctr = nullptr;
+    g.tri = d.tri;
     const bool merged = d.la_cols > 0 && d.lower && d.la_ctr;
     const bool merged_static = merged && !ctx->reserve_now && ctx->la_merge_claimed == 0;
     if ((ctx->reserve_now || (merged && !merged_static)) && d.batch <= 1 && !ctx->syrk_dynamic && d.own_world <= 1) {
@@ -435,6 +448,17 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         const int64_t rest_tiles = g.ntiles - n_la0;
         ntiles = ((n_la0 + 7) & ~(int64_t)7) + 8 * ((rest_tiles + 7) / 8);
     }
+    if (d.dynamic && g.place == 0 && !merged && d.batch <= 1 && d.own_world <= 1 && ctx->dyn_ring && ctx->yield_word) {
+        // claimed order with nothing reserved (nres = 0): every workgroup takes the next tile of the list
+        unsigned* ctr = ctx->dyn_ring + 2 * (ctx->dyn_next++ & 255);
+        FR_HIP(ctx, hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned), ctx->ls));
+        g.place = 1;
+        g.nres = 0;
+        g.xcc_word = ctx->yield_word + 4;
+        g.claim = ctr;
+        g.max_exit = 0;
+        g.nsuper = 0;
+    }
     if (g.place == 2) ntiles = 8 * ((g.ntiles + g.nres - 1) / g.nres);
     if (g.place == 1 || g.place == 3 || g.place == 5) ntiles = g.ntiles + g.max_exit;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
@@ -454,6 +478,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         flops = own_flops;
         bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + 2.0 * own_c);
     }
+    if (d.tri) flops *= (d.tri == 1 && d.lower) ? (2.0 / 3.0) : 0.5;  // average length of the restricted contraction
     const double nbatch = d.batch > 1 ? (double)d.batch : 1.0;
     ProfScope ps(ctx, d.prof_cls, flops * nbatch, bytes * nbatch);
     g.yield_word = (ctx->k4_yield && d.batch <= 1) ? ctx->yield_word : nullptr;

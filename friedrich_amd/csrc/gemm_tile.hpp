@@ -50,6 +50,11 @@ struct GemmArgs {
     // themselves done on *la_ctr (release), the panel stream waits for all of them (wait_counter_kernel)
     int64_t la_tiles;
     unsigned* la_ctr;
+    // triangular operands: the contraction of a tile runs over [kbeg, kend) only (multiples of 128, from the tile's offsets)
+    //   1: kbeg = m0  (op(A)(m, k) = 0 for k < m: the transpose of a lower-triangular matrix)
+    //   2: kbeg = n0  (op(B)(k, n) = 0 for k < n: a lower-triangular matrix as the right operand)
+    //   4: kend = m0 + 128  (op(A)(m, k) = 0 for k > m: a lower-triangular matrix as the left operand)
+    int tri;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile

@@ -305,10 +305,11 @@ extern "C" int fr_grad_terms(fr_chol* c, const fr_kprog* kernel, const double* y
     double* alpha = vec;
     double* outs = vec + ld;  // [ng] gradient halves, trace, alpha.alpha, y.alpha
     // K8: W = L^-1 (strict upper triangle of W is exactly zero), Kinv = W^T W (lower triangle)
-    FR_TRY(launch_set_identity(ctx, W, n, ld));
-    FR_TRY(trsm_lower_fwd(ctx, c, n, W, n, ld, FR_PROF_GEMM_SOLVE));
+    FR_TRY(chol_tri_inverse(ctx, c, W, ld, Kinv, FR_PROF_GEMM_SOLVE));  // (Kinv's buffer is the scratch: it is written next)
     {
         GemmDesc g;
+        g.dynamic = ctx->tri_inverse != 0;  // (the tiles' contractions differ in length: claimed, not dealt)
+        g.tri = ctx->tri_inverse ? 1 : 0;  // W^T (m, k) = W (k, m) is zero for k < m: a lower tile's contraction starts at its row offset
         g.M = n; g.N = n; g.K = n;
         g.A = W; g.lda = ld; g.a_kmajor = true;
         g.B = W; g.ldb = ld; g.b_kmajor = true;

@@ -435,6 +435,36 @@ def test_grad_terms_match_oracle(ctx, kernel):
     chol.free()
 
 
+@pytest.mark.parametrize("n", [2700, 5200])
+def test_grad_terms_triangular_inverse_path(ctx, n):
+    """Above 2048 rows the gradient's K^-1 = W^T W comes from the recursive triangular inverse and products that skip the
+    structural zeros (chol.hip: chol_tri_inverse; GemmArgs::tri, tiles claimed): against the oracle's gradient
+    (optimizer.rs:24-60, 159-203) at a ragged size, and against the dense products (option tri_inverse = 0) beyond."""
+    kernel = ("squared_exp", 0.9, 1.7)
+    X = rand_inputs(n, 3, 77)
+    y = np.sin(X.sum(axis=1))
+    noise = 0.4
+    chol = ctx.cholesky_from_inputs(kernel, X, noise)
+    g, _ = chol.grad_terms(kernel, y, noise, scaled=False, nb_parameters=2)
+    gs, scale = chol.grad_terms(kernel, y, noise, scaled=True, nb_parameters=2)
+    ctx.set_option("tri_inverse", 0)
+    try:
+        g0, _ = chol.grad_terms(kernel, y, noise, scaled=False, nb_parameters=2)
+        gs0, scale0 = chol.grad_terms(kernel, y, noise, scaled=True, nb_parameters=2)
+    finally:
+        ctx.set_option("tri_inverse", 1)
+    assert np.max(np.abs(g - g0)) < 1e-10 * (np.max(np.abs(g0)) + 1.0) and np.max(np.abs(gs - gs0)) < 1e-10 * (np.max(np.abs(gs0)) + 1.0)
+    assert abs(scale / scale0 - 1.0) < 1e-12
+    if n <= 3000:
+        with O.threads(0):
+            gp = O.OracleGP(O.ZeroPrior(), kernel, noise, None, X, y)
+            g_o = gp.gradient()
+            scale_o, gs_o = gp.scaled_gradient()
+        assert np.max(np.abs(g - g_o)) < 1e-8 * (np.max(np.abs(g_o)) + 1.0)
+        assert abs(scale / scale_o - 1.0) < 1e-9 and np.max(np.abs(gs - gs_o)) < 1e-8 * (np.max(np.abs(gs_o)) + 1.0)
+    chol.free()
+
+
 def test_concurrent_predict_from_threads(ctx):
     # GaussianProcess is Send + Sync in the reference: several threads may call &self methods of one model at once.
     # The entry points of a context take turns (per-context lock); results must equal the sequential ones.
