@@ -455,6 +455,14 @@ def test_grad_terms_triangular_inverse_path(ctx, n):
         ctx.set_option("tri_inverse", 1)
     assert np.max(np.abs(g - g0)) < 1e-10 * (np.max(np.abs(g0)) + 1.0) and np.max(np.abs(gs - gs0)) < 1e-10 * (np.max(np.abs(gs0)) + 1.0)
     assert abs(scale / scale0 - 1.0) < 1e-12
+    # Cholesky::inverse goes the same way above 2048 rows
+    Ki = chol.inverse()
+    ctx.set_option("tri_inverse", 0)
+    try:
+        Ki0 = chol.inverse()
+    finally:
+        ctx.set_option("tri_inverse", 1)
+    assert rel_err(Ki, Ki0) < 1e-11 and np.array_equal(Ki, Ki.T)
     if n <= 3000:
         with O.threads(0):
             gp = O.OracleGP(O.ZeroPrior(), kernel, noise, None, X, y)
