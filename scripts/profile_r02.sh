@@ -12,6 +12,9 @@ for c in 1 2 4; do
   cp $(find $O/config${c}_stats -name "*kernel_stats.csv" | head -1) $O/config${c}_kernel_stats.csv
   cat $O/config${c}_run.txt | grep -v amdgpu
 done
+python scripts/baseline_configs.py 2>/dev/null | grep fit_ms > $O/baseline_final.jsonl
+python scripts/grad_time.py 4096,8192,16384,32768 2>/dev/null | grep refactor > $O/grad_time.txt; cat $O/grad_time.txt
+python scripts/config0_time.py 2>/dev/null | tail -1 > $O/config0_time.txt; cat $O/config0_time.txt
 # PMC passes on two fits at N = 32768 (separate passes, never together with a trace domain other than kernel-trace)
 W="python scripts/fit_only.py 32768 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fit32k_stats -o s -- $W > /dev/null 2>&1
