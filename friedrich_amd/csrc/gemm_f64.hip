@@ -324,10 +324,10 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
 {
     if (d.M <= 0 || d.N <= 0) return FR_OK;
     const int64_t tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    // (lower mode -- the trailing updates of a factorisation -- keeps round 1's rule: its launches stay syrk_lower_f64_kernel
-    // launches, which is what the profile class and the rocprofv3 summaries count)
+    // (the trailing updates of a factorisation -- profile class SYRK -- keep round 1's rule: their launches stay
+    // syrk_lower_f64_kernel launches, which is what the profile class and the rocprofv3 summaries count)
     if (d.batch <= 1 && d.own_world <= 1 && !d.la_ctr && !d.tri && ctx->ls == ctx->stream && ctx->splitk != 0 &&
-        tiles <= (d.lower ? 192 : ctx->splitk_tiles) && d.K >= (d.lower ? 2048 : ctx->splitk_mink) &&
+        tiles <= (d.prof_cls == FR_PROF_SYRK ? 192 : ctx->splitk_tiles) && d.K >= (d.prof_cls == FR_PROF_SYRK ? 2048 : ctx->splitk_mink) &&
         d.M <= 65535 * 256) {
         int64_t S = (ctx->splitk_target + tiles - 1) / tiles;
         if (S > d.K / ctx->splitk_slice) S = d.K / ctx->splitk_slice;

@@ -308,8 +308,9 @@ extern "C" int fr_grad_terms(fr_chol* c, const fr_kprog* kernel, const double* y
     FR_TRY(chol_tri_inverse(ctx, c, W, ld, Kinv, FR_PROF_GEMM_SOLVE));  // (Kinv's buffer is the scratch: it is written next)
     {
         GemmDesc g;
-        g.dynamic = ctx->tri_inverse != 0;  // (the tiles' contractions differ in length: claimed, not dealt)
-        g.tri = ctx->tri_inverse ? 1 : 0;  // W^T (m, k) = W (k, m) is zero for k < m: a lower tile's contraction starts at its row offset
+        const bool tri = ctx->tri_inverse != 0 && n > 2048;  // (small cases: few tiles, cut along K instead -- launch_gemm)
+        g.dynamic = tri;  // the tiles' contractions differ in length: claimed, not dealt
+        g.tri = tri ? 1 : 0;  // W^T (m, k) = W (k, m) is zero for k < m: a lower tile's contraction starts at its row offset
         g.M = n; g.N = n; g.K = n;
         g.A = W; g.lda = ld; g.a_kmajor = true;
         g.B = W; g.ldb = ld; g.b_kmajor = true;
