@@ -895,7 +895,11 @@ static bool use_column_groups(const fr_ctx* ctx, const fr_chol* c, int64_t n, in
     // m = 128 7.7 vs 6.0 ms), i.e. while m n stays below about two million
     // ... and for any number of columns while m n <= 1.3e6 (n = 512 / 1024 / 2048: up to 1024 / 1024 / 512 columns, e.g. the
     // n x n identity of the gradient's small cases: 0.13 vs 0.29 ms at n = 512)
-    return (m <= 256 && m * n <= 2200000) || m * n <= 1300000;
+    if ((m <= 256 && m * n <= 2200000) || m * n <= 1300000) return true;
+    // the GEMM path's 512-row leaves need the 512 x 512 inverse blocks, which a changed factor has to rebuild first (seven
+    // launches): a one-off solve right after add_rows -- its own L21 solve above all -- stays with the groups (configs[4]:
+    // eight appends of 512 rows 15.6 -> 15.0 ms)
+    return m <= 512 && n <= 8192 && c->inv512_rows < (n / LB) * LB;
 }
 
 int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls)

@@ -17,6 +17,8 @@ n, d, kname, eps = {1: (4096, 8, "squared_exp", None), 2: (16384, 16, "matern2",
                      4: (8192, 8, "squared_exp", None)}[cfg]
 m = 1024
 ctx = Context()
+for o in [a[2:] for a in sys.argv[2:] if a.startswith("--")]:  # --name=value context options
+    ctx.set_option(o.split("=")[0], int(o.split("=")[1]))
 X, y, Xq = synth.make_problem(n, d, cfg=cfg, m=m)
 ls = ctx.mean_pairwise_distance(X)
 hp = synth.default_hyperparameters(X, y, ls)
