@@ -253,6 +253,10 @@ def main():
         chol.set_targets(y_d)
         extras["predict_ms_cached_alpha"] = best_ms(lambda: chol.predict_mean(kernel, None, Xq_d, prior_d, out=mean_d))
         if world == 1:
+            # one optimizer iteration's gradient terms (optimizer.rs:159-203: K^-1 = W^T W and the fused reductions); the
+            # refactor that precedes it in fit_parameters is `fit_ms` without the Gram heuristics
+            npar = 2
+            extras["grad_terms_ms"] = best_ms(lambda: chol.grad_terms(kernel, y_d, noise, True, npar), reps=1)
             Xrow = np.ascontiguousarray(X)  # the caller's row-major samples (ndarray / Vec<Vec<f64>> of the reference)
 
             def fit_from_host():
