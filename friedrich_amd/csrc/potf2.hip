@@ -518,62 +518,63 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
             const int nU = m3 ? 0 : rem * (rem + 1) / 2;
             const int n2 = want_inv ? rem * b : 0;
             const int l15 = lane & 15, lq = lane >> 4;
-            // Every wave takes its tile tasks four at a time (independent accumulator chains): next to a GEMM workgroup a
-            // wave gets the matrix core in turns, and a turn takes whatever is ready.  Update wave 3 joins after its
-            // store: the task list is dealt to the other waves first.
-            const int ntask = 4 * (nU + n2);
-            for (int task0 = (u + 3) % 7; task0 < ntask; task0 += 28) {
-                d4_t acc[4];
-                const double* Pp[4];
-                const double* Qp[4];
-                double* Cp[4];
-                bool tr[4], on[4];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int task = task0 + 7 * s4;
-                    on[s4] = task < ntask;
-                    const int pidx = on[s4] ? (task >> 2) : 0;
-                    const int tx = (task >> 1) & 1, ty = task & 1;
-                    acc[s4] = d4_t{0.0, 0.0, 0.0, 0.0};
-                    if (pidx < nU) {
-                        // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b:  C[x + 32 y] (x along the lanes)
-                        const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
-                        const int rk = pidx - ri * (ri - 1) / 2 + 1;
-                        tr[s4] = false;
-                        Pp[s4] = lds + slot_of(b + ri, b) + HB * tx + l15 + SB * lq;
-                        Qp[s4] = lds + slot_of(b + rk, b) + HB * ty + l15 + SB * lq;
-                        Cp[s4] = lds + slot_of(b + ri, b + rk) + (HB * tx + l15) + SB * (HB * ty + lq);
-                    } else {
-                        // (2): WT_i,cb[y + 32 x] (y along the lanes) -= L_ib WT_b,cb
-                        const int q = pidx - nU;
-                        const int bb = b > 0 ? b : 1;
-                        const int i = b + 1 + q / bb, cb = q % bb;
-                        tr[s4] = true;
-                        Pp[s4] = lds + slot_of(i, b) + HB * tx + l15 + SB * lq;
-                        Qp[s4] = lds + slot_of(b, cb) + HB * ty + l15 + SB * lq;
-                        Cp[s4] = lds + slot_of(i, cb) + (HB * ty + l15) + SB * (HB * tx + lq);
-                    }
+            // Update wave 3 joins after its store: the list is dealt to the other waves first.
+            // One 32 x 32 product per wave and turn: its four 16 x 16 accumulators share the operand fragments (two reads per
+            // k-step and operand instead of four -- the fragment reads are 4-way bank-conflicted at this sub-block stride and
+            // seven waves share one LDS, so this phase is bound by LDS traffic, not by the matrix core).
+            const int npair = nU + n2;
+            for (int pidx = (u + 3) % 7; pidx < npair; pidx += 7) {
+                const double* Pp;
+                const double* Qp;
+                double* Cp;
+                bool tr;
+                if (pidx < nU) {
+                    // pairs in the order (1,1) (2,1) (2,2) (3,1) (3,2) (3,3), relative to b:  C[x + 32 y] (x along the lanes)
+                    const int ri = (pidx >= 3) ? 3 : ((pidx >= 1) ? 2 : 1);
+                    const int rk = pidx - ri * (ri - 1) / 2 + 1;
+                    tr = false;
+                    Pp = lds + slot_of(b + ri, b) + l15 + SB * lq;
+                    Qp = lds + slot_of(b + rk, b) + l15 + SB * lq;
+                    Cp = lds + slot_of(b + ri, b + rk);
+                } else {
+                    // (2): WT_i,cb[y + 32 x] (y along the lanes) -= L_ib WT_b,cb
+                    const int q = pidx - nU;
+                    const int bb = b > 0 ? b : 1;
+                    const int i = b + 1 + q / bb, cb = q % bb;
+                    tr = true;
+                    Pp = lds + slot_of(i, b) + l15 + SB * lq;
+                    Qp = lds + slot_of(b, cb) + l15 + SB * lq;
+                    Cp = lds + slot_of(i, cb);
                 }
+                d4_t acc[2][2];  // [tx][ty]
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                    for (int ty = 0; ty < 2; ++ty) acc[tx][ty] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kk = 0; kk < SB / 4; ++kk) {
+                    double pf[2], qf[2];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        if (on[s4]) {
-                            const double pf = Pp[s4][SB * 4 * kk];
-                            const double qf = Qp[s4][SB * 4 * kk];
+                    for (int tt = 0; tt < 2; ++tt) {
+                        pf[tt] = Pp[HB * tt + SB * 4 * kk];
+                        qf[tt] = Qp[HB * tt + SB * 4 * kk];
+                    }
+#pragma unroll
+                    for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                        for (int ty = 0; ty < 2; ++ty)
                             // result index of the FIRST operand runs over lq + 4 reg, of the SECOND over the lanes
-                            acc[s4] = tr[s4] ? __builtin_amdgcn_mfma_f64_16x16x4f64(pf, qf, acc[s4], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f64_16x16x4f64(qf, pf, acc[s4], 0, 0, 0);
-                        }
-                    }
+                            acc[tx][ty] = tr ? __builtin_amdgcn_mfma_f64_16x16x4f64(pf[tx], qf[ty], acc[tx][ty], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f64_16x16x4f64(qf[ty], pf[tx], acc[tx][ty], 0, 0, 0);
                 }
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    if (on[s4]) {
+                for (int tx = 0; tx < 2; ++tx)
 #pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) Cp[s4][SB * 4 * reg] -= acc[s4][reg];
+                    for (int ty = 0; ty < 2; ++ty) {
+                        double* C = tr ? Cp + (HB * ty + l15) + SB * (HB * tx + lq) : Cp + (HB * tx + l15) + SB * (HB * ty + lq);
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) C[SB * 4 * reg] -= acc[tx][ty][reg];
                     }
-                }
             }
         }
         lds_barrier();
