@@ -620,17 +620,22 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
     // the products with W need a step of iterative refinement (chol.hip); and zeros above the diagonal of the factored
     // block in A, so that refinement can use L_bb as a plain 128 x 128 operand.
     if (want_inv) {
-        const int cg = t >> 5;
+        // The read is a transposition (LDS holds W^T): with the 32 rows of a sub-block along the lanes every lane of a read hits
+        // the same bank (32-way conflict, 12.7 k of the kernel's 131 k cycles).  8 rows x 8 columns per wave-instruction instead:
+        // 8-way conflicts in LDS, 64-byte segments in memory.
+        const int ra = t & 7, cl = (t >> 3) & 7;        // row / column inside the wave's 8 x 8 patch
+        const int rb = (t >> 6) & 3, cq = t >> 8;        // wave: rows 8 rb .., columns 16 cq + 8 cc ..
+        const int rr = 8 * rb + ra;
         double wmax = 0.0, dmin = __builtin_inf();
         for (int i = 0; i < nblk; ++i)
             for (int k = 0; k < nblk; ++k) {
                 const double* s = lds + slot_of(i, k <= i ? k : 0);
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    const int c = cg * 2 + cc;
-                    const int gr = SB * i + r, gc = SB * k + c;
+                    const int c = 16 * cq + 8 * cc + cl;
+                    const int gr = SB * i + rr, gc = SB * k + c;
                     if (gr < n && gc < n) {
-                        const double v = (k <= i) ? s[c + SB * r] : 0.0;
+                        const double v = (k <= i) ? s[c + SB * rr] : 0.0;
                         inv[gr + (int64_t)gc * ldinv] = v;
                         const double av = __builtin_fabs(v);
                         wmax = (av > wmax || av != av) ? av : wmax;  // NaN sticks
