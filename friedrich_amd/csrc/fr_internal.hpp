@@ -289,6 +289,8 @@ struct ProfScope {
 // K1: Gram assembly
 int launch_gram_cross(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_t n1, int64_t lda, const double* B,
                       int64_t n2, int64_t ldb, int64_t d, double* out, int64_t ldo);
+int launch_gram_cross_dot(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_t n1, int64_t lda, const double* B,
+                          int64_t n2, int64_t ldb, int64_t d, const double* v, double* out);
 // lower triangle (full 128x128 diagonal tiles) + noise^2 on the diagonal, rows/cols [r0, n) x [c0, n)
 // own_world > 1: only the block columns (width own_nb) owned by own_rank are assembled
 int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,

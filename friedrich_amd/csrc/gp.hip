@@ -24,7 +24,7 @@ struct QueryCtx {
     int64_t m = 0;
     QueryCtx(fr_chol* c_) : c(c_), ctx(c_->ctx), xq(c_->ctx), kstar(c_->ctx) {}
     // make_covariance_matrix(train, inputs) (mod.rs:234, 256-257, 296-297, 337-338, 377-378)
-    int init(const fr_kprog* kernel, const double* Xq, int64_t m_, int64_t ldq)
+    int init(const fr_kprog* kernel, const double* Xq, int64_t m_, int64_t ldq, bool with_gram = true)
     {
         FR_HIP(ctx, hipSetDevice(ctx->device));
         FR_TRY(kprog_check(ctx, kernel));
@@ -32,6 +32,7 @@ struct QueryCtx {
         m = m_;
         FR_TRY(xq.in(Xq, m, c->d, ldq));
         ldk = round_up(c->n > 0 ? c->n : 1, kAlign);
+        if (!with_gram) return FR_OK;  // (the caller fuses the covariance into its product: launch_gram_cross_dot)
         K = kstar.get(sizeof(double) * (size_t)ldk * (size_t)(m > 0 ? m : 1));
         if (!K) return FR_OUT_OF_MEMORY;
         return launch_gram_cross(ctx, *kernel, c->X, c->n, c->ld_x, xq.dev, m, xq.ld, c->d, K, ldk);
@@ -168,15 +169,15 @@ int fr_predict_mean(fr_chol* c, const fr_kprog* kernel, const double* y, const d
     FR_LOCK(c->ctx);
     fr_ctx* ctx = c->ctx;
     QueryCtx q(c);
-    FR_TRY(q.init(kernel, Xq, m, ldq));
+    FR_TRY(q.init(kernel, Xq, m, ldq, y != nullptr));
     Staged ys(ctx), mean(ctx);
     if (!y) {
-        // cached alpha = K^-1 y (fr_chol_set_targets): prior + K*^T alpha -- no solve at all once alpha is current, the
-        // n x m cross-Gram and one pass over it are all that is left (todo.md:10)
+        // cached alpha = K^-1 y (fr_chol_set_targets): prior + K*^T alpha -- no solve at all once alpha is current, and the
+        // n x m cross-covariance is multiplied by alpha tile by tile as K1 produces it: it never reaches memory (todo.md:10)
         FR_TRY(ensure_alpha(c));
         FR_TRY(stage_vec_out(ctx, mean, out_mean, m));
         FR_TRY(init_with_prior(ctx, mean.dev, prior_q, m));
-        FR_TRY(launch_gemv_t(ctx, q.K, c->n, m, q.ldk, c->alpha, 1.0, 1.0, mean.dev));
+        FR_TRY(launch_gram_cross_dot(ctx, *kernel, c->X, c->n, c->ld_x, q.xq.dev, m, q.xq.ld, c->d, c->alpha, mean.dev));
         return mean.commit();
     }
     FR_TRY(stage_vec_in(ctx, ys, y, c->n));

@@ -32,6 +32,10 @@ struct GramArgs {
     int64_t tiles_n;  // cross mode: tiles along n2
     int own_world, own_rank;  // sym mode, multi-GPU: only block columns (width own_nb) of own_rank are assembled
     int64_t own_nb;
+    // cross mode, fused with a product: instead of storing the tile, part[ti * n2 + j] = sum over the tile's rows i of
+    // k(a_i, b_j) dot_vec[i]  (predict with the cached alpha: the n x m cross-covariance never exists)
+    const double* dot_vec;
+    double* dot_part;
 };
 
 __device__ __forceinline__ void sym_tile(int64_t t, int64_t& bi, int64_t& tj)
@@ -112,17 +116,34 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a)
     // large for the compiler to unroll 32 times, and a rolled loop that indexes s[h][b] dynamically sends the accumulators
     // through scratch memory (measured: 4x the algorithmic bytes written, 2x fetched, per launch).  So the loop over the 16
     // columns stays rolled but always consumes element 0 and then rotates the register arrays (static indices only).
+    double av[2] = {0.0, 0.0};
+    if (a.dot_vec) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t gi = i0 + r + 64 * h;
+            av[h] = gi < a.n1 ? a.dot_vec[gi] : 0.0;
+        }
+    }
 #pragma unroll 1
     for (int b = 0; b < 16; ++b) {
         const int64_t gj = j0 + g * 16 + b;
+        double dotv = 0.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int64_t gi = i0 + r + 64 * h;
             if (gi < a.n1 && gj < a.n2) {
                 double k = kprog_eval(a.prog, s[h][0], u[h][0]);
                 if (a.sym && gi == gj) k = k + a.noise2;  // algebra/mod.rs:78
-                a.out[gi + gj * a.ldo] = k;
+                if (a.dot_vec)
+                    dotv = dotv + k * av[h];
+                else
+                    a.out[gi + gj * a.ldo] = k;
             }
+        }
+        if (a.dot_vec) {  // (uniform) the wave's 128 rows of column gj: fixed-order tree over the 64 lanes
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dotv = dotv + __shfl_xor(dotv, off, 64);
+            if (r == 0 && gj < a.n2) a.dot_part[ti * a.n2 + gj] = dotv;
         }
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
@@ -285,6 +306,8 @@ int launch_gram_cross(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_
     a.out = out;
     a.ldo = ldo;
     a.sym = 0;
+    a.dot_vec = nullptr;
+    a.dot_part = nullptr;
     a.noise2 = 0.0;
     a.own_world = 1;
     a.own_rank = 0;
@@ -292,6 +315,52 @@ int launch_gram_cross(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_
     a.tiles_n = (n2 + GT_N - 1) / GT_N;
     const int64_t tiles_m = (n1 + GT_M - 1) / GT_M;
     return launch_gram(ctx, a, tiles_m * a.tiles_n, kprog_needs(prog), (double)n1 * (double)n2);
+}
+
+// out[j] += sum over the row tiles of part[ti * m + j], in tile order (deterministic)
+__global__ __launch_bounds__(256) void gram_dot_reduce_kernel(const double* __restrict__ part, int64_t tiles, int64_t m,
+                                                             double* __restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double acc = out[j];
+    for (int64_t ti = 0; ti < tiles; ++ti) acc = acc + part[ti * m + j];
+    out[j] = acc;
+}
+
+// out (n2, holding the prior) += K(A, B)^T v without materialising the n1 x n2 covariance: K1's tiles are multiplied by v
+// as they are produced (per-tile partial sums, then one deterministic reduction).
+int launch_gram_cross_dot(fr_ctx* ctx, const fr_kprog& prog, const double* A, int64_t n1, int64_t lda, const double* B,
+                          int64_t n2, int64_t ldb, int64_t d, const double* v, double* out)
+{
+    if (n1 == 0 || n2 == 0) return FR_OK;
+    const int64_t tiles_m = (n1 + GT_M - 1) / GT_M;
+    WsGuard w(ctx);
+    double* part = w.get(sizeof(double) * (size_t)tiles_m * (size_t)n2);
+    if (!part) return FR_OUT_OF_MEMORY;
+    GramArgs a;
+    a.prog = prog;
+    a.A = A;
+    a.n1 = n1;
+    a.lda = lda;
+    a.B = B;
+    a.n2 = n2;
+    a.ldb = ldb;
+    a.d = d;
+    a.out = nullptr;
+    a.ldo = 0;
+    a.sym = 0;
+    a.dot_vec = v;
+    a.dot_part = part;
+    a.noise2 = 0.0;
+    a.own_world = 1;
+    a.own_rank = 0;
+    a.own_nb = 1;
+    a.tiles_n = (n2 + GT_N - 1) / GT_N;
+    FR_TRY(launch_gram(ctx, a, tiles_m * a.tiles_n, kprog_needs(prog), (double)n1 * (double)n2));
+    hipLaunchKernelGGL(gram_dot_reduce_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->ls, part, tiles_m, n2, out);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
 }
 
 int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,
@@ -310,6 +379,8 @@ int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t 
     a.out = out;
     a.ldo = ldo;
     a.sym = 1;
+    a.dot_vec = nullptr;
+    a.dot_part = nullptr;
     a.noise2 = noise2;
     a.tiles_n = 0;
     a.own_world = own_world;
