@@ -124,33 +124,44 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a)
             av[h] = gi < a.n1 ? a.dot_vec[gi] : 0.0;
         }
     }
+    // Two columns (four pairs) per turn, evaluated unconditionally and only STORED under the bounds test: the program's chain
+    // of dependent f64 operations (exp / pow) then overlaps four ways instead of sitting alone inside a divergent branch
+    // (padding rows / columns hold zeros: finite inputs, results discarded).
 #pragma unroll 1
-    for (int b = 0; b < 16; ++b) {
-        const int64_t gj = j0 + g * 16 + b;
-        double dotv = 0.0;
+    for (int b = 0; b < 16; b += 2) {
+        double k[2][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t gi = i0 + r + 64 * h;
-            if (gi < a.n1 && gj < a.n2) {
-                double k = kprog_eval(a.prog, s[h][0], u[h][0]);
-                if (a.sym && gi == gj) k = k + a.noise2;  // algebra/mod.rs:78
-                if (a.dot_vec)
-                    dotv = dotv + k * av[h];
-                else
-                    a.out[gi + gj * a.ldo] = k;
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) k[e][h] = kprog_eval(a.prog, s[h][e], u[h][e]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t gj = j0 + g * 16 + b + e;
+            double dotv = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t gi = i0 + r + 64 * h;
+                if (gi < a.n1 && gj < a.n2) {
+                    double kv = k[e][h];
+                    if (a.sym && gi == gj) kv = kv + a.noise2;  // algebra/mod.rs:78
+                    if (a.dot_vec)
+                        dotv = dotv + kv * av[h];
+                    else
+                        a.out[gi + gj * a.ldo] = kv;
+                }
+            }
+            if (a.dot_vec) {  // (uniform) the wave's 128 rows of column gj: fixed-order tree over the 64 lanes
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) dotv = dotv + __shfl_xor(dotv, off, 64);
+                if (r == 0 && gj < a.n2) a.dot_part[ti * a.n2 + gj] = dotv;
             }
         }
-        if (a.dot_vec) {  // (uniform) the wave's 128 rows of column gj: fixed-order tree over the 64 lanes
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) dotv = dotv + __shfl_xor(dotv, off, 64);
-            if (r == 0 && gj < a.n2) a.dot_part[ti * a.n2 + gj] = dotv;
-        }
-#pragma unroll
-        for (int i = 0; i < 15; ++i) {
-            s[0][i] = s[0][i + 1];
-            s[1][i] = s[1][i + 1];
-            u[0][i] = u[0][i + 1];
-            u[1][i] = u[1][i + 1];
+        for (int i = 0; i < 14; ++i) {
+            s[0][i] = s[0][i + 2];
+            s[1][i] = s[1][i + 2];
+            u[0][i] = u[0][i + 2];
+            u[1][i] = u[1][i + 2];
         }
     }
 }
