@@ -48,8 +48,10 @@ __device__ __forceinline__ void sym_tile(int64_t t, int64_t& bi, int64_t& tj)
     tj = t - b * (b + 1);
 }
 
+// (three waves per SIMD for the one-accumulator modes: 168 VGPRs and a few spilled values, measured 2.93 -> 2.66 ms at
+// N = 32768 -- the kernel waits on LDS broadcasts and dependent f64 chains, more waves hide more of it; four waves spill: 4.2 ms)
 template <int MODE>
-__global__ __launch_bounds__(256) void gram_kernel(const GramArgs a)
+__global__ __launch_bounds__(256, (MODE == (NEED_S | NEED_U)) ? 2 : 3) void gram_kernel(const GramArgs a)
 {
 #pragma clang fp contract(off)
     __shared__ double XA[GT_DC][GT_M];
