@@ -142,7 +142,10 @@ __device__ __forceinline__ void grad_sym_tile(int64_t t, int64_t& bi, int64_t& t
     tj = t - b * (b + 1);
 }
 
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const GradArgs a)
+// MODE: which pair statistics the kernel program needs (kprog_needs): squared distance (NEED_S), dot product (NEED_U) or both
+// -- as in K1, a kernel without the other accumulator saves its VALU work and the spills of 64 more accumulator registers.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void grad_reduce_kernel(const GradArgs a)
 {
 #pragma clang fp contract(off)
     __shared__ double XA[GR_DC][GR_M];
@@ -178,11 +181,15 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const GradArgs a)
 #pragma unroll
             for (int b = 0; b < 16; ++b) {
                 const double xb = XB[c][g * 16 + b];
-                const double d0 = xa0 - xb, d1 = xa1 - xb;
-                s[0][b] = s[0][b] + d0 * d0;
-                s[1][b] = s[1][b] + d1 * d1;
-                u[0][b] = u[0][b] + xa0 * xb;
-                u[1][b] = u[1][b] + xa1 * xb;
+                if (MODE & NEED_S) {
+                    const double d0 = xa0 - xb, d1 = xa1 - xb;
+                    s[0][b] = s[0][b] + d0 * d0;
+                    s[1][b] = s[1][b] + d1 * d1;
+                }
+                if (MODE & NEED_U) {
+                    u[0][b] = u[0][b] + xa0 * xb;
+                    u[1][b] = u[1][b] + xa1 * xb;
+                }
             }
         }
         __syncthreads();
@@ -351,7 +358,13 @@ extern "C" int fr_grad_terms(fr_chol* c, const fr_kprog* kernel, const double* y
     a.partials = partials;
     {
         ProfScope ps(ctx, FR_PROF_GRAM, 0.5 * (double)n * (double)n * (3.0 * (double)c->d + 60.0), 4.0 * (double)n * (double)n);
-        hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->ls, a);
+        const int needs = kprog_needs(*kernel);
+        if (needs == NEED_S)
+            hipLaunchKernelGGL(grad_reduce_kernel<NEED_S>, dim3((unsigned)nblocks), dim3(256), 0, ctx->ls, a);
+        else if (needs == NEED_U)
+            hipLaunchKernelGGL(grad_reduce_kernel<NEED_U>, dim3((unsigned)nblocks), dim3(256), 0, ctx->ls, a);
+        else
+            hipLaunchKernelGGL(grad_reduce_kernel<NEED_S | NEED_U>, dim3((unsigned)nblocks), dim3(256), 0, ctx->ls, a);
         FR_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(256), 0, ctx->ls, (const double*)partials, nblocks, ng,
                            (const double*)Kinv, ld, (const double*)alpha, n, outs);
