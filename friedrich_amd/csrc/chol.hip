@@ -586,7 +586,8 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (rest <= 0) break;
         const int64_t kb2 = kb_next = width(rest);
         const double* P = A + (k + kb) + k * ld;
-        // once the panel chain is longer than the trailing update, the update's launches leave XCD 0 to it (gemm_f64.hip)
+        // once the panel chain is longer than the trailing update, the update's launches leave the panel stream's XCD(s) to it
+        // (gemm_f64.hip / gemm_tile.hpp: claim_item)
         ctx->reserve_now = 0;
         ++ctx->panel_epoch;
         if (world == 1 && ctx->claim_ring && !ctx->syrk_dynamic) {
