@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--d", type=int, default=16)
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block; 0 = the library's choice (1024 on one GPU at this size, 512 sharded)")
-    ap.add_argument("--panel-split", type=int, default=0, help="N > 1: 1 = split variant of the panel step (scatter, per-rank solves, all-gather); 0 = one broadcast per panel")
+    ap.add_argument("--dist-schedule", type=int, default=-1, help="N > 1, how a panel step travels: 0 = one broadcast per panel; 1 = diagonal block broadcast + rows scattered / solved per rank / all-gathered; 2 = as 1 with the diagonal chain running ahead; -1 = the library's default (2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=5120)
     args = ap.parse_args()
@@ -155,7 +155,9 @@ def main():
 
     ctx = Context(local_rank)
     ctx.set_option("nb", args.nb)
-    ctx.set_option("panel_split", args.panel_split)
+    if args.dist_schedule >= 0:
+        ctx.set_option("dist_schedule", args.dist_schedule)
+    dist_sched = args.dist_schedule if args.dist_schedule >= 0 else 2
     nb_eff = args.nb if args.nb > 0 else (1024 if (world == 1 and args.n >= 24576) else 512)
     if use_dist:
         ids = [ctx.comm_unique_id() if rank == 0 else None]
@@ -302,7 +304,7 @@ def main():
             "config": {
                 "workload": f"GP fit (Gram + Cholesky) + predict, N={n} d={d} RBF, m={m} queries, friedrich default hyper-parameters",
                 "n": n, "d": d, "m": m, "kernel": "squared_exp", "nb": nb_eff,
-                "parallelism": "1 GPU" if world == 1 else f"block-cyclic column panels over {world} GPUs (RCCL " + ("scatter + all-gather per panel" if args.panel_split else "broadcast per panel") + "), queries sharded",
+                "parallelism": "1 GPU" if world == 1 else f"block-cyclic column panels over {world} GPUs (RCCL, " + ["one broadcast per panel", "diagonal block broadcast + scatter / all-gather of the rows below", "diagonal chain first: block to the next owner, then scatter / all-gather of the rows below"][dist_sched] + "), queries sharded",
             },
             "fit_ms": float(np.mean(fit_ms)),
             "predict_ms": float(np.mean(pred_ms)),

@@ -74,6 +74,7 @@ SIGNATURES = {
     "fr_ctx_synchronize": (_int, [_vp]),
     "fr_last_error": (ctypes.c_char_p, [_vp]),
     "fr_ctx_set_option": (_int, [_vp, ctypes.c_char_p, _i64]),
+    "fr_ctx_get_counter": (_int, [_vp, ctypes.c_char_p, _pi64]),
     "fr_ctx_profile_enable": (_int, [_vp, _int]),
     "fr_ctx_profile_reset": (_int, [_vp]),
     "fr_ctx_profile_get": (_int, [_vp, _int, _pdbl, _pi64, _pdbl, _pdbl]),

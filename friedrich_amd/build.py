@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libfriedrich_amd.so")
-SOURCES = ["ctx.hip", "gram.hip", "gemm_f64.hip", "potf2.hip", "util.hip", "chol.hip", "gp.hip", "grad.hip", "comm.hip", "trsv.hip", "panel.hip", "trsm_narrow.hip", "prior.hip"]
+SOURCES = ["ctx.hip", "gram.hip", "gemm_f64.hip", "potf2.hip", "util.hip", "chol.hip", "gp.hip", "grad.hip", "comm.hip", "trsv.hip", "trsm_narrow.hip", "prior.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CLANGXX = os.environ.get("FR_CLANGXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

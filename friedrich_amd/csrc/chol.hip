@@ -36,10 +36,9 @@ static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
 
 static int gemm(fr_ctx* ctx, int cls, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, bool a_kmajor,
                 const double* B, int64_t ldb, bool b_kmajor, double alpha, double beta, double* D, int64_t ldd,
-                bool lower = false, int place = 0)
+                bool lower = false)
 {
     GemmDesc g;
-    g.place = place;
     g.M = M;
     g.N = N;
     g.K = K;
@@ -70,130 +69,9 @@ static int factor_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, int64
 }
 
 // Rebuild the inverse of an already factored 128-block (serde upload, add_rows re-alignment).
-static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, double* inv, double* /*T*/)
+static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, double* inv, double* cest)
 {
-    return launch_potf2(ctx, A, ld, sb, 0, 3, 0.0, inv, IB, nullptr);
-}
-
-// ---- fused panel factorisation (panel.hip + the diagonal-block server of potf2.hip) ---------------------------------------
-struct Fused {
-    bool on = false;
-    int* ready = nullptr;
-    int* done = nullptr;
-    int* tdone = nullptr;
-};
-
-// Start the diagonal-block server for the factorisation of the n x n matrix at A: flags zeroed, server launched on its own
-// stream behind everything already queued on the current launch stream, and the host waits (microseconds) until the
-// server's workgroup is resident -- it needs a CU to itself, and the row-tile workgroups enqueued afterwards spin on it.
-static int fused_start(fr_ctx* ctx, Fused& f, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
-                       int64_t* info, int64_t nb, bool dist)
-{
-    f.on = false;
-    const int64_t nblk = (n + IB - 1) / IB;
-    if (!ctx->panel_fused || ctx->panel_fused == 4 || !ctx->stream3 || mode == 3 || nblk < 2) return FR_OK;
-    if (dist && ctx->world > 1) return FR_OK;  // the experimental variants are single-GPU only
-    FR_TRY(ensure_status_word(ctx));
-    if (ctx->panel_flags_cap < (size_t)(9 * nblk)) {
-        if (ctx->panel_flags) {
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipStreamSynchronize(ctx->stream3);
-            (void)hipFree(ctx->panel_flags);
-            ctx->panel_flags = nullptr;
-            ctx->panel_flags_cap = 0;
-        }
-        const size_t cap = (size_t)(9 * nblk) + 2304;
-        FR_HIP(ctx, dev_malloc(ctx, (void**)&ctx->panel_flags, sizeof(int) * cap));
-        ctx->panel_flags_cap = cap;
-    }
-    f.ready = ctx->panel_flags;  // 4 per block
-    f.done = f.ready + 4 * nblk;
-    f.tdone = f.done + nblk;  // 4 per block
-    // the previous users of the flags and of the matrix are ordered through the launch stream
-    FR_HIP(ctx, hipEventRecord(ctx->ev_server, ctx->ls));
-    FR_HIP(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_server, 0));
-    FR_HIP(ctx, hipMemsetAsync(ctx->panel_flags, 0, sizeof(int) * (size_t)(9 * nblk), ctx->stream3));
-    ServerArgs a;
-    a.A = A;
-    a.lda = ld;
-    a.n = n;
-    a.col0 = col0;
-    a.mode = mode;
-    a.sub = sub;
-    a.dinv = dinv;
-    a.info = info;
-    a.ready = f.ready;
-    a.done = f.done;
-    a.status = ctx->dev_status;
-    a.cest = (ctx->cur_cest && col0 == 0) ? ctx->cur_cest : nullptr;  // conditioning estimates, one per block (potf2.hip)
-    a.dbg = nullptr;
-    if (ctx->panel_debug && nblk <= 1024) {
-        if (!ctx->panel_dbg) {
-            void* h = nullptr;
-            FR_HIP(ctx, hipHostMalloc(&h, sizeof(unsigned long long) * 4 * 1024, hipHostMallocMapped));
-            ctx->panel_dbg = (unsigned long long*)h;
-        }
-        memset(ctx->panel_dbg, 0, sizeof(unsigned long long) * 4 * 1024);
-        void* d = nullptr;
-        FR_HIP(ctx, hipHostGetDevicePointer(&d, ctx->panel_dbg, 0));
-        a.dbg = (unsigned long long*)d;
-    }
-    a.token = ++ctx->server_token;
-    if (a.token == 0) a.token = ++ctx->server_token;
-    a.nblocks = (int)nblk;
-    a.own_world = dist ? ctx->world : 1;
-    a.own_rank = ctx->rank;
-    a.own_nb = nb;
-    FR_TRY(launch_potf2_server(ctx, ctx->stream3, a));
-    // the server must be resident before the first row-tile launch is enqueued
-    volatile unsigned* hs = ctx->host_status;
-    const auto t0 = std::chrono::steady_clock::now();
-    while (hs[1] != a.token) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-            hs[0] = 1;  // whatever did start gives up
-            (void)hipStreamSynchronize(ctx->stream3);
-            hs[0] = 0;
-            return set_err(ctx, FR_HIP_ERROR, "the diagonal-block server did not start");
-        }
-    }
-    // every launch that writes the flags comes after the memset: order the launch stream behind it
-    // (the memset ran before the server started, and the server is running: every row-tile launch from here on finds
-    // zeroed flags)
-    f.on = true;
-    return FR_OK;
-}
-
-// The server exits by itself after its last block; the launch stream must not run ahead of it.
-static int fused_finish(fr_ctx* ctx, Fused& f, hipStream_t s)
-{
-    if (!f.on) return FR_OK;
-    f.on = false;
-    if (ctx->panel_fused == 3) {  // developer probe: the server was resident but unused -- release it
-        (void)hipStreamSynchronize(ctx->stream);
-        volatile unsigned* hs = ctx->host_status;
-        hs[0] = 1;
-        (void)hipStreamSynchronize(ctx->stream3);
-        hs[0] = 0;
-        return FR_OK;
-    }
-    FR_HIP(ctx, hipEventRecord(ctx->ev_server, ctx->stream3));
-    FR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_server, 0));
-    return FR_OK;
-}
-
-// error path: make the server (and every waiting row tile) give up, then clear the word
-static void fused_abort(fr_ctx* ctx, Fused& f)
-{
-    if (!f.on) return;
-    f.on = false;
-    if (ctx->host_status) {
-        volatile unsigned* hs = ctx->host_status;
-        hs[0] = 1;
-        (void)hipStreamSynchronize(ctx->stream3);
-        (void)hipStreamSynchronize(ctx->stream);
-        if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
-        hs[0] = 0;
-    }
+    return launch_potf2(ctx, A, ld, sb, 0, 3, 0.0, inv, IB, nullptr, cest);
 }
 
 // Factor the kb-wide column block starting at column k (rows k..n), which must already carry every update of the
@@ -201,26 +79,11 @@ static void fused_abort(fr_ctx* ctx, Fused& f)
 // the first with ONE GEMM of depth kb/2 (instead of a depth-128 GEMM per 128 columns) -- the read-modify-write of the
 // result tile is a fixed cost per tile, so the deeper the contraction the closer the GEMM runs to the MFMA rate.
 static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
-                        double sub, double* dinv, int64_t* info, double* T, const Fused* f = nullptr)
+                        double sub, double* dinv, int64_t* info, double* T)
 {
-    // experimental: row-tile kernels; the diagonal blocks are factored by the resident server
-    if (f && f->on && ctx->panel_fused == 2) return launch_panel_tiles(ctx, A, ld, n, k, kb, dinv, f->ready, f->done, f->tdone);
-    // diagonal block first (per-block launches on its kb rows only), then ONE launch for all the rows below it: left-looking
-    // row tiles, no waiting (panel.hip)
-    if (ctx->panel_fused == 4 && kb > IB && n - (k + kb) >= IB && !ctx->refine_now && mode != 3) {
-        FR_TRY(factor_panel(ctx, A, ld, k + kb, k, kb, col0, mode, sub, dinv, info, T, f));
-        return launch_panel_rest(ctx, A, ld, n, k, kb, dinv);
-    }
     if (kb <= IB) {
         double* inv = dinv + (k / IB) * INV_ELEMS;
-        if (f && f->on && ctx->panel_fused != 3) {
-            // the block goes to the resident server (its own CU: ~55 us per block whatever else runs, instead of 150 - 265 us
-            // next to the trailing update) and the stream waits for it
-            const int64_t g = k / IB;
-            FR_TRY(launch_server_block(ctx, f->ready + 4 * g, f->done + g, ctx->dev_status));
-        } else {
-            FR_TRY(factor_block128(ctx, A + k + k * ld, ld, kb, col0 + k, mode, sub, inv, info, T));
-        }
+        FR_TRY(factor_block128(ctx, A + k + k * ld, ld, kb, col0 + k, mode, sub, inv, info, T));
         const int64_t below = n - (k + kb);
         if (below > 0) {
             // K5: panel TRSM  B <- B * L_kk^-T  as a GEMM against the explicit inverse (in place: one tile column)
@@ -249,140 +112,14 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
         return FR_OK;
     }
     const int64_t kb1 = ((kb / IB + 1) / 2) * IB;  // first half, a multiple of 128
-    FR_TRY(factor_panel(ctx, A, ld, n, k, kb1, col0, mode, sub, dinv, info, T, f));
+    FR_TRY(factor_panel(ctx, A, ld, n, k, kb1, col0, mode, sub, dinv, info, T));
     const int64_t below = n - (k + kb1);
     if (below > 0) {
         const double* P1 = A + (k + kb1) + k * ld;  // rows below the first half, its kb1 columns
         FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, kb - kb1, kb1, P1, ld, false, P1, ld, false, -1.0, 1.0,
                     A + (k + kb1) + (k + kb1) * ld, ld));
     }
-    return factor_panel(ctx, A, ld, n, k + kb1, kb - kb1, col0, mode, sub, dinv, info, T, f);
-}
-
-// The same factorisation with the panel chain cut down to what the NEXT diagonal block waits for (option panel_crit):
-// every product of the recursion is split by rows into the rows of the panel's own diagonal block (rows < dend: a handful
-// of tiles, launched on the panel stream, where the next diagonal-block kernel waits for them) and the bulk rows below
-// (launched on stream4, one step behind: nothing on the panel stream waits for them before the panel is finished).  With
-// ctx->reserve_now the critical launches run on the XCD the trailing update keeps off (gemm_f64.hip).
-static int factor_panel_cp(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t pk, int64_t pkb,
-                           int64_t col0, int mode, double sub, double* dinv, int64_t* info)
-{
-    const int64_t dend = pk + pkb;  // the panel is columns [pk, dend); rows below dend are bulk rows
-    const bool rest_kernel = ctx->panel_crit == 2;  // bulk rows: one left-looking launch per sub-panel (panel.hip)
-    hipStream_t S1 = ctx->stream2, SB = ctx->stream4;
-    const bool bulk = n > dend;
-    auto to_bulk = [&]() -> int {  // everything queued on the panel stream so far happens before what follows on stream4
-        FR_HIP(ctx, hipEventRecord(ctx->ev_cb, S1));
-        FR_HIP(ctx, hipStreamWaitEvent(SB, ctx->ev_cb, 0));
-        return FR_OK;
-    };
-    if (kb <= IB) {
-        double* inv = dinv + (k / IB) * INV_ELEMS;
-        ctx->ls = S1;
-        FR_TRY(factor_block128(ctx, A + k + k * ld, ld, kb, col0 + k, mode, sub, inv, info, nullptr));
-        const int64_t r0 = k + kb;
-        if (bulk) FR_TRY(to_bulk());
-        if (dend > r0)
-            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, dend - r0, kb, kb, A + r0 + k * ld, ld, false, inv, IB, false, 1.0, 0.0,
-                        A + r0 + k * ld, ld, false, 2));
-        if (bulk) {
-            ctx->ls = SB;
-            if (rest_kernel) {
-                const int sp = (int)((k - pk) / IB);
-                FR_TRY(launch_panel_rest_cols(ctx, A, ld, n, pk, pkb, dinv, sp, sp + 1));
-            } else {
-                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - dend, kb, kb, A + dend + k * ld, ld, false, inv, IB, false, 1.0, 0.0,
-                            A + dend + k * ld, ld, false, 3));
-            }
-            ctx->ls = S1;
-        }
-        return FR_OK;
-    }
-    const int64_t kb1 = ((kb / IB + 1) / 2) * IB;
-    FR_TRY(factor_panel_cp(ctx, A, ld, n, k, kb1, pk, pkb, col0, mode, sub, dinv, info));
-    const int64_t r0 = k + kb1;  // rows below the first half; the second half's own rows r0 .. k + kb are critical rows
-    const double* Q = A + r0 + k * ld;  // L(second-half rows, first-half columns): written by critical launches only
-    ctx->ls = S1;
-    if (bulk && !rest_kernel) FR_TRY(to_bulk());  // (Q is complete: its launches are already queued on the panel stream)
-    if (dend > r0)
-        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, dend - r0, kb - kb1, kb1, Q, ld, false, Q, ld, false, -1.0, 1.0, A + r0 + r0 * ld, ld,
-                    false, 2));
-    if (bulk && !rest_kernel) {
-        ctx->ls = SB;
-        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - dend, kb - kb1, kb1, A + dend + k * ld, ld, false, Q, ld, false, -1.0, 1.0,
-                    A + dend + r0 * ld, ld, false, 3));
-        ctx->ls = S1;
-    }
-    return factor_panel_cp(ctx, A, ld, n, k + kb1, kb - kb1, pk, pkb, col0, mode, sub, dinv, info);
-}
-
-// Chain-bound panels (option panel_rl, with at least two XCDs set aside): right-looking by 128-column blocks, and the chain
-// between two diagonal-block kernels is ONE single-workgroup launch (panel_step_kernel: the next diagonal row tile's solve
-// and its own rank-128 update).  Everything else runs beside the chain on stream4, on the helper XCDs (place 5):
-//   T(j): L[i, j] = A[i, j] W_j^T for the rows from block j + 2 on      -- after the diagonal-block kernel of block j
-//   U(j): A[i, c] -= L[i, j] L[c, j]^T, rows from block j + 2 on, columns of the panel's blocks > j  -- after step(j + 1)
-// and step(j + 2) waits for U(j).  Chain per block: diagonal-block kernel + one step, ~60 + ~40 us.
-static int factor_panel_rl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
-                           double sub, double* dinv, int64_t* info)
-{
-    hipStream_t S1 = ctx->stream2, SB = ctx->stream4;
-    const int64_t nblk = (kb + IB - 1) / IB;
-    const int64_t pend = k + kb;
-    auto chain_to_helpers = [&]() -> int {
-        FR_HIP(ctx, hipEventRecord(ctx->ev_cb, S1));
-        FR_HIP(ctx, hipStreamWaitEvent(SB, ctx->ev_cb, 0));
-        return FR_OK;
-    };
-    for (int64_t j = 0; j < nblk; ++j) {
-        const int64_t c = k + j * IB, cb = imin(IB, pend - c);
-        double* inv = dinv + (c / IB) * INV_ELEMS;
-        ctx->ls = S1;
-        if (j > 0) {
-            if (j > 1) FR_HIP(ctx, hipStreamWaitEvent(S1, ctx->ev_u, 0));  // U(j - 2): the last update of row tile j from outside
-            FR_TRY(launch_panel_step(ctx, A, ld, n, c, c - IB, IB, inv - INV_ELEMS));
-            // U(j - 1) needs L[j, j - 1]
-            FR_TRY(chain_to_helpers());
-            const int64_t r2 = c + IB;  // rows from block j + 1 on
-            if (n > r2) {
-                ctx->ls = SB;
-                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - r2, pend - c, IB, A + r2 + (c - IB) * ld, ld, false, A + c + (c - IB) * ld, ld,
-                            false, -1.0, 1.0, A + r2 + c * ld, ld, false, 5));
-                FR_HIP(ctx, hipEventRecord(ctx->ev_u, SB));
-                ctx->ls = S1;
-            }
-        }
-        FR_TRY(factor_block128(ctx, A + c + c * ld, ld, cb, col0 + c, mode, sub, inv, info, nullptr));
-        // T(j): the rows from block j + 2 on (row tile j + 1 is the next step's); the last block: every row below it
-        const int64_t r2 = (j + 1 < nblk) ? c + 2 * IB : c + cb;
-        if (n > r2) {
-            FR_TRY(chain_to_helpers());
-            ctx->ls = SB;
-            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - r2, cb, cb, A + r2 + c * ld, ld, false, inv, IB, false, 1.0, 0.0, A + r2 + c * ld, ld,
-                        false, 5));
-            ctx->ls = S1;
-        }
-    }
-    // the panel is finished when the helpers are
-    FR_HIP(ctx, hipEventRecord(ctx->ev_bulk, SB));
-    FR_HIP(ctx, hipStreamWaitEvent(S1, ctx->ev_bulk, 0));
-    return FR_OK;
-}
-
-// One panel of the look-ahead pipeline: the critical-path variant when it applies, and then the main stream is made to wait
-// for the bulk stream as well (the caller records ev_panel on the panel stream).
-static int factor_panel_la(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
-                           double sub, double* dinv, int64_t* info, double* T, const Fused* f, bool cp)
-{
-    if (ctx->panel_rl && ctx->reserve_now >= 2 && ctx->stream4 && !ctx->refine_now && mode != 3 && !(f && f->on) &&
-        ctx->panel_fused == 0 && kb > IB)
-        return factor_panel_rl(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info);
-    if (!cp) return factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T, f);
-    FR_TRY(factor_panel_cp(ctx, A, ld, n, k, kb, k, kb, col0, mode, sub, dinv, info));
-    if (n > k + kb) {
-        FR_HIP(ctx, hipEventRecord(ctx->ev_bulk, ctx->stream4));
-        FR_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_bulk, 0));  // ev_panel (recorded next) then covers both
-    }
-    return FR_OK;
+    return factor_panel(ctx, A, ld, n, k + kb1, kb - kb1, col0, mode, sub, dinv, info, T);
 }
 
 // Multi-GPU: block column b (width nb) of the matrix being factored is owned by rank b % world.
@@ -475,27 +212,8 @@ static int split_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k,
 // the panel then travels to every rank with one broadcast on the panel stream (so it overlaps the trailing updates
 // still running on the main stream), and every rank updates only the trailing block columns it owns.  Because every
 // panel is broadcast, each rank ends up holding the complete factor -- no final all-gather is needed.
-static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
-                              int64_t* info, int64_t nb, bool dist, const Fused* fz);
-
-// `pre`: a diagonal-block server started by the caller (before it queued the Gram assembly); otherwise one is started here.
 static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
-                         int64_t* info, int64_t nb, bool dist = false, Fused* pre = nullptr)
-{
-    if (n <= 0) return FR_OK;
-    Fused local;
-    Fused* f = pre ? pre : &local;
-    if (!pre) FR_TRY(fused_start(ctx, *f, A, ld, n, col0, mode, sub, dinv, info, nb, dist));
-    const int st = potrf_blocked_impl(ctx, A, ld, n, col0, mode, sub, dinv, info, nb, dist, f);
-    if (st != FR_OK) {
-        fused_abort(ctx, *f);
-        return st;
-    }
-    return fused_finish(ctx, *f, ctx->stream);
-}
-
-static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
-                              int64_t* info, int64_t nb, bool dist, const Fused* fz)
+                         int64_t* info, int64_t nb, bool dist = false)
 {
     if (n <= 0) return FR_OK;
     WsGuard tg(ctx), pg(ctx);
@@ -511,7 +229,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
     if (!la) {
         for (int64_t k = 0; k < n; k += nb) {
             const int64_t kb = imin(nb, n - k);
-            FR_TRY(factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T, fz));
+            FR_TRY(factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T));
             const int64_t rest = n - (k + kb);
             if (rest > 0) {
                 // K6: trailing update, lower triangle only
@@ -524,7 +242,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
     }
     double* pbuf = nullptr;
     int64_t split_rows = 0;
-    const bool split = world > 1 && ctx->panel_split != 0;
+    const bool split = world > 1 && ctx->dist_schedule != 0;
     if (world > 1) {
         // (split variant: head + W slices of whole 128-row blocks)
         split_rows = round_up((n + world - 1) / world, IB);
@@ -541,9 +259,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
     }
     hipStream_t S0 = ctx->stream, S1 = ctx->stream2;
     int st = FR_OK;
-    const bool cp = world == 1 && ctx->panel_crit && ctx->stream4 && !ctx->refine_now && mode != 3 &&
-                    !(fz && fz->on) && ctx->panel_fused == 0;
-    if (world == 1 && (ctx->xcd_reserve != 0 || ctx->xcd_reserve2 > 0 || ctx->la_merge) && ctx->claim_ring) {
+    if (world == 1 && ctx->xcd_reserve != 0 && ctx->claim_ring) {
         // claim counters of the launches that keep off the panel stream's XCD (gemm_f64.hip): one pair per launch
         FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 2 * kClaimSlots, S0));
         ctx->claim_next = 0;
@@ -552,7 +268,6 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (world > 1) comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
         ctx->ls = S0;
         ctx->reserve_now = 0;
-        if (ctx->stream4) (void)hipStreamSynchronize(ctx->stream4);
         (void)hipStreamSynchronize(S1);
         return code;
     };
@@ -573,7 +288,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (split) {
             st = split_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(0, nb, world));
         } else {
-            if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel_la(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, fz, cp);
+            if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T);
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
         }
         if (st != FR_OK) return fail(st);
@@ -590,50 +305,16 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         // (gemm_f64.hip / gemm_tile.hpp: claim_item)
         ctx->reserve_now = 0;
         ++ctx->panel_epoch;
-        if (world == 1 && ctx->claim_ring && !ctx->syrk_dynamic) {
+        if (world == 1 && ctx->claim_ring) {
             if (ctx->xcd_reserve < 0) {
                 // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
                 // own products are too large for one or two XCDs and every setting is neutral or worse
                 if (kb2 <= 512) ctx->reserve_now = rest <= 8192 ? 2 : (rest <= 16384 ? 1 : 0);  // (12288 .. 16384: the same to 1 %)
             } else {
-                if (ctx->xcd_reserve > 0 && (ctx->xcd_reserve_rest == 0 || rest <= ctx->xcd_reserve_rest)) ctx->reserve_now = (int)ctx->xcd_reserve;
-                if (ctx->xcd_reserve2 > 0 && rest <= ctx->xcd_reserve_rest2) ctx->reserve_now = (int)ctx->xcd_reserve2;
+                ctx->reserve_now = (int)ctx->xcd_reserve;  // explicit: that many XCDs for the whole factorisation
             }
         }
         const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
-        // Merged variant (option la_merge): look-ahead update and trailing update are ONE lower-mode launch over all `rest`
-        // rows, its tiles claimed column by column so that the next panel's columns come first; those tiles count themselves
-        // done and the panel stream waits for the count instead of for a separate launch (gemm_f64.hip).
-        // (measured in one process, fit at N = 32768: 194.4 / 195.4 -> 192.4 / 192.3 ms; at N <= 16384, where the panel chain waits
-        // for these tiles, +1 ... +3 %: the count-and-wait hand-off is slower than the launch boundary it replaces -- so only
-        // while more than la_merge rows remain)
-        // ... and no more than la_merge_max: above ~40000 rows the claimed tile order costs the trailing update more than the
-        // launch it saves (N = 40960 / 49152 / 65536 with the merge at every size: -0.4 / +0.6 / +1.1 %)
-        const bool merge = world == 1 && ctx->la_merge > 0 && rest > ctx->la_merge && rest <= ctx->la_merge_max && ctx->claim_ring &&
-                           ctx->claim_next + 2 < kClaimSlots && !ctx->syrk_dynamic;
-        if (merge) {
-            unsigned* la_ctr = ctx->claim_ring + 2 * ctx->claim_next++;
-            GemmDesc g;
-            g.M = rest; g.N = rest; g.K = kb;
-            g.A = P; g.lda = ld; g.a_kmajor = false;
-            g.B = P; g.ldb = ld; g.b_kmajor = false;
-            g.D = A + (k + kb) + (k + kb) * ld; g.ldd = ld;
-            g.Cin = g.D; g.ldcin = ld;
-            g.alpha = -1.0; g.beta = 1.0; g.lower = true; g.prof_cls = FR_PROF_SYRK;
-            g.la_cols = kb2; g.la_ctr = la_ctr;
-            st = launch_gemm(ctx, g);
-            if (st != FR_OK) return fail(st);
-            const int64_t Tt = (rest + IB - 1) / IB, lat = (kb2 + IB - 1) / IB;
-            const int64_t target = lat * Tt - lat * (lat - 1) / 2;  // tiles of the first `lat` tile columns of the lower triangle
-            ctx->ls = S1;
-            st = launch_wait_counter(ctx, la_ctr, (unsigned)target);
-            if (st == FR_OK) st = factor_panel_la(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, fz, cp);
-            if (st == FR_OK && ctx->reserve_now) st = launch_release_xcds(ctx, ctx->panel_epoch);
-            if (st != FR_OK) return fail(st);
-            if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
-            ctx->ls = S0;
-            continue;
-        }
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
         if (own_next) {
             // (profile class: panel -- the SYRK class times exactly the syrk_lower_f64_kernel launches)
@@ -647,7 +328,7 @@ static int potrf_blocked_impl(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int
         if (split) {
             st = split_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(k + kb, nb, world));
         } else {
-            if (own_next) st = factor_panel_la(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, fz, cp);
+            if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T);
             if (st == FR_OK && ctx->reserve_now) st = launch_release_xcds(ctx, ctx->panel_epoch);  // (on the panel stream)
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
         }
@@ -1035,7 +716,6 @@ static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t
     c->capacity = imax(capacity, 1);
     // a multiple of 128: the persistent solves (trsv.hip) read whole 128-row blocks, the rows behind the last one included
     c->ld_a = round_up(c->capacity, IB);
-    if (c->ld_a % 1024 == 0) c->ld_a += ctx->ld_pad;
     c->ld_x = c->ld_a;
     c->d = d;
     const int64_t nblk = (c->capacity + IB - 1) / IB;
@@ -1046,6 +726,7 @@ static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t
     if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->dinv, sizeof(double) * (size_t)nblk * INV_ELEMS);
     if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->info, sizeof(int64_t) * (size_t)c->info_cap);
     if (e == hipSuccess) e = dev_malloc(ctx, (void**)&c->cest, sizeof(double) * (size_t)nblk);
+    if (e == hipSuccess) e = hipMemsetAsync(c->cest, 0, sizeof(double) * (size_t)nblk, ctx->stream);  // (estimates exist only for blocks factored / inverted here)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         chol_release(c);
@@ -1204,19 +885,18 @@ static int assemble_and_factor_once(fr_chol* c, const fr_kprog* kernel, double n
     c->inv512_rows = 0;
     ++c->gen;
     FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
-    // the diagonal-block server takes its CU while the chip is still idle: before the Gram assembly is queued
-    Fused fz;
-    FR_TRY(fused_start(ctx, fz, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true));
-    int gst = launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank,
-                              c->nb);
-    if (gst != FR_OK) {
-        fused_abort(ctx, fz);
-        return gst;
-    }
-    FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true, &fz));
+    FR_HIP(ctx, hipMemsetAsync(c->cest, 0, sizeof(double) * (size_t)((c->capacity + IB - 1) / IB), ctx->stream));
+    FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank, c->nb));
+    FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true));
     FR_TRY(chol_fetch_info(c));
-    FR_TRY(fetch_max_cest(c));
-    if (ctx->world > 1) FR_TRY(merge_info(c));
+    if (ctx->world > 1) {
+        // sharded: a rank holds the estimates of the blocks it factored only, and the ranks would have to agree on a
+        // repeat -- the refinement policy does not apply (assemble_and_factor), so no estimate is reported either
+        c->max_cest = 0.0;
+        FR_TRY(merge_info(c));
+    } else {
+        FR_TRY(fetch_max_cest(c));
+    }
     if (c->fail_col >= 0)
         return set_err(ctx, FR_NOT_POSITIVE_DEFINITE,
                        has_eps ? "Cholesky decomposition failed even though we used `cholesky_epsilon` value of %g (column %lld)"
@@ -1258,6 +938,7 @@ static int chol_grow(fr_chol* c, int64_t required)
         if (e == hipSuccess)
             e = hipMemcpyAsync(nc.dinv, c->dinv, sizeof(double) * (size_t)nblk * INV_ELEMS, hipMemcpyDeviceToDevice,
                                ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nc.cest, c->cest, sizeof(double) * (size_t)nblk, hipMemcpyDeviceToDevice, ctx->stream);
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(nc.info, c->info, sizeof(int64_t) * (size_t)imin(c->info_cap, nc.info_cap),
@@ -1335,13 +1016,30 @@ int fr_chol_from_matrix(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, in
     if (n < 0 || lda < imax(n, 1)) return set_err(ctx, FR_SHAPE, "bad matrix shape");
     fr_chol* c = nullptr;
     FR_TRY(chol_alloc(ctx, n, n, 0, &c));
-    int st = upload_rows(ctx, A, lda, c->A, c->ld_a, n, n);
-    if (st == FR_OK) {
-        hipError_t e = hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream);
-        if (e != hipSuccess) st = set_err(ctx, FR_HIP_ERROR, "memset failed");
+    // refinement policy as in assemble_and_factor: factor; if a diagonal block turns out ill-conditioned (automatic mode),
+    // upload the matrix again and factor once more with the refinement step behind every product with an inverse block
+    c->refine = ctx->refine == 1;
+    int st = FR_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        st = upload_rows(ctx, A, lda, c->A, c->ld_a, n, n);
+        if (st == FR_OK && (hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream) != hipSuccess ||
+                            hipMemsetAsync(c->cest, 0, sizeof(double) * (size_t)((c->capacity + IB - 1) / IB), ctx->stream) != hipSuccess))
+            st = set_err(ctx, FR_HIP_ERROR, "memset failed");
+        if (st == FR_OK) {
+            ctx->refine_now = c->refine;
+            ctx->cur_cest = c->cest;
+            st = potrf_device(ctx, c, 0, n, has_eps ? 1 : 0, eps);
+            ctx->refine_now = false;
+            ctx->cur_cest = nullptr;
+        }
+        if (st == FR_OK) st = chol_fetch_info(c);
+        if (st == FR_OK) st = fetch_max_cest(c);
+        if (st == FR_OK && attempt == 0 && ctx->refine == -1 && !c->refine && c->max_cest > ctx->refine_threshold) {
+            c->refine = true;
+            continue;
+        }
+        break;
     }
-    if (st == FR_OK) st = potrf_device(ctx, c, 0, n, has_eps ? 1 : 0, eps);
-    if (st == FR_OK) st = chol_fetch_info(c);
     if (st == FR_OK && c->fail_col >= 0)
         st = set_err(ctx, FR_NOT_POSITIVE_DEFINITE, "Cholesky decomposition failed at column %lld", (long long)c->fail_col);
     if (st != FR_OK && st != FR_NOT_POSITIVE_DEFINITE) {
@@ -1375,65 +1073,82 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     if (n_old > 0) FR_TRY(check_zero_diag(c, "Cholesky::insert_column: Unable to solve lower triangular system!"));
     // (the cached 512-block inverses stay valid: rows below n_old are appended, blocks inside the old factor do not change)
     FR_TRY(chol_grow(c, n_all));
-    struct Scope {
-        fr_ctx* ctx;
-        ~Scope() { ctx->refine_now = false; }
-    } scope{ctx};
-    ctx->refine_now = c->refine;
     ++c->gen;  // cached alpha is stale; the targets cover n_old rows only and have to be handed over again
     c->nb = pick_nb(ctx, n_all);
     // new rows of the EMatrix mirror
     FR_TRY(upload_rows(ctx, Xall + n_old, ldx, c->X + n_old, c->ld_x, nb_new, d));
-    const int64_t ld = c->ld_a;
-    double* A21 = c->A + n_old;               // nb_new x n_old
-    double* A22 = c->A + n_old + n_old * ld;  // nb_new x nb_new
-    // K21 = k(new, old), K22 = lower(k(new, new)) + noise^2 I       (algebra/mod.rs:115-121)
-    FR_TRY(launch_gram_sym(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, d, noise * noise, A22, ld));
-    // L21 = K21 L11^-T ; K22 -= L21 L21^T ; L22 = chol(K22) with insert_column's plain sqrt (mode 2)
-    if (n_old >= 4 * IB && nb_new >= IB) {
-        // a short, wide block: solving from the right would be GEMMs of nb_new rows (four tile rows, ~120 launches); the
-        // transposed problem  L21^T = L11^-1 K12  is a forward solve with nb_new right-hand sides (tall GEMMs, 512-row
-        // leaves), then one transposition into place
-        WsGuard wg(ctx);
-        const int64_t ldw = round_up(n_old, kAlign);
-        double* W = wg.get(sizeof(double) * (size_t)ldw * (size_t)nb_new);
-        if (!W) return FR_OUT_OF_MEMORY;
-        FR_TRY(launch_gram_cross(ctx, *kernel, c->X, n_old, c->ld_x, c->X + n_old, nb_new, c->ld_x, d, W, ldw));
-        FR_TRY(trsm_lower_fwd(ctx, c, n_old, W, nb_new, ldw, FR_PROF_GEMM_PANEL));
-        FR_TRY(launch_transpose(ctx, W, n_old, nb_new, ldw, A21, ld));
-        FR_TRY(gemm(ctx, FR_PROF_SYRK, nb_new, nb_new, n_old, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
-    } else {
-        FR_TRY(launch_gram_cross(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, c->X, n_old, c->ld_x, d, A21, ld));
-        if (n_old > 0) {
-            FR_TRY(trsm_right_rec(ctx, c->A, ld, c->dinv, n_old, A21, nb_new, ld, FR_PROF_GEMM_PANEL));
+    // The append itself is restartable (everything it writes is recomputed from X and the old factor), which serves two
+    // purposes: a persistent L21 solve that gave up on a hand-off is repeated on the recursive path (solve_retry), and an
+    // append whose new diagonal blocks turn out ill-conditioned is repeated with iterative refinement (the policy of
+    // assemble_and_factor; the estimates come from the re-aligned inverse blocks).
+    auto append = [&]() -> int {
+        struct Scope {
+            fr_ctx* ctx;
+            ~Scope() { ctx->refine_now = false; }
+        } scope{ctx};
+        ctx->refine_now = c->refine;
+        c->n = n_old;
+        const int64_t ld = c->ld_a;
+        double* A21 = c->A + n_old;               // nb_new x n_old
+        double* A22 = c->A + n_old + n_old * ld;  // nb_new x nb_new
+        // K21 = k(new, old), K22 = lower(k(new, new)) + noise^2 I       (algebra/mod.rs:115-121)
+        FR_TRY(launch_gram_sym(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, d, noise * noise, A22, ld));
+        // L21 = K21 L11^-T ; K22 -= L21 L21^T ; L22 = chol(K22) with insert_column's plain sqrt (mode 2)
+        if (n_old >= 4 * IB && nb_new >= IB) {
+            // a short, wide block: solving from the right would be GEMMs of nb_new rows (four tile rows, ~120 launches); the
+            // transposed problem  L21^T = L11^-1 K12  is a forward solve with nb_new right-hand sides (tall GEMMs, 512-row
+            // leaves), then one transposition into place
+            WsGuard wg(ctx);
+            const int64_t ldw = round_up(n_old, kAlign);
+            double* W = wg.get(sizeof(double) * (size_t)ldw * (size_t)nb_new);
+            if (!W) return FR_OUT_OF_MEMORY;
+            FR_TRY(launch_gram_cross(ctx, *kernel, c->X, n_old, c->ld_x, c->X + n_old, nb_new, c->ld_x, d, W, ldw));
+            FR_TRY(trsm_lower_fwd(ctx, c, n_old, W, nb_new, ldw, FR_PROF_GEMM_PANEL));
+            FR_TRY(launch_transpose(ctx, W, n_old, nb_new, ldw, A21, ld));
             FR_TRY(gemm(ctx, FR_PROF_SYRK, nb_new, nb_new, n_old, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
+        } else {
+            FR_TRY(launch_gram_cross(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, c->X, n_old, c->ld_x, d, A21, ld));
+            if (n_old > 0) {
+                FR_TRY(trsm_right_rec(ctx, c->A, ld, c->dinv, n_old, A21, nb_new, ld, FR_PROF_GEMM_PANEL));
+                FR_TRY(gemm(ctx, FR_PROF_SYRK, nb_new, nb_new, n_old, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
+            }
         }
-    }
-    {
-        WsGuard tmp(ctx);
-        const int64_t nblk = (nb_new + IB - 1) / IB;
-        double* dinv_tmp = tmp.get(sizeof(double) * (size_t)nblk * INV_ELEMS);
-        if (!dinv_tmp) return FR_OUT_OF_MEMORY;
-        FR_TRY(potrf_blocked(ctx, A22, ld, nb_new, n_old, 2, 0.0, dinv_tmp, c->info, c->nb));
-    }
-    c->n = n_all;
-    // re-align the inverse blocks with the global 128-grid over the rows that changed
-    {
-        WsGuard tg(ctx);
-        double* T = tg.get(sizeof(double) * 64 * 64);
-        if (!T) return FR_OUT_OF_MEMORY;
+        {
+            WsGuard tmp(ctx);
+            const int64_t nblk = (nb_new + IB - 1) / IB;
+            double* dinv_tmp = tmp.get(sizeof(double) * (size_t)nblk * INV_ELEMS);
+            if (!dinv_tmp) return FR_OUT_OF_MEMORY;
+            FR_TRY(potrf_blocked(ctx, A22, ld, nb_new, n_old, 2, 0.0, dinv_tmp, c->info, c->nb));
+        }
+        c->n = n_all;
+        // re-align the inverse blocks with the global 128-grid over the rows that changed (and take their conditioning estimates)
         for (int64_t b = n_old / IB; b * IB < n_all; ++b) {
             const int64_t j = b * IB, sb = imin(IB, n_all - j);
-            FR_TRY(invert_block128(ctx, c->A + j + j * ld, ld, sb, c->dinv + b * INV_ELEMS, T));
+            FR_TRY(invert_block128(ctx, c->A + j + j * ld, ld, sb, c->dinv + b * INV_ELEMS, c->cest + b));
+        }
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return check_status_word(ctx);
+    };
+    int st = solve_retry(ctx, append);
+    if (st != FR_OK) {
+        c->n = n_old;
+        return st;
+    }
+    if (ctx->refine == -1 && ctx->world <= 1) {
+        FR_TRY(fetch_max_cest(c));
+        if (!c->refine && c->max_cest > ctx->refine_threshold) {
+            c->refine = true;  // an ill-conditioned appended block: once more with the refinement step behind every inverse product
+            st = solve_retry(ctx, append);
+            if (st != FR_OK) c->n = n_old;
         }
     }
-    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return FR_OK;
+    return st;
 }
 
 int fr_chol_info(const fr_chol* c, int64_t* n, int64_t* capacity, int64_t* d, int64_t* n_subst, int64_t* fail_col)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);  // (a concurrent refactor / add_rows on the same handle is legal: read a consistent state)
     if (n) *n = c->n;
     if (capacity) *capacity = c->capacity;
     if (d) *d = c->d;
@@ -1445,6 +1160,7 @@ int fr_chol_info(const fr_chol* c, int64_t* n, int64_t* capacity, int64_t* d, in
 int fr_chol_conditioning(const fr_chol* c, double* max_estimate, int* refined)
 {
     if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     if (max_estimate) *max_estimate = c->max_cest;
     if (refined) *refined = c->refine ? 1 : 0;
     return FR_OK;
@@ -1453,21 +1169,43 @@ int fr_chol_conditioning(const fr_chol* c, double* max_estimate, int* refined)
 int fr_chol_substitutions(const fr_chol* c, int64_t* idx, int64_t max_idx)
 {
     if (!c || (!idx && max_idx > 0)) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
     for (int64_t i = 0; i < c->n_subst && i < max_idx; ++i) idx[i] = c->subst[(size_t)i];
     return FR_OK;
+}
+
+// In-place solves on a DEVICE operand: a persistent solve that gave up leaves B partly overwritten, so the operand is saved
+// first whenever a persistent kernel may run (n x m doubles next to the 4 n^2 bytes of factor the solve streams) and put
+// back before the repeat on the recursive path.
+static int solve_in_place(fr_chol* c, double* B, int64_t m, int64_t ldb, bool both)
+{
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    const bool persistent = ctx->trsv && !c->refine && c->n > 0 && m > 0 && (m == 1 || use_column_groups(ctx, c, c->n, m));
+    WsGuard bk(ctx);
+    double* backup = nullptr;
+    if (persistent && is_device_ptr(B) && ldb >= c->n) {
+        backup = bk.get(sizeof(double) * (size_t)c->n * (size_t)m);
+        if (!backup) return FR_OUT_OF_MEMORY;
+        FR_TRY(launch_copy(ctx, B, ldb, backup, c->n, c->n, m));
+    }
+    bool first = true;
+    return solve_retry(ctx, [&]() -> int {
+        if (!first && backup) FR_TRY(launch_copy(ctx, backup, c->n, B, ldb, c->n, m));
+        first = false;
+        Staged b(ctx);
+        FR_TRY(b.inout(B, c->n, m, ldb));
+        FR_TRY(trsm_lower_fwd(ctx, c, c->n, b.dev, m, b.ld, FR_PROF_GEMM_SOLVE));
+        if (both) FR_TRY(trsm_lower_bwd(ctx, c, c->n, b.dev, m, b.ld, FR_PROF_GEMM_SOLVE));
+        return b.commit();  // (device operand: nothing to copy back, but commit reads the status of a persistent kernel)
+    });
 }
 
 int fr_chol_solve(fr_chol* c, double* B, int64_t m, int64_t ldb)
 {
     if (!c) return FR_INVALID_ARGUMENT;
     FR_LOCK(c->ctx);
-    fr_ctx* ctx = c->ctx;
-    FR_HIP(ctx, hipSetDevice(ctx->device));
-    Staged b(ctx);
-    FR_TRY(b.inout(B, c->n, m, ldb));
-    FR_TRY(trsm_lower_fwd(ctx, c, c->n, b.dev, m, b.ld, FR_PROF_GEMM_SOLVE));
-    FR_TRY(trsm_lower_bwd(ctx, c, c->n, b.dev, m, b.ld, FR_PROF_GEMM_SOLVE));
-    return b.commit();
+    return solve_in_place(c, B, m, ldb, true);
 }
 
 static int check_zero_diag(fr_chol* c, const char* what)
@@ -1486,19 +1224,22 @@ int fr_chol_solve_lower(fr_chol* c, double* B, int64_t m, int64_t ldb)
 {
     if (!c) return FR_INVALID_ARGUMENT;
     FR_LOCK(c->ctx);
-    fr_ctx* ctx = c->ctx;
-    FR_HIP(ctx, hipSetDevice(ctx->device));
+    FR_HIP(c->ctx, hipSetDevice(c->ctx->device));
     FR_TRY(check_zero_diag(c, "solve_lower_triangular"));
-    Staged b(ctx);
-    FR_TRY(b.inout(B, c->n, m, ldb));
-    FR_TRY(trsm_lower_fwd(ctx, c, c->n, b.dev, m, b.ld, FR_PROF_GEMM_SOLVE));
-    return b.commit();
+    return solve_in_place(c, B, m, ldb, false);
 }
+
+static int chol_inverse_impl(fr_chol* c, double* out, int64_t ldo);
 
 int fr_chol_inverse(fr_chol* c, double* out, int64_t ldo)
 {
     if (!c) return FR_INVALID_ARGUMENT;
     FR_LOCK(c->ctx);
+    return solve_retry(c->ctx, [&]() -> int { return chol_inverse_impl(c, out, ldo); });
+}
+
+static int chol_inverse_impl(fr_chol* c, double* out, int64_t ldo)
+{
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     Staged o(ctx);
@@ -1558,14 +1299,14 @@ int fr_chol_upload_l(fr_ctx* ctx, const double* L, int64_t n, int64_t ldl, const
         if (e != hipSuccess) st = set_err(ctx, FR_HIP_ERROR, "memset failed");
     }
     if (st == FR_OK) {
-        WsGuard tg(ctx);
-        double* T = tg.get(sizeof(double) * 64 * 64);
-        if (!T) st = FR_OUT_OF_MEMORY;
         for (int64_t b = 0; st == FR_OK && b * IB < n; ++b) {
             const int64_t j = b * IB, sb = imin(IB, n - j);
-            st = invert_block128(ctx, c->A + j + j * c->ld_a, c->ld_a, sb, c->dinv + b * INV_ELEMS, T);
+            st = invert_block128(ctx, c->A + j + j * c->ld_a, c->ld_a, sb, c->dinv + b * INV_ELEMS, c->cest + b);
         }
         if (st == FR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = FR_HIP_ERROR;
+        // the uploaded factor's conditioning decides whether this handle's solves take the refinement step (fr_ctx::refine)
+        if (st == FR_OK) st = fetch_max_cest(c);
+        if (st == FR_OK) c->refine = ctx->refine == 1 || (ctx->refine == -1 && c->max_cest > ctx->refine_threshold);
     }
     if (st != FR_OK) {
         fr_chol_free(c);

@@ -215,7 +215,13 @@ int Staged::inout(double* p, int64_t r, int64_t c, int64_t ldp)
 
 int Staged::commit()
 {
-    if (!owns || !host || rows == 0 || cols == 0) return FR_OK;
+    if (!owns || !host || rows == 0 || cols == 0) {
+        // device destination: nothing to copy and normally no synchronisation -- unless a persistent solve was launched since
+        // the last status check: its hand-offs can time out, and the caller must learn that before it trusts the result
+        if (!ctx->persistent_pending) return FR_OK;
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return check_status_word(ctx);
+    }
     FR_HIP(ctx, hipMemcpy2DAsync(host, sizeof(double) * host_ld, dev, sizeof(double) * ld, sizeof(double) * rows, cols,
                                  is_device_ptr(host) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -241,10 +247,12 @@ int ensure_status_word(fr_ctx* ctx)
 
 int check_status_word(fr_ctx* ctx)
 {
+    ctx->persistent_pending = false;
     if (!ctx->host_status) return FR_OK;
     volatile unsigned* s = ctx->host_status;
     if (s[0] != 0) {
         s[0] = 0;
+        ctx->solve_timeout_seen = true;
         return set_err(ctx, FR_HIP_ERROR, "a device-side wait timed out (persistent kernel hand-off); results are invalid");
     }
     return FR_OK;
@@ -330,6 +338,8 @@ int fr_ctx_create(fr_ctx** out, int device)
     fr_ctx* ctx = new fr_ctx();
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("FRIEDRICH_AMD_TEST_FORCE_SOLVE_TIMEOUT")) ctx->test_force_timeout = e[0] == '1';
+    if (const char* e = getenv("FRIEDRICH_AMD_TEST_MAX_WORKGROUPS")) ctx->test_max_wgs = atoi(e);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return FR_HIP_ERROR;
@@ -339,21 +349,17 @@ int fr_ctx_create(fr_ctx** out, int device)
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
     if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, lo) != hipSuccess ||  // resident for a whole fit: a busy HIGH-priority queue throttles the dispatch of every other queue (measured: +16 % on the trailing updates)
-        hipStreamCreateWithPriority(&ctx->stream4, hipStreamNonBlocking, hi) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_cb, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, hi) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_bulk, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_u, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_server, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_diag, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_la, hipEventDisableTiming) != hipSuccess) {
         fr_ctx_destroy(ctx);
         return FR_HIP_ERROR;
     }
-    if (hipMalloc((void**)&ctx->yield_word, 64) != hipSuccess || hipMemset(ctx->yield_word, 0, 64) != hipSuccess ||
+    if (hipMalloc((void**)&ctx->xcc_word, 64) != hipSuccess || hipMemset(ctx->xcc_word, 0, 64) != hipSuccess ||
         hipMalloc((void**)&ctx->claim_ring, sizeof(unsigned) * 2 * kClaimSlots) != hipSuccess ||
-        hipMalloc((void**)&ctx->dyn_ring, sizeof(unsigned) * 2 * 256) != hipSuccess ||
-        hipMalloc((void**)&ctx->step_flags, 64) != hipSuccess || hipMemset(ctx->step_flags, 0, 64) != hipSuccess) {
+        hipMalloc((void**)&ctx->dyn_ring, sizeof(unsigned) * 2 * 256) != hipSuccess) {
         fr_ctx_destroy(ctx);
         return FR_HIP_ERROR;
     }
@@ -376,28 +382,18 @@ void fr_ctx_destroy(fr_ctx* ctx)
     for (auto& b : ctx->pool)
         if (b.p) (void)hipFree(b.p);
     if (ctx->trsv_gran) (void)hipFree(ctx->trsv_gran);
-    if (ctx->syrk_ctr) (void)hipFree(ctx->syrk_ctr);
     if (ctx->trsmn_buf) (void)hipFree(ctx->trsmn_buf);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->yield_word) (void)hipFree(ctx->yield_word);
+    if (ctx->xcc_word) (void)hipFree(ctx->xcc_word);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
-    if (ctx->stream4) {
-        (void)hipStreamSynchronize(ctx->stream4);
-        (void)hipStreamDestroy(ctx->stream4);
-    }
-    if (ctx->ev_cb) (void)hipEventDestroy(ctx->ev_cb);
-    if (ctx->ev_bulk) (void)hipEventDestroy(ctx->ev_bulk);
-    if (ctx->ev_u) (void)hipEventDestroy(ctx->ev_u);
     if (ctx->claim_ring) (void)hipFree(ctx->claim_ring);
-    if (ctx->step_flags) (void)hipFree(ctx->step_flags);
     if (ctx->dyn_ring) (void)hipFree(ctx->dyn_ring);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
         (void)hipStreamDestroy(ctx->stream3);
     }
-    if (ctx->ev_server) (void)hipEventDestroy(ctx->ev_server);
-    if (ctx->panel_flags) (void)hipFree(ctx->panel_flags);
-    if (ctx->panel_dbg) (void)hipHostFree(ctx->panel_dbg);
+    if (ctx->ev_bulk) (void)hipEventDestroy(ctx->ev_bulk);
+    if (ctx->ev_diag) (void)hipEventDestroy(ctx->ev_diag);
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamDestroy(ctx->stream2);
@@ -444,8 +440,23 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->lookahead = value != 0;
         return FR_OK;
     }
-    if (!strcmp(name, "gemm_tile")) {
-        ctx->gemm_tile = value;
+    if (!strcmp(name, "nb_switch_rows")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "nb_switch_rows must be >= 0");
+        ctx->nb_switch_rows = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "xcd_reserve")) {
+        if (value < -1 || value > 4) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve must be in [-1, 4]");
+        ctx->xcd_reserve = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "dist_schedule")) {
+        if (value < 0 || value > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "dist_schedule must be 0 (broadcast), 1 (split) or 2 (diagonal chain first)");
+        ctx->dist_schedule = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "splitk")) {
+        ctx->splitk = value != 0;
         return FR_OK;
     }
     if (!strcmp(name, "narrow_max")) {
@@ -458,157 +469,26 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->narrow_batched_max = value;
         return FR_OK;
     }
-    if (!strcmp(name, "gemm_lower_probe")) {
-        ctx->gemm_lower_probe = value != 0;
-        return FR_OK;
-    }
-    if (!strcmp(name, "splitk")) {
-        ctx->splitk = value != 0;
-        return FR_OK;
-    }
-    if (!strcmp(name, "panel_debug")) {
-        ctx->panel_debug = value;
-        if (value == 4) {  // developer probe: allocate the stamp buffer (trsv backward stamps)
-            if (!ctx->panel_dbg) {
-                void* h = nullptr;
-                FR_HIP(ctx, hipHostMalloc(&h, sizeof(unsigned long long) * 4 * 1024, hipHostMallocMapped));
-                ctx->panel_dbg = (unsigned long long*)h;
-            }
-            memset(ctx->panel_dbg, 0, sizeof(unsigned long long) * 4 * 1024);
-            ctx->panel_debug = 1;
-            return FR_OK;
-        }
-        if (value == 5 && ctx->panel_dbg) {  // dump trsv backward stamps: per block, relative to the previous block's publish
-            const unsigned long long* t = ctx->panel_dbg;
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-            int cnt = 0;
-            for (int j = 0; j + 1 < 512; ++j) {
-                if (!t[8 * j + 4] || !t[8 * (j + 1) + 4]) continue;
-                // block j follows block j + 1 in the backward sweep
-                a0 += (double)(t[8 * j + 0] - t[8 * (j + 1) + 4]);  // publish of j+1 -> last FMA of j done
-                a1 += (double)(t[8 * j + 1] - t[8 * j + 0]);        // first reduction
-                a2 += (double)(t[8 * j + 2] - t[8 * j + 1]);        // b load, tv, inverse fetch, barrier
-                a3 += (double)(t[8 * j + 3] - t[8 * j + 2]);        // product + second reduction
-                a4 += (double)(t[8 * j + 4] - t[8 * j + 3]);        // publish
-                ++cnt;
-            }
-            if (cnt)
-                fprintf(stderr, "trsv backward, %d steps (us): hand-off + last tile %.2f, reduce %.2f, b/tv/inverse/barrier %.2f, product + reduce %.2f, publish %.2f\n",
-                        cnt, a0 / cnt / 100, a1 / cnt / 100, a2 / cnt / 100, a3 / cnt / 100, a4 / cnt / 100);
-            return FR_OK;
-        }
-        if (value == 2 && ctx->panel_dbg) {  // dump the last factorisation's server time stamps (us, relative)
-            const unsigned long long* t = ctx->panel_dbg;
-            double wait = 0, fac = 0, pub = 0;
-            int cnt = 0;
-            for (int g = 1; g < 1024 && t[4 * g + 3]; ++g) {
-                wait += (double)(t[4 * g + 1] - t[4 * (g - 1) + 3]);
-                fac += (double)(t[4 * g + 2] - t[4 * g + 1]);
-                pub += (double)(t[4 * g + 3] - t[4 * g + 2]);
-                ++cnt;
-            }
-            if (getenv("FR_PANEL_DEBUG_VERBOSE")) {
-                for (int g = 1; g < 40 && t[4 * g + 3]; ++g)
-                    fprintf(stderr, "  block %d: outside %.1f us, factor %.1f us\n", g, (double)(t[4 * g + 1] - t[4 * (g - 1) + 3]) / 100.0,
-                            (double)(t[4 * g + 2] - t[4 * g + 1]) / 100.0);
-            }
-            if (cnt)
-                fprintf(stderr, "panel server: %d blocks, per block: turnaround outside the server %.1f us, factor %.1f us, publish %.1f us\n",
-                        cnt, wait / cnt / 100.0, fac / cnt / 100.0, pub / cnt / 100.0);
-            ctx->panel_debug = 1;
-        }
-        return FR_OK;
-    }
-    if (!strcmp(name, "panel_fused")) {
-        if (value < 0 || value > 4) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_fused must be 0 .. 4");
-        ctx->panel_fused = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "panel_split")) {
-        ctx->panel_split = value != 0;
-        return FR_OK;
-    }
-    if (!strcmp(name, "xcd_reserve")) {
-        if (value < -1 || value > 4) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve must be in [-1, 4]");
-        ctx->xcd_reserve = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "xcd_reserve2")) {
-        if (value < 0 || value > 4) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve2 must be in [0, 4]");
-        ctx->xcd_reserve2 = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "xcd_reserve_rest2")) {
-        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve_rest2 must be >= 0");
-        ctx->xcd_reserve_rest2 = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "xcd_reserve_rest")) {
-        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve_rest must be >= 0");
-        ctx->xcd_reserve_rest = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "bulk_xcd_tiles")) {
-        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "bulk_xcd_tiles must be >= 0");
-        ctx->bulk_xcd_tiles = value;
-        return FR_OK;
-    }
     if (!strcmp(name, "narrow_pair_min")) {
         if (value < -1) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow_pair_min must be >= -1");
         ctx->narrow_pair_min = value;
         return FR_OK;
     }
-    if (!strcmp(name, "la_merge_claimed")) {
-        ctx->la_merge_claimed = value != 0;
+    if (!strcmp(name, "leaf512")) {
+        ctx->leaf512 = value != 0;
         return FR_OK;
     }
-    if (!strcmp(name, "splitk_slice")) {
-        ctx->splitk_slice = value < 64 ? 64 : value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "splitk_tiles")) {
-        ctx->splitk_tiles = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "splitk_mink")) {
-        ctx->splitk_mink = value < 256 ? 256 : value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "splitk_target")) {
-        ctx->splitk_target = value < 1 ? 1 : value;
+    if (!strcmp(name, "trsv")) {
+        ctx->trsv = value != 0;
         return FR_OK;
     }
     if (!strcmp(name, "tri_inverse")) {
         ctx->tri_inverse = value != 0;
         return FR_OK;
     }
-    if (!strcmp(name, "la_merge_max")) {
-        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "la_merge_max must be >= 0");
-        ctx->la_merge_max = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "la_merge")) {
-        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "la_merge must be >= 0");
-        ctx->la_merge = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "nb_switch_rows")) {
-        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "nb_switch_rows must be >= 0");
-        ctx->nb_switch_rows = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "panel_rl")) {
-        if (value < 0 || value > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_rl must be 0, 1 or 2");
-        ctx->panel_rl = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "panel_crit")) {
-        if (value < 0 || value > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_crit must be 0, 1 or 2");
-        ctx->panel_crit = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "k4_yield")) {
-        ctx->k4_yield = value != 0;
+    if (!strcmp(name, "predict_assoc")) {
+        if (value != 0 && value != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "predict_assoc must be 0 or 1");
+        ctx->predict_assoc = value;
         return FR_OK;
     }
     if (!strcmp(name, "refine")) {
@@ -621,34 +501,24 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->refine_threshold = (double)value;
         return FR_OK;
     }
-    if (!strcmp(name, "syrk_dynamic_tiles")) {
-        if (value < 1 || value > 1024) return set_err(ctx, FR_INVALID_ARGUMENT, "syrk_dynamic_tiles must be in [1, 1024]");
-        ctx->syrk_dynamic_tiles = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "syrk_dynamic")) {
-        ctx->syrk_dynamic = value != 0;
-        return FR_OK;
-    }
-    if (!strcmp(name, "trsv")) {
-        ctx->trsv = value != 0;
-        return FR_OK;
-    }
-    if (!strcmp(name, "leaf512")) {
-        ctx->leaf512 = value != 0;
-        return FR_OK;
-    }
-    if (!strcmp(name, "ld_pad")) {
-        if (value < 0 || value % kAlign != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "ld_pad must be a multiple of 64");
-        ctx->ld_pad = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "predict_assoc")) {
-        if (value != 0 && value != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "predict_assoc must be 0 or 1");
-        ctx->predict_assoc = value;
-        return FR_OK;
-    }
     return set_err(ctx, FR_INVALID_ARGUMENT, "unknown option %s", name);
+}
+
+int fr_ctx_get_counter(fr_ctx* ctx, const char* name, int64_t* out)
+{
+    if (!ctx || !name || !out) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
+    if (!strcmp(name, "solve_retries")) {
+        *out = ctx->solve_retries;
+        return FR_OK;
+    }
+    if (!strcmp(name, "pool_bytes")) {
+        size_t b = 0;
+        for (auto& d : ctx->pool) b += d.cap;
+        *out = (int64_t)b;
+        return FR_OK;
+    }
+    return set_err(ctx, FR_INVALID_ARGUMENT, "unknown counter %s", name);
 }
 
 int fr_inputs_to_device(fr_ctx* ctx, int layout, const void* data, int64_t n, int64_t d, int64_t stride, double** out_dev,

@@ -47,34 +47,39 @@ struct fr_ctx {
     bool own_stream = true;
     hipStream_t ls = nullptr;       // stream the kernel launchers enqueue on (== stream except inside look-ahead)
     hipStream_t stream2 = nullptr;  // high-priority panel stream of the look-ahead Cholesky
-    hipEvent_t ev_panel = nullptr, ev_la = nullptr;
-    int64_t lookahead = 1;
+    hipStream_t stream3 = nullptr;  // sharded factorisation: the bulk rows of a panel (solves + all-gather) off the diagonal chain
+    hipEvent_t ev_panel = nullptr, ev_la = nullptr, ev_diag = nullptr, ev_bulk = nullptr;
     std::string err;
     // grow-only workspace pool (stream-ordered reuse inside one context)
     std::vector<fr::DevBuf> pool;
-    // options
-    int64_t nb = 0;         // outer Cholesky block; 0 = chosen from the matrix size (pick_nb)
-    int64_t gemm_tile = 0;      // tile-order experiments (gemm_f64.hip)
-    int64_t ld_pad = 0;         // probe: elements added to a factor's leading dimension when it is a multiple of 1024
+    // ---- options (fr_ctx_set_option) ----
+    int64_t nb = 0;             // outer Cholesky block; 0 = chosen from the matrix size (pick_nb)
+    int64_t lookahead = 1;      // the next panel is factored on the panel stream under the trailing update
+    int64_t nb_switch_rows = 16384;  // automatic nb = 1024: panels of 512 columns once at most this many rows remain (0: never)
+    // XCD reservation (gemm_f64.hip): the main stream's GEMM launches of a factorisation leave the first `reserve_now` XCDs
+    // (counted from the one the diagonal-block kernels run on) to the panel stream -- their workgroups there exit at once
+    int64_t xcd_reserve = -1;   // -1: chosen by the factorisation (single GPU, nb <= 512: 1 XCD below 16384 rows, 2 below 8192); 0: never; 1 .. 4: always
+    int64_t dist_schedule = 2;  // sharded factorisation, panel step: 0 owner solves the whole panel + one broadcast; 1 diagonal block
+                                // broadcast, rows scattered / solved per rank / all-gathered; 2 as 1 with the diagonal chain running ahead
+                                // (diagonal block sent to the next owner first, bulk rows on their own stream: chol.hip)
     int64_t splitk = 1;         // GEMMs with few result tiles and a deep contraction are cut along K (gemm_f64.hip)
-    int64_t narrow_batched_max = -1;  // right-hand sides up to which the persistent solve runs in column groups of 16 (trsm_narrow.hip); -1: chosen from n and m (chol.hip)
     int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
-    int64_t gemm_lower_probe = 0;  // probe: fr_gemm computes only the lower-triangular tile set of a square result
-    bool potf2_lds_set = false;  // dynamic-LDS attribute of the diagonal-block kernel applied on this device
-    bool potf2_server_lds_set = false;
-    // Experimental panel-factorisation variants, measured in round 2 and NOT adopted: 0 (default): one
-    // diagonal-block launch per 128 columns; 1: the diagonal blocks go to a resident server workgroup on a CU of its own
-    // (potf2.hip), handed over at stream level; 2: fused row-tile kernels (panel.hip); 3: probe (server resident, unused)
-    int64_t panel_fused = 0;
-    hipStream_t stream3 = nullptr;  // the diagonal-block server's stream
-    hipEvent_t ev_server = nullptr;
-    int* panel_flags = nullptr;     // ready (4 per 128-block) / done (1) / tdone (4), grow-only
-    size_t panel_flags_cap = 0;     // ints
-    unsigned server_token = 0;
-    int64_t panel_debug = 0;              // developer probe: the server records time stamps per block
-    unsigned long long* panel_dbg = nullptr;  // host-mapped, 4 x 1024 entries
+    int64_t narrow_batched_max = -1;  // right-hand sides up to which the persistent solve runs in column groups of 16 (trsm_narrow.hip); -1: chosen from n and m (chol.hip)
+    int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0: never, -1: by size)
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
+    int64_t trsv = 1;           // solves with few right-hand sides as one persistent launch per direction (trsv.hip, trsm_narrow.hip)
+    int64_t tri_inverse = 1;    // gradient terms: L^-1 and W^T W skip the structural zeros (chol_tri_inverse); 0: dense products
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
+    // Products with explicit inverse blocks lose a factor cond(L_bb) of backward accuracy against substitution.  refine:
+    // -1 (default) automatic -- a factorisation whose diagonal blocks turn out ill-conditioned (estimate from the
+    // diagonal-block kernel above refine_threshold) is repeated with one step of iterative refinement behind every such
+    // product, and the handle keeps refining (factor, add_rows, solves); 0 never; 1 always
+    int64_t refine = -1;
+    double refine_threshold = 30.0;
+    // ---- state ----
+    bool potf2_lds_set = false;  // dynamic-LDS attributes applied on this device (per context = per device)
+    bool trsv_lds_set = false;
+    bool prior_lds_set = false;
     // profiling
     bool prof = false;
     unsigned prof_mask = ~0u;
@@ -84,66 +89,27 @@ struct fr_ctx {
     int64_t prof_launches[FR_PROF_COUNT] = {0};
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
-    // cooperative yield: GEMM waves sleep while the diagonal-block kernel works on their CU (gemm_tile.hpp)
-    // sharded factorisation: 0 (default) the owner solves the whole panel and broadcasts it; 1: the owner factors the
-    // nb x nb diagonal block only, the rows below are scattered, every rank solves its share, one all-gather returns them
-    int64_t panel_split = 0;
-    // XCD reservation (gemm_f64.hip): the main stream's GEMM launches of a factorisation leave the first `xcd_reserve` XCDs
-    // to the panel stream (their workgroups there exit at once) while the trailing matrix has at most `xcd_reserve_rest` rows
-    int64_t xcd_reserve = -1;  // -1: chosen by the factorisation (single GPU, nb <= 512: 1 XCD below 16384 rows, 2 below 8192)
-    int64_t xcd_reserve_rest = 0;  // 0: whenever xcd_reserve > 0
-    int64_t xcd_reserve2 = 0, xcd_reserve_rest2 = 0;  // second tier: this many XCDs once the trailing matrix is this small
     int reserve_now = 0;           // XCDs reserved right now (set by the factorisation around the launches it applies to)
     unsigned panel_epoch = 0;      // number of the panel being factored on the panel stream (see claim_item)
-    int64_t tri_inverse = 1;       // gradient terms: L^-1 and W^T W skip the structural zeros (chol_tri_inverse); 0: dense products
+    unsigned* xcc_word = nullptr;    // device: [0] = 1 + XCC_ID of the XCD the diagonal-block kernels run on (0: unknown), [1] = last panel whose chain is finished
     unsigned* dyn_ring = nullptr;    // device: counter pairs of `dynamic` launches outside a factorisation, zeroed one by one
     int64_t dyn_next = 0;
     unsigned* claim_ring = nullptr;  // device: {tile counter, retire counter} per reserved launch of a factorisation
     int64_t claim_next = 0;
-    int64_t bulk_xcd_tiles = 0;    // bulk launches of at most this many tiles run ON the reserved XCD
-    int* step_flags = nullptr;     // device: the four slice flags of panel_step4_kernel (monotonic target step_epoch)
-    int step_epoch = 0;
-    int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0: never, -1: by size)
-    // split-K rule of launch_gemm (gemm_f64.hip): products of at most splitk_tiles result tiles and a contraction of at least
-    // splitk_mink are cut into ~splitk_target / tiles slices.  Round 1 used 192 / 2048 / 384; measured with 256 / 512 / 512
-    // (scripts/splitk_ab.py): forward solve of 512 / 1024 / 2048 / 4096 columns at n = 32768: 18.7 / 26.6 / 41.6 / 70.6 ->
-    // 14.0 / 22.1 / 37.6 / 68.3 ms, 1024 columns at n = 8192: 3.45 -> 2.48 ms, fits -1 %
-    int64_t splitk_tiles = 256, splitk_mink = 512, splitk_target = 512, splitk_slice = 128;  // (slices of 128: another -8 ... -13 % on 512 ... 1024 columns)
-    int64_t la_merge_max = 36864;
-    int64_t la_merge_claimed = 1;  // merged launches claim their tiles (0: static order, next panel's tiles first, then per-XCD runs:
-                                   // measured neutral at every size, the claimed order -0.6 ... -0.8 % at N = 24576 ... 32768)
-    int64_t la_merge = 0;          // > 0: look-ahead update and trailing update as ONE launch while more than this many rows remain.
-                                   // OFF by default: the panel stream then WAITS IN A KERNEL for tiles of a concurrently running launch, which
-                                   // never arrives when a tool serialises kernel execution (rocprofv3 --pmc does: the wait times out, the
-                                   // fit reports FR_HIP_ERROR) -- not worth the 0.6 ... 1.3 % it gains at N = 24576 ... 32768
-    int64_t nb_switch_rows = 16384;  // automatic nb = 1024: panels of 512 columns once at most this many rows remain (0: never)
-    int64_t panel_rl = 0;          // chain-bound panels: per-block right-looking schedule (chol.hip, factor_panel_rl)
-    hipEvent_t ev_u = nullptr;
-    int64_t panel_crit = 0;        // panel factorisation split into critical rows (panel stream) and bulk rows (stream4)
-    hipStream_t stream4 = nullptr;
-    hipEvent_t ev_cb = nullptr, ev_bulk = nullptr;
-    int64_t k4_yield = 0;  // measured: K4 153 -> 106 us at N = 16384, but the extra load in the pinned K-loop costs the GEMMs 12 - 35 %
-    unsigned* yield_word = nullptr;  // device
-    int64_t syrk_dynamic = 0;   // trailing update: tiles pulled from per-XCD work lists by resident workgroups (gemm_f64.hip)
-    unsigned* syrk_ctr = nullptr;
-    int64_t syrk_dynamic_tiles = 3;
-    // Products with explicit inverse blocks lose a factor cond(L_bb) of backward accuracy against substitution.  refine:
-    // -1 (default) automatic -- a factorisation whose diagonal blocks turn out ill-conditioned (estimate from the
-    // diagonal-block kernel above refine_threshold) is repeated with one step of iterative refinement behind every such
-    // product, and the handle keeps refining (factor, add_rows, solves); 0 never; 1 always
-    int64_t refine = -1;
-    double refine_threshold = 30.0;
     bool refine_now = false;      // state of the running operation (set under the context lock)
     double* cur_cest = nullptr;   // where the diagonal-block kernel of the running factorisation puts its estimates
-    int64_t trsv = 1;           // single right-hand-side solves as one persistent launch per direction (trsv.hip)
     // device-side waits report a timeout here (host-mapped, so the host can read it after any synchronisation)
     unsigned* host_status = nullptr;
     unsigned* dev_status = nullptr;
+    bool solve_timeout_seen = false;  // a persistent solve timed out on this context: the entry point re-runs on the recursive path
+    bool persistent_pending = false;  // a persistent solve was launched since the last check_status_word
+    int64_t solve_retries = 0;        // how often that happened (fr_ctx_get_counter)
+    int test_max_wgs = 0;             // FRIEDRICH_AMD_TEST_MAX_WORKGROUPS at context creation: cap on the grid of the persistent solves (tests: many blocks per workgroup)
+    bool test_force_timeout = false;  // FRIEDRICH_AMD_TEST_FORCE_SOLVE_TIMEOUT=1 at context creation: every persistent solve reports a timeout (tests of the retry)
     int num_cus = 256;
     // hand-off granules of the persistent solves (grow-only)
     void* trsv_gran = nullptr;
     size_t trsv_gran_cap = 0;
-    bool trsv_lds_set = false;
     // pinned bounce buffer of the host <-> device staging (grow-only)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -327,13 +293,6 @@ struct GemmDesc {
     int64_t own_nb = 1, own_col0 = 0;
     // batched launch: `batch` independent problems of the same shape, operands `batch_*` elements apart
     int64_t batch = 1, batch_a = 0, batch_b = 0, batch_c = 0, batch_d = 0;
-    // XCD reservation (while ctx->reserve_now): 0 = keep off the panel stream's XCD unless launched on the panel stream,
-    // 2 = critical-path launch, ON the panel stream's XCD; 3 = bulk launch, on that XCD when it is small
-    int place = 0;
-    // lower mode, merged look-ahead: the first la_cols columns are the next panel's; their tiles are computed first and counted
-    // on *la_ctr (device word, zero before the launch)
-    int64_t la_cols = 0;
-    unsigned* la_ctr = nullptr;
     int tri = 0;  // triangular operands: see GemmArgs::tri (gemm_tile.hpp)
     // tiles claimed in dispatch order instead of dealt per XCD: for launches whose tiles differ in length (tri), where equal
     // tile counts per XCD are unequal work
@@ -341,45 +300,12 @@ struct GemmDesc {
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 int launch_release_xcds(fr_ctx* ctx, unsigned epoch);  // on ctx->ls: the chain of panel `epoch` is finished
-int claim_setup(fr_ctx* ctx, int place, int64_t items, const unsigned** xcc_word, unsigned** claim, unsigned* max_exit,
-                int64_t* grid, bool force = false);
-int launch_wait_counter(fr_ctx* ctx, const unsigned* ctr, unsigned target);  // on ctx->ls
 
 // K4: factor one diagonal block (nbk <= 128) and emit its explicit inverse (inv may be NULL).
 //   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows),
 //   mode 3: the block already holds a factor, only the inverse is produced
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub,
                  double* inv, int64_t ldinv, int64_t* info, double* cest = nullptr);
-
-// Fused panel factorisation (potf2.hip server + panel.hip row tiles).  Flags: one int per 128-block of the matrix.
-struct ServerArgs {
-    double* A;        // the n x n matrix being factored (lower triangle), block g at A + 128 g (lda + 1)
-    int64_t lda, n, col0;
-    int mode;
-    double sub;
-    double* dinv;     // inverse of block g at dinv + g * 128 * 128
-    double* cest;     // conditioning estimate of block g, or NULL
-    int64_t* info;
-    int* ready;       // [4 g + a] = 1: 32-row slice a of diagonal block g carries every update; all four: it may be factored
-    int* done;        // [g] = 1: block g factored, inverse written
-    unsigned* status; // host-visible: [0] timeout word, [1] <- token when the server workgroup is resident
-    unsigned token;
-    unsigned long long* dbg;  // developer probe: 4 time stamps per block, or NULL
-    int nblocks;
-    int own_world, own_rank;
-    int64_t own_nb;
-};
-int launch_potf2_server(fr_ctx* ctx, hipStream_t stream, const ServerArgs& a);
-// hand block over to the server (ready4: its 4 ready flags) and hold the launch stream until it is factored
-int launch_server_block(fr_ctx* ctx, int* ready4, const int* done, unsigned* status);
-// one launch per panel: rows k .. n of the kb columns starting at k; enqueued on ctx->ls
-int launch_panel_tiles(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv,
-                       int* ready, int* done, int* tdone);
-
-int launch_panel_rest(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv);
-int launch_panel_step(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t cols, const double* W);
-int launch_panel_rest_cols(fr_ctx* ctx, double* A, int64_t lda, int64_t n, int64_t k, int64_t kb, const double* dinv, int s_lo,
-                           int s_hi);
 
 // small helpers (elementwise / reductions)
 int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v);
@@ -415,6 +341,28 @@ int ensure_status_word(fr_ctx* ctx);
 int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* c, double* B, int64_t m, int64_t ldb, bool fwd, int prof_cls);
 // FR_HIP_ERROR if a device-side wait timed out since the last check (call after a synchronisation)
 int check_status_word(fr_ctx* ctx);
+
+// Run the body of an entry point; if a persistent solve inside it gave up on a hand-off (bounded device-side wait -> status
+// word -> check_status_word returns FR_HIP_ERROR and raises ctx->solve_timeout_seen), run the body ONCE more with the
+// persistent kernels switched off: the same solve as a recursion of GEMM launches, which waits for nothing but stream order.
+// The body must be restartable (inputs re-staged from the caller's memory, in-place device operands restored by the caller).
+template <class F>
+int solve_retry(fr_ctx* ctx, F&& body)
+{
+    ctx->solve_timeout_seen = false;
+    int st = body();
+    if (st == FR_HIP_ERROR && ctx->solve_timeout_seen && ctx->trsv) {
+        ctx->solve_timeout_seen = false;
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->host_status) ((volatile unsigned*)ctx->host_status)[0] = 0;
+        const int64_t saved = ctx->trsv;
+        ctx->trsv = 0;
+        ++ctx->solve_retries;
+        st = body();
+        ctx->trsv = saved;
+    }
+    return st;
+}
 
 // ---- collectives (comm.hip): RCCL over xGMI, or the in-process local transport; enqueue on ctx->ls ----------
 int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root);

@@ -25,7 +25,7 @@
 
 namespace fr {
 
-template <bool A_KMAJ, bool B_KMAJ, bool YIELD = false>
+template <bool A_KMAJ, bool B_KMAJ>
 __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
 {
 
@@ -45,19 +45,11 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
         const int64_t sidx = ((b >> 3) >> 6) * 8 + xcd;
         const int within = (int)((b >> 3) & 63);
         if (sidx >= g.nsuper) return;
-        if (g.lower) {
-            int64_t row = (int64_t)((sqrt(8.0 * (double)sidx + 1.0) - 1.0) * 0.5);
-            while (row * (row + 1) / 2 > sidx) --row;
-            while ((row + 1) * (row + 2) / 2 <= sidx) ++row;
-            tm = row * 8 + (within & 7);
-            tn = (sidx - row * (row + 1) / 2) * 8 + (within >> 3);
-            if (tn > tm || tm >= g.tiles_m) return;
-        } else {
-            const int sh = 64 >> g.sw_log2;
-            tm = (sidx % g.super_m) * sh + (within & (sh - 1));
-            tn = (sidx / g.super_m) * (1 << g.sw_log2) + (within >> (6 - g.sw_log2));
-            if (tm >= g.tiles_m || tn >= g.tiles_n) return;
-        }
+        // (full products only: the lower-mode SYRK next to the panel stream was measured ~4 % faster in plain order)
+        const int sh = 64 >> g.sw_log2;
+        tm = (sidx % g.super_m) * sh + (within & (sh - 1));
+        tn = (sidx / g.super_m) * (1 << g.sw_log2) + (within >> (6 - g.sw_log2));
+        if (tm >= g.tiles_m || tn >= g.tiles_n) return;
     } else {
         // plain order: each XCD gets a contiguous run of the tile list
         int64_t tlin;
@@ -69,52 +61,15 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
             if (x >= g.nres) return;
             tlin = (b >> 3) * g.nres + x;
             if (tlin >= g.ntiles) return;
-        } else if (g.place == 1 || g.place == 3 || g.place == 5) {
+        } else if (g.place == 1) {
             tlin = claim_item(g.place, g.nres, g.epoch, g.xcc_word, g.claim, g.max_exit, g.ntiles);  // gemm_tile.hpp
             if (tlin < 0) return;
-        } else if (g.lower == 2 && g.la_tiles > 0) {
-            // merged look-ahead, static order: the next panel's tiles first, dealt one by one over the XCDs (workgroups
-            // [0, LA8)), then the remaining triangle in the plain order's per-XCD runs (a pure function of blockIdx.x)
-            const int64_t n_la0 = g.la_tiles * g.tiles_m - g.la_tiles * (g.la_tiles - 1) / 2;
-            const int64_t LA8 = (n_la0 + 7) & ~(int64_t)7;
-            if (b < LA8) {
-                if (b >= n_la0) return;
-                tlin = b;
-            } else {
-                const int64_t nblk = g.ntiles - n_la0;
-                const int64_t q = nblk >> 3, r8 = nblk & 7;
-                const int64_t slot = (b - LA8) >> 3;
-                if (slot >= q + (xcd < r8 ? 1 : 0)) return;
-                tlin = n_la0 + (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
-            }
         } else {
             const int64_t nblk = gridDim.x;
             const int64_t q = nblk >> 3, r8 = nblk & 7;
             tlin = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
         }
-        // merged look-ahead: the first la_tiles tile columns come first (column by column), then the triangle of the remaining
-        // rows and columns row by row, exactly as the separate trailing update would run
-        const int64_t n_la = g.la_tiles * g.tiles_m - g.la_tiles * (g.la_tiles - 1) / 2;
-        if (g.lower == 2 && g.la_tiles > 0 && tlin >= n_la) {
-            const int64_t tl2 = tlin - n_la;
-            int64_t row = (int64_t)((sqrt(8.0 * (double)tl2 + 1.0) - 1.0) * 0.5);
-            while (row * (row + 1) / 2 > tl2) --row;
-            while ((row + 1) * (row + 2) / 2 <= tl2) ++row;
-            tm = g.la_tiles + row;
-            tn = g.la_tiles + (tl2 - row * (row + 1) / 2);
-        } else if (g.lower == 2) {
-            // lower triangle column by column (tm fastest), like the full mode: consecutive workgroups continue down the
-            // same 128 columns of C (the next 1 KiB of every column) and share one B panel.  Column tn holds T - tn tiles.
-            const int64_t T = g.tiles_m;
-            const double tt = 2.0 * (double)T + 1.0;
-            int64_t col = (int64_t)((tt - sqrt(tt * tt - 8.0 * (double)tlin)) * 0.5);
-            if (col < 0) col = 0;
-            if (col >= T) col = T - 1;
-            while (col > 0 && col * T - col * (col - 1) / 2 > tlin) --col;
-            while ((col + 1) * T - (col + 1) * col / 2 <= tlin) ++col;
-            tn = col;
-            tm = col + (tlin - (col * T - col * (col - 1) / 2));
-        } else if (g.lower) {
+        if (g.lower) {
             int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
             while (row * (row + 1) / 2 > tlin) --row;
             while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
@@ -139,17 +94,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
         gt.B += kbeg * (B_KMAJ ? 1 : g.ldb);
         gt.K = kend - kbeg;
     }
-    gemm_f64_tile<A_KMAJ, B_KMAJ, YIELD>(gt, lds, m0, n0);
-    if (g.la_ctr && tn < g.la_tiles) {
-        // a tile of the next panel's columns: tell the panel stream (every wave drains its stores, then ONE release + count)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(g.la_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
 }
 
 // Two kernel symbols over the same body: the lower-mode launch is the trailing SYRK update of the factorisation (the
@@ -171,68 +116,6 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g
 {
     __shared__ double lds[4 * TILE_ELEMS];
     gemm_f64_body<false, false>(g, lds);
-}
-
-// the same two kernels with the cooperative yield compiled in (gemm_tile.hpp): launched when a yield word is attached
-__global__ __launch_bounds__(256, 2) void syrk_lower_yield_f64_kernel(const GemmArgs g)
-{
-    __shared__ double lds[4 * TILE_ELEMS];
-    gemm_f64_body<false, false, true>(g, lds);
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_nn_yield_f64_kernel(const GemmArgs g0)
-{
-    __shared__ double lds[4 * TILE_ELEMS];
-    GemmArgs g = g0;
-    const int64_t bz = blockIdx.y;
-    g.A += bz * g.batch_a;
-    g.B += bz * g.batch_b;
-    g.Cin += bz * g.batch_c;
-    g.D += bz * g.batch_d;
-    gemm_f64_body<false, false, true>(g, lds);
-}
-
-// The same trailing update with the tiles pulled from work lists instead of dealt statically: 2 workgroups per CU stay
-// resident and fetch their next tile with one device-scope atomic.  The hardware deals a grid's workgroups evenly over
-// the shader engines, so with one tile per workgroup a CU that is (partly) taken by the panel stream's kernels makes its
-// engine -- and with it the whole launch -- finish late (round-2 probe: one CU held by another dispatch costs the trailing
-// updates 12 %, = 1/8 of an engine of 8 CUs).  Pulling tiles lets every CU take what it can.  One list per XCD (the static
-// order's contiguous runs, so that the tiles an XCD works on share operand panels in its L2); a workgroup that finds its
-// XCD's list empty steals from the next.  ctr: 8 counters, zeroed before the launch.
-__global__ __launch_bounds__(256, 2) void syrk_lower_dyn_kernel(const GemmArgs g, unsigned* __restrict__ ctr, const int max_tiles)
-{
-    __shared__ double lds[4 * TILE_ELEMS];
-    __shared__ long long next_tile;
-    const int64_t T = g.tiles_m;
-    const int64_t nt = T * (T + 1) / 2;
-    const int64_t q = nt >> 3, r8 = nt & 7;
-    int y = (int)(blockIdx.x & 7);  // observed: block b runs on XCD b % 8 (used for locality only)
-    int tried = 0;
-    for (int done_tiles = 0; done_tiles < max_tiles; ++done_tiles) {
-        if (threadIdx.x == 0) {
-            long long tl = -1;
-            while (tried < 8) {
-                const int64_t len = q + (y < r8 ? 1 : 0);
-                const unsigned i = __hip_atomic_fetch_add(ctr + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int64_t)i < len) {
-                    tl = (y < r8 ? y * (q + 1) : r8 * (q + 1) + (y - r8) * q) + (int64_t)i;
-                    break;
-                }
-                y = (y + 1) & 7;
-                ++tried;
-            }
-            next_tile = tl;
-        }
-        __syncthreads();
-        const int64_t tlin = next_tile;
-        __syncthreads();  // next_tile and the tile buffers are free again
-        if (tlin < 0) return;
-        int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
-        while (row * (row + 1) / 2 > tlin) --row;
-        while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
-        const int64_t tm = row, tn = tlin - row * (row + 1) / 2;
-        gemm_f64_tile<false, false>(g, lds, tm * BM, tn * BN);
-    }
 }
 
 // D = beta * Cin + sum over slices of the partial products (split-K), slices M x N with leading dimension M
@@ -259,78 +142,50 @@ __global__ void release_xcds_kernel(unsigned* word, unsigned epoch)
 
 int launch_release_xcds(fr_ctx* ctx, unsigned epoch)
 {
-    hipLaunchKernelGGL(release_xcds_kernel, dim3(1), dim3(64), 0, ctx->ls, ctx->yield_word + 5, epoch);
+    hipLaunchKernelGGL(release_xcds_kernel, dim3(1), dim3(64), 0, ctx->ls, ctx->xcc_word + 1, epoch);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
 
-// The panel stream's side of the merged look-ahead: one wave that returns when `target` tiles have counted themselves done.
-__global__ void wait_counter_kernel(const unsigned* ctr, unsigned target, unsigned* status)
-{
-    if (threadIdx.x != 0) return;
-    unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v < target) {
-        const unsigned long long t0 = wall_clock64();
-        unsigned spins = 0;
-        for (;;) {
-            __builtin_amdgcn_s_sleep(8);
-            v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v >= target) break;
-            if ((++spins & 63u) == 0) {
-                const bool dead = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-                if (dead || wall_clock64() - t0 > 500000000ull) {  // 5 s of the 100 MHz clock
-                    __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-int launch_wait_counter(fr_ctx* ctx, const unsigned* ctr, unsigned target)
-{
-    FR_TRY(ensure_status_word(ctx));
-    hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, ctx->ls, ctr, target, ctx->dev_status);
-    FR_HIP(ctx, hipGetLastError());
-    return FR_OK;
-}
-
-// Host side of claim_item (gemm_tile.hpp): a counter pair from the factorisation's ring for one launch that keeps off (1) /
-// runs on (3) the panel stream's XCD.  Returns the placement to use (0: launch plainly) and the grid size.
-int claim_setup(fr_ctx* ctx, int place, int64_t items, const unsigned** xcc_word, unsigned** claim, unsigned* max_exit,
-                int64_t* grid, bool force)
+// Host side of claim_item (gemm_tile.hpp): a counter pair from the factorisation's ring for one launch that keeps off the
+// panel stream's XCDs.  Returns the placement to use (0: launch plainly) and the grid size.
+static int claim_setup(fr_ctx* ctx, int64_t items, const unsigned** xcc_word, unsigned** claim, unsigned* max_exit, int64_t* grid)
 {
     *xcc_word = nullptr;
     *claim = nullptr;
     *max_exit = 0;
     *grid = items;
-    if ((!ctx->reserve_now && !force) || ctx->ls == ctx->stream2 || !ctx->claim_ring || ctx->claim_next >= kClaimSlots) return 0;
-    *xcc_word = ctx->yield_word + 4;
+    if (!ctx->reserve_now || ctx->ls == ctx->stream2 || !ctx->claim_ring || ctx->claim_next >= kClaimSlots) return 0;
+    *xcc_word = ctx->xcc_word;
     *claim = ctx->claim_ring + 2 * ctx->claim_next++;
-    const int64_t R = ctx->reserve_now;
-    const int64_t on = place == 3 ? R : (place == 5 ? R - 1 : 8 - R);  // XCDs whose workgroups take items
+    const int64_t on = 8 - ctx->reserve_now;  // XCDs whose workgroups take items
     if (on <= 0) return 0;
     *max_exit = (unsigned)(items * (8 - on) / on + 16);
     *grid = items + *max_exit;
-    return place;
+    return 1;
 }
 
 // Few result tiles and a deep contraction (a 512-row block against 8192 columns: add_rows, narrow predicts; the lower levels
 // of the recursive wide solves): one tile's K-loop is then the whole run time while most CUs idle.  The contraction is cut into slices computed as one batched
 // launch into a workspace, and a second small kernel adds them up (fixed order).  Main stream only (the workspace pool
 // relies on stream order), single GPU ownership only.
+// The rule: products of at most kSplitkTiles result tiles and a contraction of at least kSplitkMinK are cut into
+// ~kSplitkTarget / tiles slices of at least kSplitkSlice.  Round 1 used 192 / 2048 / 384; measured in round 2 with
+// 256 / 512 / 512 (forward solve of 512 / 1024 / 2048 / 4096 columns at n = 32768: 18.7 / 26.6 / 41.6 / 70.6 ->
+// 14.0 / 22.1 / 37.6 / 68.3 ms, 1024 columns at n = 8192: 3.45 -> 2.48 ms, fits -1 %; slices of 128: another -8 ... -13 %)
+constexpr int64_t kSplitkTiles = 256, kSplitkMinK = 512, kSplitkTarget = 512, kSplitkSlice = 128;
+
 int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
 {
     if (d.M <= 0 || d.N <= 0) return FR_OK;
     const int64_t tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     // (the trailing updates of a factorisation -- profile class SYRK -- keep round 1's rule: their launches stay
     // syrk_lower_f64_kernel launches, which is what the profile class and the rocprofv3 summaries count)
-    if (d.batch <= 1 && d.own_world <= 1 && !d.la_ctr && !d.tri && ctx->ls == ctx->stream && ctx->splitk != 0 &&
-        tiles <= (d.prof_cls == FR_PROF_SYRK ? 192 : ctx->splitk_tiles) && d.K >= (d.prof_cls == FR_PROF_SYRK ? 2048 : ctx->splitk_mink) &&
+    if (d.batch <= 1 && d.own_world <= 1 && !d.tri && ctx->ls == ctx->stream && ctx->splitk != 0 &&
+        tiles <= (d.prof_cls == FR_PROF_SYRK ? 192 : kSplitkTiles) && d.K >= (d.prof_cls == FR_PROF_SYRK ? 2048 : kSplitkMinK) &&
         d.M <= 65535 * 256) {
-        int64_t S = (ctx->splitk_target + tiles - 1) / tiles;
-        if (S > d.K / ctx->splitk_slice) S = d.K / ctx->splitk_slice;
+        int64_t S = (kSplitkTarget + tiles - 1) / tiles;
+        if (S > d.K / kSplitkSlice) S = d.K / kSplitkSlice;
         if (S > 32) S = 32;
         while (S > 1 && (d.K % S != 0 || (d.K / S) % BK != 0)) --S;
         if (S > 1) {
@@ -376,7 +231,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.ldd = d.ldd;
     g.alpha = d.alpha;
     g.beta = d.beta;
-    g.lower = d.lower ? ((ctx->gemm_tile == 5) ? 2 : 1) : 0;
+    g.lower = d.lower ? 1 : 0;
     g.own_world = d.own_world;
     g.own_rank = d.own_rank;
     g.own_nb = d.own_nb > 0 ? d.own_nb : 1;
@@ -385,11 +240,11 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.tiles_n = (d.N + BN - 1) / BN;
     double flops;
     int64_t ntiles;
+    g.sw_log2 = 3;
+    g.super_m = 1;
+    g.nsuper = 0;
     if (d.lower) {
         if (d.M != d.N) return set_err(ctx, FR_INVALID_ARGUMENT, "lower-mode GEMM needs a square result");
-        g.sw_log2 = 3;
-        g.super_m = (g.tiles_m + 7) / 8;
-        g.nsuper = g.super_m * (g.super_m + 1) / 2;
         ntiles = g.tiles_m * (g.tiles_m + 1) / 2;
         flops = (double)d.M * (double)(d.M + 1) * (double)g.K;  // 2 * M(M+1)/2 * K
     } else {
@@ -403,13 +258,9 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         flops = 2.0 * (double)d.M * (double)d.N * (double)g.K;
     }
     g.per_xcd = (g.nsuper + 7) / 8;
-    // measured inside the factorisation (scripts/order_ab.py): super-tiles pay for large shallow full products only; the
-    // lower-mode SYRK next to the panel stream is ~4 % faster in plain order.  Option gemm_tile: 0 = this default,
-    // 1 = never, 2 = both modes, 3 = lower mode only (A/B probes).
-    bool use_super = g.K <= 2048 && g.nsuper >= 128;
-    if (ctx->gemm_tile == 0 && d.lower) use_super = false;
-    if (ctx->gemm_tile == 1) use_super = false;
-    if (ctx->gemm_tile == 3 && !d.lower) use_super = false;
+    // measured inside the factorisation (round 1, in-process A/B): super-tiles pay for large shallow full products only; the
+    // lower-mode SYRK next to the panel stream is ~4 % faster in plain order
+    bool use_super = !d.lower && g.K <= 2048 && g.nsuper >= 128;
     g.place = 0;
     g.ntiles = ntiles;
     g.xcc_word = nullptr;
@@ -417,50 +268,33 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.max_exit = 0;
     g.nres = ctx->reserve_now;
     g.epoch = ctx->panel_epoch;
-    g.la_tiles = 0;
-    g.la_ctr = nullptr;
     g.tri = d.tri;
-    const bool merged = d.la_cols > 0 && d.lower && d.la_ctr;
-    const bool merged_static = merged && !ctx->reserve_now && ctx->la_merge_claimed == 0;
-    if ((ctx->reserve_now || (merged && !merged_static)) && d.batch <= 1 && !ctx->syrk_dynamic && d.own_world <= 1) {
+    if (ctx->reserve_now && d.batch <= 1 && d.own_world <= 1) {
         if (ctx->ls == ctx->stream2) {
             if (!d.lower) g.place = 2;
         } else {
             int64_t grid = 0;
-            g.place = claim_setup(ctx, (d.place == 5 && !d.lower) ? 5 : ((d.place == 3 && !d.lower && ntiles <= ctx->bulk_xcd_tiles) ? 3 : 1), ntiles, &g.xcc_word,
-                                  &g.claim, &g.max_exit, &grid, merged);
+            g.place = claim_setup(ctx, ntiles, &g.xcc_word, &g.claim, &g.max_exit, &grid);
         }
         if (g.place) use_super = false;
-    }
-    if (merged) {
-        if (!merged_static && g.place != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "merged look-ahead update needs a claim slot");
-        g.lower = 2;  // the order (claimed, or static: see the kernel) starts with the next panel's columns
-        g.la_tiles = (d.la_cols + BN - 1) / BN;
-        g.la_ctr = d.la_ctr;
-        use_super = false;
     }
     if (use_super)
         ntiles = g.per_xcd * 8 * 64;
     else
         g.nsuper = 0;
-    if (merged_static) {
-        const int64_t n_la0 = g.la_tiles * g.tiles_m - g.la_tiles * (g.la_tiles - 1) / 2;
-        const int64_t rest_tiles = g.ntiles - n_la0;
-        ntiles = ((n_la0 + 7) & ~(int64_t)7) + 8 * ((rest_tiles + 7) / 8);
-    }
-    if (d.dynamic && g.place == 0 && !merged && d.batch <= 1 && d.own_world <= 1 && ctx->dyn_ring && ctx->yield_word) {
+    if (d.dynamic && g.place == 0 && d.batch <= 1 && d.own_world <= 1 && ctx->dyn_ring && ctx->xcc_word) {
         // claimed order with nothing reserved (nres = 0): every workgroup takes the next tile of the list
         unsigned* ctr = ctx->dyn_ring + 2 * (ctx->dyn_next++ & 255);
         FR_HIP(ctx, hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned), ctx->ls));
         g.place = 1;
         g.nres = 0;
-        g.xcc_word = ctx->yield_word + 4;
+        g.xcc_word = ctx->xcc_word;
         g.claim = ctr;
         g.max_exit = 0;
         g.nsuper = 0;
     }
     if (g.place == 2) ntiles = 8 * ((g.ntiles + g.nres - 1) / g.nres);
-    if (g.place == 1 || g.place == 3 || g.place == 5) ntiles = g.ntiles + g.max_exit;
+    if (g.place == 1) ntiles = g.ntiles + g.max_exit;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
     double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
     if (d.own_world > 1) {
@@ -481,29 +315,14 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     if (d.tri) flops *= (d.tri == 1 && d.lower) ? (2.0 / 3.0) : 0.5;  // average length of the restricted contraction
     const double nbatch = d.batch > 1 ? (double)d.batch : 1.0;
     ProfScope ps(ctx, d.prof_cls, flops * nbatch, bytes * nbatch);
-    g.yield_word = (ctx->k4_yield && d.batch <= 1) ? ctx->yield_word : nullptr;
     g.batch_a = d.batch_a;
     g.batch_b = d.batch_b;
     g.batch_c = d.batch_c;
     g.batch_d = d.batch_d;
     if (d.batch > 1 && d.lower) return set_err(ctx, FR_INVALID_ARGUMENT, "batched GEMM is full-mode only");
     dim3 grid((unsigned)ntiles, (unsigned)(d.batch > 1 ? d.batch : 1)), block(256);
-    if (d.lower && !d.a_kmajor && !d.b_kmajor && ctx->syrk_dynamic && d.own_world <= 1 && g.nsuper == 0 && g.lower == 1 &&
-        ntiles > 2 * (int64_t)ctx->num_cus) {
-        if (!ctx->syrk_ctr) FR_HIP(ctx, dev_malloc(ctx, (void**)&ctx->syrk_ctr, 64));
-        FR_HIP(ctx, hipMemsetAsync(ctx->syrk_ctr, 0, 32, ctx->ls));
-        // a workgroup retires after `per` tiles: its slot is then up for grabs again (the panel stream's kernels take theirs
-        // that way), and the grid holds 1/8 more workgroups than the tiles need, so that the engines that run ahead can
-        // take more than their share -- the last workgroups to start find the lists empty
-        const int per = (int)ctx->syrk_dynamic_tiles;
-        const int64_t wgs = (ntiles + per - 1) / per;
-        hipLaunchKernelGGL(syrk_lower_dyn_kernel, dim3((unsigned)(wgs + wgs / 8 + 8)), block, 0, ctx->ls, g, ctx->syrk_ctr, per);
-    } else if (d.lower && !d.a_kmajor && !d.b_kmajor && g.yield_word)
-        hipLaunchKernelGGL(syrk_lower_yield_f64_kernel, grid, block, 0, ctx->ls, g);
-    else if (d.lower && !d.a_kmajor && !d.b_kmajor)
+    if (d.lower && !d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL(syrk_lower_f64_kernel, grid, block, 0, ctx->ls, g);
-    else if (!d.a_kmajor && !d.b_kmajor && g.yield_word)
-        hipLaunchKernelGGL(gemm_nn_yield_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && d.b_kmajor)

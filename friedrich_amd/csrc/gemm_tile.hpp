@@ -1,5 +1,4 @@
-// gemm_tile.hpp -- device code of the FP64 matrix-core GEMM tile (see gemm_f64.hip for the design notes): shared by the
-// GEMM kernels (gemm_f64.hip) and the fused panel kernel (panel.hip).
+// gemm_tile.hpp -- device code of the FP64 matrix-core GEMM tile (see gemm_f64.hip for the design notes).
 #pragma once
 
 #include "fr_internal.hpp"
@@ -34,9 +33,6 @@ struct GemmArgs {
     int64_t own_nb, own_col0;
     // batch: blockIdx.y selects a problem; operands advance by these strides (elements)
     int64_t batch_a, batch_b, batch_c, batch_d;
-    // cooperative yield (see cu_key / yield_if_asked): word that names the CU on which a diagonal-block kernel wants to
-    // run undisturbed, or NULL
-    const unsigned* yield_word;
     // XCD reservation (gemm_f64.hip): place 1 = keep off the XCD named by *xcc_word (tiles claimed from claim[0], at most
     // max_exit workgroups retire through claim[1]); place 2 = only the workgroups with blockIdx.x % 8 == 0 work
     int place;
@@ -46,10 +42,6 @@ struct GemmArgs {
     const unsigned* xcc_word;  // 1 + XCC_ID of the XCD the diagonal-block kernels run on (0: not known yet)
     unsigned* claim;
     unsigned max_exit;
-    // merged look-ahead (lower mode, column-major claimed order): the tiles of the first la_tiles tile columns count
-    // themselves done on *la_ctr (release), the panel stream waits for all of them (wait_counter_kernel)
-    int64_t la_tiles;
-    unsigned* la_ctr;
     // triangular operands: the contraction of a tile runs over [kbeg, kend) only (multiples of 128, from the tile's offsets)
     //   1: kbeg = m0  (op(A)(m, k) = 0 for k < m: the transpose of a lower-triangular matrix)
     //   2: kbeg = n0  (op(B)(k, n) = 0 for k < n: a lower-triangular matrix as the right operand)
@@ -119,31 +111,6 @@ __device__ __forceinline__ void store_tile(double* __restrict__ S, int t, const 
     }
 }
 
-// ---- cooperative yield ---------------------------------------------------------------------------------------------------
-// The diagonal-block kernel (potf2.hip) is a chain of dependent f64 operations; sharing its CU with a GEMM workgroup makes
-// every one of them queue behind the neighbour's MFMAs (55 us alone, 150 - 265 us in situ), and it cannot have a CU to
-// itself (a workgroup that only fits an empty CU is starved by the trailing update's queue; one that holds a CU costs the
-// other kernels an eighth of an engine: DESIGN.md section 5).  So the NEIGHBOUR steps aside: the diagonal-block kernel
-// publishes the identity of its CU in a global word, every GEMM wave looks at the word once per K-step (a load issued at the
-// top of the step, consumed at its end: no stall) and sleeps while the word names its own CU.  One tile of the trailing
-// update finishes ~60 us late; the pivot chain gets the CU's issue slots.
-__device__ __forceinline__ unsigned cu_key()
-{
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    return ((xcc & 0xfu) << 16) | (hw & 0xff00u) | 1u;  // (XCC, SE / SH / CU fields of HW_ID): unique per CU (scripts/hwid_probe.hip)
-}
-
-__device__ __forceinline__ void yield_if_asked(const unsigned* word, unsigned seen, unsigned mine)
-{
-    if (seen != mine) return;
-    for (int spins = 0; spins < 4000; ++spins) {  // bounded: ~2 ms
-        __builtin_amdgcn_s_sleep(20);
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine) break;
-    }
-}
-
 // ---- XCD reservation -----------------------------------------------------------------------------------------------------
 // While the panel chain bounds a factorisation, the XCD on which the panel stream's diagonal-block kernel runs is left to
 // it (a dependent f64 operation of the pivot chain costs 7 cycles on a CU of its own and 54 - 85 next to a GEMM workgroup's
@@ -151,8 +118,8 @@ __device__ __forceinline__ void yield_if_asked(const unsigned* word, unsigned se
 // diagonal-block kernel publishes which (xcc_word = 1 + XCC_ID); a launch of that stream deals workgroup b to XCD
 // (that one + b) % 8, so `nres` XCDs can be set aside for the panel stream: its launches use the workgroups with b % 8 <
 // nres only (place 2, a pure function of b), everybody else keeps off the nres XCDs from the published one on.  place 1: a workgroup dealt to that XCD retires at once
-// (its slot is free again within a microsecond, so the dispatcher's round over the engines never waits there); place 3:
-// the opposite, only the workgroups on that XCD work.  Correct whatever the dispatcher does: work items are CLAIMED (one
+// (its slot is free again within a microsecond, so the dispatcher's round over the engines never waits there).
+// Correct whatever the dispatcher does: work items are CLAIMED (one
 // atomic on claim[0]) and at most max_exit workgroups may retire without one (claim[1]) -- the grid holds n + max_exit
 // workgroups.  Returns the claimed item or -1.
 __device__ __forceinline__ long long claim_item(int place, int nres, unsigned epoch, const unsigned* xcc_word, unsigned* claim,
@@ -168,13 +135,8 @@ __device__ __forceinline__ long long claim_item(int place, int nres, unsigned ep
         const bool held = (int)(released - epoch) < 0;
         const bool known = word != 0u;
         const unsigned dist = (phys - (word - 1u)) & 7u;  // 0: the XCD of the diagonal-block kernels
-        bool want;  // should this workgroup take an item?
-        if (place == 1)
-            want = !(held && known && dist < (unsigned)nres);  // trailing update: keep off the reserved XCDs
-        else if (place == 3)
-            want = known && dist < (unsigned)nres;  // on the reserved XCDs
-        else
-            want = known && dist >= 1u && dist < (unsigned)nres;  // place 5, helpers of the panel chain: reserved, but not the chain's own
+        (void)place;
+        const bool want = !(held && known && dist < (unsigned)nres);  // trailing update: keep off the reserved XCDs
         bool retire = false;
         if (!want) retire = __hip_atomic_fetch_add(claim + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < max_exit;
         long long tl = -1;
@@ -188,9 +150,8 @@ __device__ __forceinline__ long long claim_item(int place, int nres, unsigned ep
     return claimed;
 }
 
-// One 128 x 128 result tile at (m0, n0): the whole K-loop and the epilogue.  Called by the GEMM kernels (one tile per
-// workgroup) and by the fused panel kernel (panel.hip: a workgroup walks through the tile products of its row tile).
-template <bool A_KMAJ, bool B_KMAJ, bool YIELD = false>
+// One 128 x 128 result tile at (m0, n0): the whole K-loop and the epilogue (one tile per workgroup).
+template <bool A_KMAJ, bool B_KMAJ>
 __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, const int64_t m0, const int64_t n0)
 {
 
@@ -206,9 +167,6 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
 
-    // YIELD: compile-time, so that the plain instantiation keeps its pinned instruction schedule byte for byte
-    const unsigned* ywp = YIELD ? g.yield_word : nullptr;
-    const unsigned ykey = YIELD ? cu_key() : 0u;
     const int64_t nk = (g.K + BK - 1) / BK;
     const int64_t nk_full = g.K / BK;  // K-steps that need no k predicate
     const bool a_fast = (m0 + BM) <= g.M, b_fast = (n0 + BN) <= g.N;
@@ -247,8 +205,6 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, co
             pb += more ? step_b : 0;
             load_tile_fast<A_KMAJ>(pa, g.lda, ra);
             load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
-            unsigned yseen = 0u;
-            if constexpr (YIELD) yseen = __hip_atomic_load(ywp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double* As = lds + cur * 2 * TILE_ELEMS;
             const double* Bs = As + TILE_ELEMS;
 #pragma unroll
@@ -289,7 +245,6 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, co
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             }
-            if constexpr (YIELD) yield_if_asked(ywp, yseen, ykey);
             __syncthreads();
             cur ^= 1;
         }

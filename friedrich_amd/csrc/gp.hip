@@ -84,6 +84,10 @@ static int ensure_alpha(fr_chol* c)
         const int64_t ld = c->targets_cap;
         FR_TRY(trsm_lower_fwd(ctx, c, c->n, c->alpha, 1, ld, FR_PROF_GEMM_SOLVE));
         FR_TRY(trsm_lower_bwd(ctx, c, c->n, c->alpha, 1, ld, FR_PROF_GEMM_SOLVE));
+        // alpha is marked current only once the solves are known to have completed (a timed-out hand-off would otherwise
+        // leave garbage behind a valid generation tag); once per change of the factor, so the synchronisation is free
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FR_TRY(check_status_word(ctx));
     }
     c->alpha_gen = c->gen;
     return FR_OK;
@@ -93,38 +97,7 @@ static int ensure_alpha(fr_chol* c)
 
 using namespace fr;
 
-extern "C" {
-
-int fr_chol_set_targets(fr_chol* c, const double* y)
-{
-    if (!c) return FR_INVALID_ARGUMENT;
-    FR_LOCK(c->ctx);
-    fr_ctx* ctx = c->ctx;
-    FR_HIP(ctx, hipSetDevice(ctx->device));
-    if (c->n > 0 && !y) return set_err(ctx, FR_INVALID_ARGUMENT, "null training-output vector (y)");
-    if (c->targets_cap < c->capacity || !c->yt) {
-        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (c->yt) (void)hipFree(c->yt);
-        if (c->alpha) (void)hipFree(c->alpha);
-        c->yt = c->alpha = nullptr;
-        c->targets_cap = 0;
-        const int64_t cap = round_up(c->capacity > 0 ? c->capacity : 1, kAlign);
-        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->yt, sizeof(double) * (size_t)cap));
-        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->alpha, sizeof(double) * (size_t)cap));
-        c->targets_cap = cap;
-    }
-    if (c->n > 0) {
-        const bool dev = is_device_ptr(y);
-        FR_HIP(ctx, hipMemcpyAsync(c->yt, y, sizeof(double) * (size_t)c->n, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                   ctx->stream));
-        if (!dev) FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    c->targets_n = c->n;
-    c->alpha_gen = 0;  // solved lazily by the first predict
-    return FR_OK;
-}
-
-int fr_likelihood(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, double* out)
+static int fr_likelihood_impl(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, double* out)
 {
     if (!c || !out) return FR_INVALID_ARGUMENT;
     FR_LOCK(c->ctx);
@@ -157,12 +130,13 @@ int fr_likelihood(fr_chol* c, const fr_kprog* kernel, const double* y, double no
     double h[2] = {0.0, 0.0};
     FR_HIP(ctx, hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FR_TRY(check_status_word(ctx));
     const double normalization_constant = (double)n * std::log(2.0 * M_PI);  // :217
     *out = -(h[0] + h[1] + normalization_constant) / 2.0;                    // :219
     return FR_OK;
 }
 
-int fr_predict_mean(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m, int64_t ldq,
+static int fr_predict_mean_impl(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m, int64_t ldq,
                     const double* prior_q, double* out_mean)
 {
     if (!c) return FR_INVALID_ARGUMENT;
@@ -203,7 +177,7 @@ int fr_predict_mean(fr_chol* c, const fr_kprog* kernel, const double* y, const d
     return mean.commit();
 }
 
-int fr_predict_variance(fr_chol* c, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq, double* out_var)
+static int fr_predict_variance_impl(fr_chol* c, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq, double* out_var)
 {
     if (!c) return FR_INVALID_ARGUMENT;
     FR_LOCK(c->ctx);
@@ -224,7 +198,7 @@ int fr_predict_variance(fr_chol* c, const fr_kprog* kernel, const double* Xq, in
     return var.commit();
 }
 
-int fr_predict_mean_variance(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m,
+static int fr_predict_mean_variance_impl(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m,
                              int64_t ldq, const double* prior_q, double* out_mean, double* out_var)
 {
     if (!c) return FR_INVALID_ARGUMENT;
@@ -254,7 +228,7 @@ int fr_predict_mean_variance(fr_chol* c, const fr_kprog* kernel, const double* y
     return var.commit();
 }
 
-int fr_predict_covariance(fr_chol* c, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq, double* out_cov,
+static int fr_predict_covariance_impl(fr_chol* c, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq, double* out_cov,
                           int64_t ldc)
 {
     if (!c) return FR_INVALID_ARGUMENT;
@@ -278,7 +252,7 @@ int fr_predict_covariance(fr_chol* c, const fr_kprog* kernel, const double* Xq, 
     return cov.commit();
 }
 
-int fr_posterior(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m, int64_t ldq,
+static int fr_posterior_impl(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m, int64_t ldq,
                  const double* prior_q, double* out_mean, double* out_cov, int64_t ldc, double* out_cov_l, int64_t ldl)
 {
     if (!c) return FR_INVALID_ARGUMENT;
@@ -329,6 +303,83 @@ int fr_posterior(fr_chol* c, const fr_kprog* kernel, const double* y, const doub
     return FR_OK;
 }
 
+extern "C" {
+
+int fr_chol_set_targets(fr_chol* c, const double* y)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
+    fr_ctx* ctx = c->ctx;
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    if (c->n > 0 && !y) return set_err(ctx, FR_INVALID_ARGUMENT, "null training-output vector (y)");
+    if (c->targets_cap < c->capacity || !c->yt) {
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (c->yt) (void)hipFree(c->yt);
+        if (c->alpha) (void)hipFree(c->alpha);
+        c->yt = c->alpha = nullptr;
+        c->targets_cap = 0;
+        const int64_t cap = round_up(c->capacity > 0 ? c->capacity : 1, kAlign);
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->yt, sizeof(double) * (size_t)cap));
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->alpha, sizeof(double) * (size_t)cap));
+        c->targets_cap = cap;
+    }
+    if (c->n > 0) {
+        const bool dev = is_device_ptr(y);
+        FR_HIP(ctx, hipMemcpyAsync(c->yt, y, sizeof(double) * (size_t)c->n, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                   ctx->stream));
+        if (!dev) FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    c->targets_n = c->n;
+    c->alpha_gen = 0;  // solved lazily by the first predict
+    return FR_OK;
+}
+
+int fr_likelihood(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, double* out)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
+    return solve_retry(c->ctx, [&]() -> int { return fr_likelihood_impl(c, kernel, y, noise, out); });
+}
+
+int fr_predict_mean(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m, int64_t ldq,
+                    const double* prior_q, double* out_mean)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
+    return solve_retry(c->ctx, [&]() -> int { return fr_predict_mean_impl(c, kernel, y, Xq, m, ldq, prior_q, out_mean); });
+}
+
+int fr_predict_variance(fr_chol* c, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq, double* out_var)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
+    return solve_retry(c->ctx, [&]() -> int { return fr_predict_variance_impl(c, kernel, Xq, m, ldq, out_var); });
+}
+
+int fr_predict_mean_variance(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m,
+                             int64_t ldq, const double* prior_q, double* out_mean, double* out_var)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
+    return solve_retry(c->ctx, [&]() -> int { return fr_predict_mean_variance_impl(c, kernel, y, Xq, m, ldq, prior_q, out_mean, out_var); });
+}
+
+int fr_predict_covariance(fr_chol* c, const fr_kprog* kernel, const double* Xq, int64_t m, int64_t ldq, double* out_cov,
+                          int64_t ldc)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
+    return solve_retry(c->ctx, [&]() -> int { return fr_predict_covariance_impl(c, kernel, Xq, m, ldq, out_cov, ldc); });
+}
+
+int fr_posterior(fr_chol* c, const fr_kprog* kernel, const double* y, const double* Xq, int64_t m, int64_t ldq,
+                 const double* prior_q, double* out_mean, double* out_cov, int64_t ldc, double* out_cov_l, int64_t ldl)
+{
+    if (!c) return FR_INVALID_ARGUMENT;
+    FR_LOCK(c->ctx);
+    return solve_retry(c->ctx, [&]() -> int { return fr_posterior_impl(c, kernel, y, Xq, m, ldq, prior_q, out_mean, out_cov, ldc, out_cov_l, ldl); });
+}
+
 int fr_gemm(fr_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc)
 {
@@ -349,8 +400,7 @@ int fr_gemm(fr_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t
     g.B = b.dev; g.ldb = b.ld; g.b_kmajor = trans_b == 0;   // stored K x N: element (k,n) at B[k + n*ldb]
     g.Cin = c.dev; g.ldcin = c.ld; g.D = c.dev; g.ldd = c.ld;
     g.alpha = alpha; g.beta = beta; g.prof_cls = FR_PROF_GEMM_SOLVE;
-    // developer probes time the lower-triangular tile set through this entry point (option gemm_lower_probe)
-    g.lower = ctx->gemm_lower_probe != 0 && M == N;
+    g.lower = false;
     FR_TRY(launch_gemm(ctx, g));
     return c.commit();
 }

@@ -285,11 +285,20 @@ static int kprog_counts(const fr_kprog& p, int* nb_parameters, int* nb_gradients
 
 using namespace fr;
 
+static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, int scaled, double* out_grad,
+                           double* out_scale);
+
 extern "C" int fr_grad_terms(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, int scaled,
                              double* out_grad, double* out_scale)
 {
     if (!c || !out_grad) return FR_INVALID_ARGUMENT;
     FR_LOCK(c->ctx);
+    return solve_retry(c->ctx, [&]() -> int { return grad_terms_impl(c, kernel, y, noise, scaled, out_grad, out_scale); });
+}
+
+static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, double noise, int scaled, double* out_grad,
+                           double* out_scale)
+{
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
     FR_TRY(kprog_check(ctx, kernel));
@@ -343,6 +352,7 @@ extern "C" int fr_grad_terms(fr_chol* c, const fr_kprog* kernel, const double* y
     double h_ya = 0.0;
     FR_HIP(ctx, hipMemcpyAsync(&h_ya, outs + ng + 2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FR_TRY(check_status_word(ctx));  // (the alpha solves are persistent kernels)
     const double scale = h_ya / (double)n;
     // K2: fused reductions over the lower triangle
     const int64_t nbk = (n + GR_M - 1) / GR_M;

@@ -37,7 +37,6 @@
 // f64 operation then queues behind the neighbour's MFMAs and an LDS round trip costs ~900 cycles instead of ~150
 // (scripts/contention_probe.hip, scripts/potf2_bench_phases.hip).
 #include "fr_internal.hpp"
-#include "handoff.hpp"
 
 namespace fr {
 
@@ -47,9 +46,6 @@ constexpr int SBE = SB * SB;
 constexpr int PT = 512;  // 8 waves; <= 128 VGPRs so that they fit beside ONE resident GEMM workgroup
 constexpr int NSLOT = 10;
 constexpr size_t POTF2_LDS = (size_t)NSLOT * SBE * sizeof(double) + 16;  // + the column counter of the panel wave
-// the server asks for 96 KiB: 160 - 96 < 73.7 KiB, so no GEMM / panel-tile workgroup fits beside it on its CU
-constexpr size_t POTF2_SERVER_LDS = 96 * 1024;
-constexpr int SERVER_NSL = 4;  // ready flags per block: one per 32-row slice (panel.hip)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every
 // outstanding factor-column store to be acknowledged by memory (microseconds under GEMM load).
@@ -672,7 +668,7 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
 __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                                    double sub, double* __restrict__ inv, int64_t ldinv,
                                                    int64_t* __restrict__ info, double* __restrict__ cest,
-                                                   unsigned* __restrict__ yield_word, unsigned* __restrict__ xcc_word)
+                                                   unsigned* __restrict__ xcc_word)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (xcc_word && threadIdx.x == 0) {
@@ -681,104 +677,7 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_store(xcc_word, (xcc & 7u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ask the GEMM workgroup that shares this CU to step aside for the length of the pivot chain (gemm_tile.hpp)
-    unsigned key = 0;
-    if (yield_word && threadIdx.x == 0) {
-        unsigned xcc, hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        key = ((xcc & 0xfu) << 16) | (hw & 0xff00u) | 1u;
-        __hip_atomic_store(yield_word, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
-    if (yield_word && threadIdx.x == 0) {
-        // (only if the word is still ours: a later diagonal-block kernel of another stream may have taken it over)
-        unsigned expect = key;
-        (void)__hip_atomic_compare_exchange_strong(yield_word, &expect, 0u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// ---- the diagonal-block SERVER of the fused panel factorisation (panel.hip) ----------------------------------------------
-// One workgroup that lives for a whole factorisation and factors the 128 x 128 diagonal blocks one after the other, as the
-// row-tile workgroups of the panel kernels hand them over (ready[g]) and wait for them (done[g]).  It asks for more LDS
-// than a CU can spare beside a GEMM workgroup, so the CU it lands on stays its own for the whole fit: the pivot chain runs
-// at the speed it has on an idle chip (~60 us per block) instead of the ~150 - 265 us it takes next to the trailing
-// update's MFMA stream (round-1 measurement), and nothing is paid per block for launching or finding a CU.
-__global__ __launch_bounds__(PT, 2) void potf2_server_kernel(const ServerArgs a)  // alone on its CU: 256 VGPRs per lane
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    // tell the host that this workgroup is RESIDENT: the row-tile launches wait for it, so it must hold its CU before they
-    // are enqueued (a chip full of waiting row tiles would leave it no CU to start on)
-    if (threadIdx.x == 0) __hip_atomic_store((hgu32*)(a.status + 1), a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int g = 0; g < a.nblocks; ++g) {
-        const int64_t j = (int64_t)g * PB;
-        if (a.own_world > 1 && (int)((j / a.own_nb) % a.own_world) != a.own_rank) continue;  // another rank's panel
-        unsigned long long t0 = 0, t1 = 0, t2 = 0;
-        if (a.dbg) t0 = wall_clock64();
-        if (!handoff_wait_all_ge(a.ready + SERVER_NSL * g, SERVER_NSL, 1, a.status)) return;  // every 32-row slice of the block
-        if (a.dbg) t1 = wall_clock64();
-        const int64_t left = a.n - j;
-        potf2_block(lds, a.A + j + j * a.lda, a.lda, (int)(left < PB ? left : PB), a.col0 + j, a.mode, a.sub,
-                    a.dinv + (int64_t)g * (PB * PB), PB, a.info, a.cest ? a.cest + g : nullptr);
-        if (a.dbg) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            t2 = wall_clock64();
-        }
-        handoff_publish(a.done + g, 1);  // factor columns and inverse are in memory: the panel's row tiles may use them
-        if (a.dbg && threadIdx.x == 0) {  // developer probe (option panel_debug): 100 MHz ticks
-            a.dbg[4 * g + 0] = t0;
-            a.dbg[4 * g + 1] = t1;
-            a.dbg[4 * g + 2] = t2;
-            a.dbg[4 * g + 3] = wall_clock64();
-        }
-    }
-}
-
-// Stream-level hand-offs with the server (panel_fused = 1): a one-wave kernel that hands diagonal block g over (everything
-// queued before it on the stream -- the updates of the block -- is complete and visible at the kernel boundary), and a
-// one-wave kernel that holds the stream until the server has factored it.  Both fit beside two resident GEMM workgroups.
-__global__ __launch_bounds__(64) void server_signal_kernel(int* ready)
-{
-    if (threadIdx.x < SERVER_NSL) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store((hgi32*)(ready + threadIdx.x), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__global__ __launch_bounds__(64) void server_wait_kernel(const int* done, unsigned* status)
-{
-    (void)handoff_wait_ge(done, 1, status);
-}
-
-int launch_server_block(fr_ctx* ctx, int* ready4, const int* done, unsigned* status)
-{
-    hipLaunchKernelGGL(server_signal_kernel, dim3(1), dim3(64), 0, ctx->ls, ready4);
-    hipLaunchKernelGGL(server_wait_kernel, dim3(1), dim3(64), 0, ctx->ls, done, status);
-    FR_HIP(ctx, hipGetLastError());
-    return FR_OK;
-}
-
-int launch_potf2_server(fr_ctx* ctx, hipStream_t stream, const ServerArgs& a)
-{
-    if (!ctx->potf2_server_lds_set) {
-        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_server_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_SERVER_LDS));
-        ctx->potf2_server_lds_set = true;
-    }
-    if (getenv("FR_SERVER_TINY")) {  // developer probe: a ONE-WAVE resident kernel instead of the server (what does residency itself cost?)
-        __hip_atomic_store(ctx->host_status + 1, a.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        hipLaunchKernelGGL(server_wait_kernel, dim3(1), dim3(64), 0, stream, a.done + a.nblocks - 1, a.status);
-        FR_HIP(ctx, hipGetLastError());
-        return FR_OK;
-    }
-    size_t lds_bytes = POTF2_SERVER_LDS;
-    if (const char* e = getenv("FR_SERVER_LDS_KB")) {  // developer probe
-        const long kb = atol(e);
-        if (kb * 1024 >= (long)POTF2_LDS && kb <= 96) lds_bytes = (size_t)kb * 1024;
-    }
-    hipLaunchKernelGGL(potf2_server_kernel, dim3(1), dim3(PT), lds_bytes, stream, a);
-    FR_HIP(ctx, hipGetLastError());
-    return FR_OK;
 }
 
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub, double* inv,
@@ -793,8 +692,7 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
     }
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
     hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv,
-                       info, cest, ctx->k4_yield ? ctx->yield_word : nullptr,
-                       (ctx->xcd_reserve != 0 || ctx->xcd_reserve2 > 0) ? ctx->yield_word + 4 : nullptr);
+                       info, cest, ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

@@ -143,12 +143,11 @@ extern "C" int fr_linear_prior_fit(fr_ctx* ctx, const double* X, int64_t n, int6
     FR_TRY(ys.in(y, n, 1, n > 0 ? n : 1));
     std::vector<double> Rz((size_t)p * P, 0.0);
     if (n > 0) {
-        static bool attr_set = false;
         const size_t lds = sizeof(double) * (size_t)QLD * (size_t)P;
-        if (!attr_set) {
+        if (!ctx->prior_lds_set) {  // per context (= per device): the attribute belongs to the device's copy of the kernel
             FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tsqr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)(sizeof(double) * QLD * QP_MAX)));
-            attr_set = true;
+            ctx->prior_lds_set = true;
         }
         WsGuard g0(ctx), g1(ctx);
         int64_t rows = n;

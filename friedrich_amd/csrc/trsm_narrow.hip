@@ -37,10 +37,23 @@ struct TrsmnArgs {
     int m;
     double* xg;         // hand-off payload: block g at xg + g * NB * MR, [col][q]
     int* flags;         // one per block
+    unsigned* tickets;  // one block claim counter per column group (zeroed with the flags before every launch)
     unsigned* status;
-    int nblk, G, bwd;
+    int nblk, bwd;
     int ngroups;        // column groups of 16 right-hand sides (blockIdx.y); hand-off state per group
 };
+
+// The next unclaimed block of this column group's sweep, or -1 (uniform).  Blocks are taken in order of arrival, so a block
+// only waits for blocks held by workgroups that are already running: no co-residency needed (see trsv.hip).
+__device__ __forceinline__ int claim_block(unsigned* ticket, int nblk, int* slot)
+{
+    if (threadIdx.x == 0) {
+        const unsigned i = __hip_atomic_fetch_add((hgu32*)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *slot = i < (unsigned)nblk ? (int)i : -1;
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*slot);
+}
 
 struct Frag {
     const double* base;  // element (0, 0)
@@ -137,9 +150,13 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArg
         a.m = a.m - grp * MRT < MRT ? a.m - grp * MRT : MRT;
         a.xg += (int64_t)grp * a.nblk * (NB * MRT);
         a.flags += (int64_t)grp * a.nblk;
+        a.tickets += grp;
     }
+    __shared__ int claim_slot;
 #pragma nounroll
-    for (int bi = blockIdx.x; bi < a.nblk; bi += a.G) {
+    for (;;) {
+        const int bi = claim_block(a.tickets, a.nblk, &claim_slot);
+        if (bi < 0) return;
         const int blk = a.bwd ? last - bi : bi;
         const int cnt = a.bwd ? last - blk : blk;  // tiles; item q uses the solution block dep(q); item cnt: the inverse block
         const int64_t b0 = (int64_t)blk * NB;
@@ -246,9 +263,13 @@ __global__ __launch_bounds__(NTH, 2) void trsm_narrow_kernel(const TrsmnArgs a0)
         a.m = a.m - grp * MR < MR ? a.m - grp * MR : MR;
         a.xg += (int64_t)grp * a.nblk * (NB * MR);
         a.flags += (int64_t)grp * a.nblk;
+        a.tickets += grp;
     }
+    __shared__ int claim_slot;
 #pragma nounroll
-    for (int bi = blockIdx.x; bi < a.nblk; bi += a.G) {
+    for (;;) {
+        const int bi = claim_block(a.tickets, a.nblk, &claim_slot);
+        if (bi < 0) return;
         const int blk = a.bwd ? last - bi : bi;
         const int cnt = a.bwd ? last - blk : blk;  // tiles; item q uses the solution block dep(q)
         const int64_t b0 = (int64_t)blk * NB;
@@ -369,7 +390,7 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     const int nblk = (int)((n + NB - 1) / NB);
     FR_TRY(ensure_status_word(ctx));
     if (!fwd) FR_TRY(ensure_transposed(ctx, c));
-    const size_t bytes = (sizeof(double) * (size_t)nblk * NB * MRT + sizeof(int) * (size_t)nblk) * (size_t)ngroups + 64;
+    const size_t bytes = (sizeof(double) * (size_t)nblk * NB * MRT + sizeof(int) * (size_t)(nblk + 1)) * (size_t)ngroups + 64;
     if (ctx->trsmn_buf_cap < bytes) {
         if (ctx->trsmn_buf) {
             (void)hipStreamSynchronize(ctx->stream);
@@ -390,20 +411,27 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     a.m = (int)m;
     a.xg = (double*)ctx->trsmn_buf;
     a.flags = (int*)((char*)ctx->trsmn_buf + sizeof(double) * (size_t)nblk * NB * MRT * (size_t)ngroups);
+    a.tickets = (unsigned*)(a.flags + (size_t)nblk * (size_t)ngroups);
     a.ngroups = ngroups;
     a.status = ctx->dev_status;
     a.nblk = nblk;
-    a.G = nblk < ctx->num_cus ? nblk : ctx->num_cus;  // (two workgroups fit a CU: two column groups' chains side by side)
+    int G = nblk < ctx->num_cus ? nblk : ctx->num_cus;  // (two workgroups fit a CU: two column groups' chains side by side)
+    if (ctx->test_max_wgs > 0 && G > ctx->test_max_wgs) G = ctx->test_max_wgs;
     a.bwd = fwd ? 0 : 1;
-    FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)nblk * (size_t)ngroups, ctx->ls));
+    FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)(nblk + 1) * (size_t)ngroups, ctx->ls));
     ProfScope ps(ctx, prof_cls, (double)n * (double)n * (double)m, 4.0 * (double)n * (double)n);
     if (nq == 2)
-        hipLaunchKernelGGL(trsm_narrow_half_kernel<2>, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
+        hipLaunchKernelGGL(trsm_narrow_half_kernel<2>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     else if (ngroups >= 2)
-        hipLaunchKernelGGL(trsm_narrow_half_kernel<1>, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
+        hipLaunchKernelGGL(trsm_narrow_half_kernel<1>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     else
-        hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)a.G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
+        hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
+    ctx->persistent_pending = true;
+    if (ctx->test_force_timeout) {  // test hook: behave as if a hand-off of this launch had timed out
+        FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+        ((volatile unsigned*)ctx->host_status)[0] = 1u;
+    }
     return FR_OK;
 }
 

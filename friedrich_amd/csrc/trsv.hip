@@ -15,8 +15,16 @@
 // independent.  The tile that a block needs LAST (the one next to the diagonal) and its inverse block are already in
 // registers when the hand-off arrives, so a step of the chain costs one poll + 2 x 64 FMAs per lane + two small reductions.
 //
-// Deterministic: every sum has a fixed order (no atomics on data).  Every spin is bounded (wall-clock timeout -> status
-// word in host-visible memory -> FR_HIP_ERROR), so a scheduling accident cannot hang the GPU.
+// Deterministic: every sum has a fixed order (no atomics on data).
+//
+// Forward progress.  A workgroup CLAIMS its block with an atomic ticket when it starts (and again after every block it
+// finishes): block index = order of arrival (forward: ticket i -> block i, backward: ticket i -> block nblk - 1 - i).  A block
+// only ever waits for blocks with LOWER tickets, i.e. for workgroups that are already running -- whatever part of the grid
+// the dispatcher has not placed yet (other kernels holding CUs, a second context, a CU mask) cannot be waited on, so the
+// launch needs no co-residency guarantee.  (Round 2 dealt block r to workgroup r % G: with more blocks than resident
+// workgroups a workgroup's second block waited for first blocks of workgroups that were never dispatched.)
+// Every spin is still bounded (wall-clock timeout -> status word in host-visible memory); the entry point then repeats the
+// operation on the recursive GEMM path (solve_retry in fr_internal.hpp) instead of failing.
 #include "fr_internal.hpp"
 
 namespace fr {
@@ -36,11 +44,24 @@ struct TrsvArgs {
     const double* dinv;  // block b at dinv + b * TB * TB, ld TB
     double* b;           // right-hand side in, solution out
     u64* gran;           // 2 granules per entry of x: [2 i] = {epoch, low word}, [2 i + 1] = {epoch, high word}
+    unsigned* ticket;    // block claim counter, zeroed with the granules before every launch
     unsigned* status;    // host-visible: [0] != 0 after a timed-out wait
-    int nblk, G;
+    int nblk;
     unsigned epoch;
-    unsigned long long* dbg;  // developer probe: 8 time stamps per block (100 MHz), or NULL
 };
+
+// The next unclaimed block of the sweep, or -1 when none is left (uniform; the barrier also separates the LDS use of two
+// consecutive blocks of this workgroup).
+__device__ __forceinline__ int claim_block(unsigned* ticket, int nblk, int* slot)
+{
+    if (threadIdx.x == 0) {
+        const unsigned i = __hip_atomic_fetch_add((gu32*)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *slot = i < (unsigned)nblk ? (int)i : -1;
+    }
+    __syncthreads();
+    const int r = __builtin_amdgcn_readfirstlane(*slot);
+    return r;
+}
 
 __device__ __forceinline__ u64 gran_load(const u64* p)
 {
@@ -190,9 +211,12 @@ __global__ __launch_bounds__(NT, 2) void trsv_fwd_kernel(const TrsvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double wl[];  // TB x TB inverse block
     __shared__ Shared s;
+    __shared__ int claim_slot;
     const int t = threadIdx.x, rp = t & 63, cg = __builtin_amdgcn_readfirstlane(t >> 6);  // cg: wave-uniform
 #pragma nounroll
-    for (int r = blockIdx.x; r < a.nblk; r += a.G) {
+    for (;;) {
+        const int r = claim_block(a.ticket, a.nblk, &claim_slot);
+        if (r < 0) return;
         const int64_t r0 = (int64_t)r * TB;
         double acc0 = 0.0, acc1 = 0.0;
         double2 A[NC], B[NC];
@@ -293,8 +317,11 @@ __global__ __launch_bounds__(NT, 2) void trsv_bwd_kernel(const TrsvArgs a)
     double* wt = dyn;
     const int t = threadIdx.x, rp = t & 63, cg = __builtin_amdgcn_readfirstlane(t >> 6);  // cg: wave-uniform
     double* red = dyn + WT_ELEMS + cg * (NC * RS);
+    __shared__ int claim_slot;
 #pragma nounroll
-    for (int jj = blockIdx.x; jj < a.nblk; jj += a.G) {
+    for (;;) {
+        const int jj = claim_block(a.ticket, a.nblk, &claim_slot);
+        if (jj < 0) return;
         const int j = a.nblk - 1 - jj;
         const int last = a.nblk - 1;
         const int cnt = last - j;  // tiles L[last - q, j], q = 0 .. cnt - 1
@@ -332,14 +359,10 @@ __global__ __launch_bounds__(NT, 2) void trsv_bwd_kernel(const TrsvArgs a)
                 bwd_fma(B, x.x, x.y, p);
             }
         }
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
-        if (a.dbg) ts0 = wall_clock64();
         // t_j = b_j - u, u = column sums of the partial products
         const double u = wave_reduce_cols(p, rp, red);
-        if (a.dbg) ts1 = wall_clock64();
         if ((rp & 3) == 0) s.tv[col] = bj - u;
         __syncthreads();  // tv complete (and the staged inverse)
-        if (a.dbg) ts2 = wall_clock64();
         // x_j = W_j^T t_j: the lane owns the outputs 2 rp, 2 rp + 1, its wave the rows 16 cg .. 16 cg + 15 of W_j
         double x0 = 0.0, x1 = 0.0;
         if (2 * rp < 16 * (cg + 1)) {
@@ -359,20 +382,12 @@ __global__ __launch_bounds__(NT, 2) void trsv_bwd_kernel(const TrsvArgs a)
         s.part[cg][2 * rp] = x0;
         s.part[cg][2 * rp + 1] = x1;
         __syncthreads();
-        if (a.dbg) ts3 = wall_clock64();
         if (t < TB) {
             const double x = sum_parts(s, t);
             publish_entry(a, j0 + t, x);
             if (j0 + t < a.n) a.b[j0 + t] = x;
         }
         __syncthreads();  // wt / part / tv are reused by the next block of this workgroup
-        if (a.dbg && t == 0) {
-            a.dbg[8 * j + 0] = ts0;
-            a.dbg[8 * j + 1] = ts1;
-            a.dbg[8 * j + 2] = ts2;
-            a.dbg[8 * j + 3] = ts3;
-            a.dbg[8 * j + 4] = wall_clock64();
-        }
     }
 }
 
@@ -384,7 +399,7 @@ int launch_trsv(fr_ctx* ctx, const fr_chol* c, double* b, bool fwd, int prof_cls
     if (n <= 0) return FR_OK;
     const int nblk = (int)((n + TB - 1) / TB);
     FR_TRY(ensure_status_word(ctx));
-    const size_t gran_bytes = sizeof(u64) * 2 * (size_t)nblk * TB;
+    const size_t gran_bytes = sizeof(u64) * 2 * (size_t)nblk * TB + 64;  // + the ticket word
     if (ctx->trsv_gran_cap < gran_bytes) {
         if (ctx->trsv_gran) {
             (void)hipStreamSynchronize(ctx->stream);
@@ -405,16 +420,13 @@ int launch_trsv(fr_ctx* ctx, const fr_chol* c, double* b, bool fwd, int prof_cls
     a.dinv = c->dinv;
     a.b = b;
     a.gran = (u64*)ctx->trsv_gran;
+    a.ticket = (unsigned*)((char*)ctx->trsv_gran + gran_bytes - 64);
     a.status = ctx->dev_status;
     a.nblk = nblk;
-    a.G = nblk < ctx->num_cus ? nblk : ctx->num_cus;
     a.epoch = 1u;
-    a.dbg = nullptr;
-    if (ctx->panel_debug && ctx->panel_dbg && !fwd && nblk <= 512) {
-        void* d = nullptr;
-        FR_HIP(ctx, hipHostGetDevicePointer(&d, ctx->panel_dbg, 0));
-        a.dbg = (unsigned long long*)d;
-    }
+    // one workgroup per CU (> 64 KiB of LDS); blocks are claimed, so the grid is only a degree of parallelism
+    int G = nblk < ctx->num_cus ? nblk : ctx->num_cus;
+    if (ctx->test_max_wgs > 0 && G > ctx->test_max_wgs) G = ctx->test_max_wgs;
     if (!ctx->trsv_lds_set) {  // per context (= per device): > 64 KiB of dynamic LDS needs the attribute
         FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_fwd_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSV_LDS));
@@ -424,10 +436,15 @@ int launch_trsv(fr_ctx* ctx, const fr_chol* c, double* b, bool fwd, int prof_cls
     }
     ProfScope ps(ctx, prof_cls, (double)n * (double)n, 4.0 * (double)n * (double)n);
     if (fwd)
-        hipLaunchKernelGGL(trsv_fwd_kernel, dim3((unsigned)a.G), dim3(NT), TRSV_LDS, ctx->ls, a);
+        hipLaunchKernelGGL(trsv_fwd_kernel, dim3((unsigned)G), dim3(NT), TRSV_LDS, ctx->ls, a);
     else
-        hipLaunchKernelGGL(trsv_bwd_kernel, dim3((unsigned)a.G), dim3(NT), TRSV_BWD_LDS, ctx->ls, a);
+        hipLaunchKernelGGL(trsv_bwd_kernel, dim3((unsigned)G), dim3(NT), TRSV_BWD_LDS, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
+    ctx->persistent_pending = true;
+    if (ctx->test_force_timeout) {  // test hook: behave as if a hand-off of this launch had timed out
+        FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+        ((volatile unsigned*)ctx->host_status)[0] = 1u;
+    }
     return FR_OK;
 }
 

@@ -134,6 +134,11 @@ class Context:
     def set_option(self, name, value):
         self.check(self.lib.fr_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def counter(self, name):
+        v = ctypes.c_int64(0)
+        self.check(self.lib.fr_ctx_get_counter(self.h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
+
     def synchronize(self):
         self.check(self.lib.fr_ctx_synchronize(self.h))
 

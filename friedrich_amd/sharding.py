@@ -38,7 +38,7 @@ def panel_schedule(n, nb, world):
 
 
 def split_slices(n, k, kb, world, block=128):
-    """option panel_split: the rows below the diagonal block of the panel at k, cut into `world` slices of whole 128-row
+    """option dist_schedule = 1: the rows below the diagonal block of the panel at k, cut into `world` slices of whole 128-row
     blocks -> (slice_rows, [(first row, rows) per rank])  (mirrors split_panel in chol.hip)"""
     slice_rows = -(-(-(-n // world)) // block) * block
     below0 = k + kb

@@ -18,10 +18,13 @@
  *    turns the status back into the reference's panic text.
  *  - Work is enqueued on the context's HIP stream; functions that return host results synchronise that
  *    stream before returning, functions that only touch device memory do not.
- *  - Thread safety: every entry point takes its context's lock, so any number of host threads may call into one
- *    context / one fr_chol concurrently (friedrich's GaussianProcess is Send + Sync: concurrent &self predicts are
- *    legal); the calls of one context take turns on its streams and workspaces.  Handles of different contexts are
- *    independent and run in parallel.
+ *  - Thread safety: every entry point that takes a context or a factor takes the context's lock (fr_last_error and
+ *    fr_ctx_comm_info excepted: they return a pointer into / a snapshot of state the caller must not race with), so any
+ *    number of host threads may call into one context / one fr_chol concurrently (friedrich's GaussianProcess is
+ *    Send + Sync: concurrent &self predicts are legal); the calls of one context take turns on its streams and
+ *    workspaces.  Handles of different contexts are independent and run in parallel -- also on the same GPU: the
+ *    persistent solves claim their blocks in order of arrival and need no co-residency (trsv.hip), so a second
+ *    context's kernels holding CUs only slow them down.
  */
 #ifndef FRIEDRICH_AMD_H
 #define FRIEDRICH_AMD_H
@@ -93,31 +96,33 @@ void fr_ctx_destroy(fr_ctx* ctx);
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
-/* Tunables:
- *   "nb"            outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096];
- *                   "nb_switch_rows" (16384): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
- *   "lookahead"     1 (default): factor the next panel on a second stream under the trailing update
- *   "gemm_tile"     tile-order experiments of the GEMM (0 = default; see gemm_f64.hip)
- *   "narrow_max"    16 (default): solves with at most this many right-hand sides use memory-bound kernels instead of the
- *                   128-wide GEMM tiles
- *   "splitk"        1 (default): products with few result tiles and a deep contraction are cut along K; 0: never
- *   "leaf512"       1 (default): wide triangular solves (>= 256 right-hand sides) end in 512-row leaves against
- *                   explicit inverses of the 512 x 512 diagonal blocks, built on demand; 0: 128-row leaves only
- *   "refine"        -1 (default): automatic -- see fr_chol_conditioning; 0: never; 1: always.  "refine_threshold": 30
- *   "trsv"          1 (default): solves with ONE right-hand side run as one persistent launch per direction
- *   "predict_assoc" 0 (default): predict as the reference associates it, prior + (K^-1 K*)^T y  (mod.rs:234-241,
- *                   two n x m triangular solves);  1: prior + K*^T (K^-1 y), the same value up to rounding with two
- *                   n x 1 solves instead
- *   "xcd_reserve"   -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
- *                   the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, nb <= 512 only: DESIGN.md
- *                   section 5); 0: never; 1..4 with "xcd_reserve_rest" / "xcd_reserve2" / "xcd_reserve_rest2": explicit tiers
- *   "la_merge"      0 (default: off); e.g. 16384: while more than this many rows (and at most "la_merge_max", 36864) remain,
- *                   look-ahead update and trailing update of a single-GPU factorisation are one launch (the next panel's
- *                   tiles first, counted; -0.6 ... -1.3 % at N = 24576 ... 32768).  Needs kernels of two streams to run
- *                   concurrently: under tools that serialise kernel execution (rocprofv3 --pmc) its in-kernel wait times out
- *   developer probes kept behind options (measured, not adopted): "panel_fused", "panel_crit",
- *   "panel_rl", "syrk_dynamic", "k4_yield", "panel_split" (multi-GPU: section 6) */
+/* Tunables (15 names; everything else the library decides from the problem size):
+ *   "nb"             outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
+ *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
+ *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
+ *   "xcd_reserve"    -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
+ *                    the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, nb <= 512 only: DESIGN.md
+ *                    section 5); 0: never; 1..4: that many XCDs for the whole factorisation
+ *   "dist_schedule"  sharded (multi-GPU) factorisation, how a panel step travels: 0 = the owner solves the whole panel, one
+ *                    broadcast; 1 = diagonal block broadcast, rows below scattered / solved per rank / all-gathered;
+ *                    2 (default) = as 1 with the chain of diagonal blocks running ahead of the bulk rows
+ *   "splitk"         1 (default): products with few result tiles and a deep contraction are cut along K; 0: never
+ *   "narrow_max"     16 (default): solves with at most this many right-hand sides use memory-bound kernels instead of the
+ *                    128-wide GEMM tiles;  "narrow_batched_max" (-1: by size): up to this many right-hand sides the persistent
+ *                    solve runs in column groups;  "narrow_pair_min" (-1: by size): from this many on, 32 per group
+ *   "leaf512"        1 (default): wide triangular solves (>= 256 right-hand sides) end in 512-row leaves against
+ *                    explicit inverses of the 512 x 512 diagonal blocks, built on demand; 0: 128-row leaves only
+ *   "trsv"           1 (default): solves with few right-hand sides run as one persistent launch per direction; 0: the
+ *                    recursive GEMM / matrix-vector path (what a solve falls back to after a timed-out hand-off)
+ *   "tri_inverse"    1 (default): the gradient terms form L^-1 and K^-1 = W^T W skipping the structural zeros
+ *   "refine"         -1 (default): automatic -- see fr_chol_conditioning; 0: never; 1: always.  "refine_threshold": 30
+ *   "predict_assoc"  0 (default): predict as the reference associates it, prior + (K^-1 K*)^T y  (mod.rs:234-241,
+ *                    two n x m triangular solves);  1: prior + K*^T (K^-1 y), the same value up to rounding with two
+ *                    n x 1 solves instead */
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
+/* Observability: "solve_retries" = how often an entry point of this context repeated its work on the recursive path because a
+ * persistent solve gave up on a hand-off (0 in normal operation); "pool_bytes" = bytes held by the workspace pool. */
+int fr_ctx_get_counter(fr_ctx* ctx, const char* name, int64_t* out);
 
 /* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline leg). */
 typedef enum {

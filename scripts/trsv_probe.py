@@ -42,16 +42,3 @@ for n in [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["81
     ctx.set_option("trsv", 1)
     chol.free()
 
-# backward chain breakdown (in-kernel time stamps)
-n = 16384
-X, y, _ = synth.make_problem(n, 16, cfg=4)
-ls = ctx.mean_pairwise_distance(X)
-hp = synth.default_hyperparameters(X, y, ls)
-k = ("squared_exp", hp["ls"], hp["ampl"])
-chol = ctx.cholesky_from_inputs(k, X, hp["noise"], capacity_hint=n)
-b = torch.from_numpy(y).to(dev)
-ctx.set_option("panel_debug", 4)
-chol.solve(b)
-ctx.synchronize()
-ctx.set_option("panel_debug", 5)
-ctx.set_option("panel_debug", 0)

@@ -45,11 +45,11 @@ def run_ranks(world, fn):
     return results
 
 
-@pytest.mark.parametrize("split", [0, 1], ids=["bcast", "split"])
+@pytest.mark.parametrize("split", [0, 1, 2], ids=["bcast", "split", "chain"])
 @pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.parametrize("n,nb", [(1500, 128), (1024, 256), (700, 128), (100, 128), (2100, 512)])
 def test_sharded_cholesky_matches_oracle(world, n, nb, split):
-    """split = 1: option panel_split -- the owner factors the diagonal block only, the rows below are scattered, every rank
+    """split = 1: option dist_schedule -- the owner factors the diagonal block only, the rows below are scattered, every rank
     solves its slice, one all-gather returns them."""
     k = ("matern2", 0.7, 1.2)
     X = rand_inputs(n, 5, n)
@@ -60,7 +60,7 @@ def test_sharded_cholesky_matches_oracle(world, n, nb, split):
 
     def fn(ctx, rank):
         ctx.set_option("nb", nb)
-        ctx.set_option("panel_split", split)
+        ctx.set_option("dist_schedule", split)
         chol = ctx.cholesky_from_inputs(k, X, 0.1)
         out = (chol.l(), chol.solve(B), chol.info())
         chol.refactor(k, 0.1)  # the optimizer's re-fit takes the same sharded path
@@ -83,10 +83,10 @@ def test_sharded_substitution_log_is_merged():
     st, L_o, idx_o = O.make_cholesky_cov_matrix(k, X, 0.0, 1e-6)
     assert st == 0 and len(idx_o) > 100
 
-    for split in (0, 1):
+    for split in (0, 1, 2):
         def fn(ctx, rank):
             ctx.set_option("nb", 128)
-            ctx.set_option("panel_split", split)
+            ctx.set_option("dist_schedule", split)
             chol = ctx.cholesky_from_inputs(k, X, 0.0, eps=1e-6)
             idx = chol.substitutions()
             chol.free()

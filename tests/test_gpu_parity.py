@@ -617,12 +617,10 @@ def test_degenerate_sizes(ctx):
         chol.free()
 
 
-@pytest.mark.parametrize("opt,val", [("panel_fused", 1), ("panel_fused", 2), ("panel_fused", 3), ("panel_fused", 4), ("syrk_dynamic", 1),
-                                     ("k4_yield", 1), ("lookahead", 0), ("nb", 1024), ("la_merge", 1)])
-def test_probe_options_keep_the_factor(ctx, opt, val):
-    """The design probes kept behind options (resident diagonal-block server, fused row-tile panel
-    kernel, rest kernel, dynamically pulled trailing update, cooperative yield) stay correct: the oracle's factor, the same
-    conditioning estimate as the default path."""
+@pytest.mark.parametrize("opt,val", [("lookahead", 0), ("nb", 1024)])
+def test_schedule_options_keep_the_factor(ctx, opt, val):
+    """Without look-ahead, and with 1024-column panels that switch to 512 columns for the tail (the large-N schedule forced
+    onto a small matrix): the oracle's factor, the same conditioning estimate as the default path."""
     k = PD_KERNELS[0]
     n = 2700
     X = rand_inputs(n, 3, 4242)
@@ -647,11 +645,10 @@ def test_probe_options_keep_the_factor(ctx, opt, val):
 
 
 @pytest.mark.parametrize("n", [1536, 2500, 3200])
-def test_xcd_reservation_and_panel_schedules(ctx, n):
+def test_xcd_reservation(ctx, n):
     """The look-ahead pipeline with XCDs set aside for the panel chain (gemm_f64.hip: trailing-update tiles CLAIMED by the
-    workgroups that do not sit on the panel stream's XCDs, panel launches on the b % 8 < R workgroups) and the panel
-    schedules built on it (critical / bulk rows, per-sub-panel rest launches, right-looking chain steps): every setting
-    gives the oracle's factor, the default (automatic reservation) and "off" bit for bit the same one."""
+    workgroups that do not sit on the panel stream's XCDs, panel launches on the b % 8 < R workgroups): every setting gives
+    bit for bit the factor of the default (automatic reservation) -- same arithmetic, only placed differently."""
     k = PD_KERNELS[0]
     X = rand_inputs(n, 3, 77 + n)
     st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
@@ -659,28 +656,14 @@ def test_xcd_reservation_and_panel_schedules(ctx, n):
     chol = ctx.cholesky_from_inputs(k, X, 0.1)
     L_auto = chol.l()
     assert rel_err(L_auto, L_o) < TOL
-    settings = [  # (xcd_reserve, xcd_reserve2 / rest2, panel_crit, panel_rl)
-        (0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (4, 0, 0, 0), (1, 3, 0, 0), (1, 0, 1, 0), (2, 0, 2, 0), (3, 0, 0, 1), (2, 4, 0, 1), (3, 0, 0, 2), (2, 4, 0, 2)]
     try:
-        for (r1, r2, crit, rl) in settings:
+        for r1 in (0, 1, 2, 3, 4):
             ctx.set_option("xcd_reserve", r1)
-            ctx.set_option("xcd_reserve_rest", 0)
-            ctx.set_option("xcd_reserve2", r2)
-            ctx.set_option("xcd_reserve_rest2", 2048)
-            ctx.set_option("panel_crit", crit)
-            ctx.set_option("panel_rl", rl)
             for rep in range(2):  # (twice: the claim counters are recycled, the published XCD is known the second time)
                 chol.refactor(k, 0.1)
-                L = chol.l()
-                assert rel_err(L, L_o) < TOL, (r1, r2, crit, rl)
-                if crit != 2 and rl == 0:
-                    assert np.array_equal(L, L_auto), (r1, r2, crit, rl)  # same arithmetic, only placed differently
-                else:
-                    assert rel_err(L, L_auto) < 1e-12
+                assert np.array_equal(chol.l(), L_auto), r1
     finally:
-        for o, v in (("xcd_reserve", -1), ("xcd_reserve_rest", 0), ("xcd_reserve2", 0), ("xcd_reserve_rest2", 0), ("panel_crit", 0),
-                     ("panel_rl", 0)):
-            ctx.set_option(o, v)
+        ctx.set_option("xcd_reserve", -1)
     chol.free()
 
 

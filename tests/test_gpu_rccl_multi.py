@@ -32,7 +32,7 @@ def _worker(rank, world, port, n, nb, split, out_dir):
     ctx.comm_init(rank, world, ids[0])
     ctx.comm_selftest()
     ctx.set_option("nb", nb)
-    ctx.set_option("panel_split", split)
+    ctx.set_option("dist_schedule", split)
     k = ("matern2", 0.7, 1.2)
     X = rand_inputs(n, 5, n)
     chol = ctx.cholesky_from_inputs(k, X, 0.1)
@@ -43,7 +43,7 @@ def _worker(rank, world, port, n, nb, split, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("split", [0, 1], ids=["bcast", "split"])
+@pytest.mark.parametrize("split", [0, 1, 2], ids=["bcast", "split", "chain"])
 def test_rccl_two_processes_sharded_factor(tmp_path, split):
     torch = pytest.importorskip("torch")
     if torch.cuda.device_count() < 2:

@@ -11,7 +11,7 @@ from conftest import ROOT, rand_inputs, rel_err
 
 
 def _worker_split(rank, world, port, n, nb, out_dir):
-    """the split variant (option panel_split): diagonal block by the owner + broadcast, scatter of the rows below, every
+    """the split variant (option dist_schedule = 1): diagonal block by the owner + broadcast, scatter of the rows below, every
     rank solves its slice, all-gather"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
