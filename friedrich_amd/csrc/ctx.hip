@@ -215,13 +215,14 @@ int Staged::inout(double* p, int64_t r, int64_t c, int64_t ldp)
 
 int Staged::commit()
 {
-    if (!owns || !host || rows == 0 || cols == 0) {
-        // device destination: nothing to copy and normally no synchronisation -- unless a persistent solve was launched since
-        // the last status check: its hand-offs can time out, and the caller must learn that before it trusts the result
-        if (!ctx->persistent_pending) return FR_OK;
+    // A persistent solve launched since the last status check may have given up on a hand-off: the caller must learn that
+    // BEFORE its memory is overwritten with a partial result (the entry point then repeats the work from the caller's intact
+    // operand, solve_retry) -- and also when the destination is device memory, where there is otherwise nothing to wait for.
+    if (ctx->persistent_pending) {
         FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return check_status_word(ctx);
+        FR_TRY(check_status_word(ctx));
     }
+    if (!owns || !host || rows == 0 || cols == 0) return FR_OK;
     FR_HIP(ctx, hipMemcpy2DAsync(host, sizeof(double) * host_ld, dev, sizeof(double) * ld, sizeof(double) * rows, cols,
                                  is_device_ptr(host) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
