@@ -146,7 +146,23 @@ static int exchange_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t
     return FR_OK;
 }
 
-// The split variant of a panel step (option panel_split): the owner factors the kb x kb DIAGONAL block only and
+// rows x kb block S (leading dimension lds) of still unsolved rows of the panel at column k  ->  S L_kk^-T, against the factored
+// kb x kb diagonal block in A and its 128-block inverses: left-looking over the 128-column sub-panels,
+// S_s <- (S_s - S_{<s} L[s, <s]^T) W_s^T.  Every element's arithmetic is independent of how the rows are cut into blocks.
+static int solve_rows(fr_ctx* ctx, double* S, int64_t lds, int64_t rows, const double* A, int64_t ld, int64_t k, int64_t kb,
+                      const double* dblk)
+{
+    const int64_t nblk = (kb + IB - 1) / IB;
+    for (int64_t s = 0; s < nblk; ++s) {
+        const int64_t c0 = s * IB, cs = imin(IB, kb - c0);
+        if (s > 0)
+            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, rows, cs, c0, S, lds, false, A + (k + c0) + k * ld, ld, false, -1.0, 1.0, S + c0 * lds, lds));
+        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, rows, cs, cs, S + c0 * lds, lds, false, dblk + s * INV_ELEMS, IB, false, 1.0, 0.0, S + c0 * lds, lds));
+    }
+    return FR_OK;
+}
+
+// The split variant of a panel step (option dist_schedule = 1): the owner factors the kb x kb DIAGONAL block only and
 // broadcasts it with its inverse blocks (2.5 MB at kb = 512); the still unsolved rows below it are scattered in W equal
 // slices (each over its own xGMI link), every rank solves its slice against the diagonal block -- the serial part of the
 // step shrinks from "the whole panel on one GPU" to "the diagonal block on one GPU" -- and one all-gather, which moves
@@ -179,24 +195,205 @@ static int split_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k,
     }
     if (below <= 0) return FR_OK;
     FR_TRY(comm_scatter(ctx, slices, (size_t)(slice_rows * kb), owner));
-    const int64_t mine = rows_of(me);
-    if (mine > 0) {
-        // left-looking over the 128-column sub-panels: S_s <- (S_s - S_{<s} L[s, <s]^T) W_s^T
-        double* S = slices + (int64_t)me * slice_rows * kb;
-        for (int64_t s = 0; s < nblk; ++s) {
-            const int64_t c0 = s * IB, cs = imin(IB, kb - c0);
-            if (s > 0)
-                FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, mine, cs, c0, S, slice_rows, false, A + (k + c0) + k * ld, ld, false, -1.0, 1.0,
-                            S + c0 * slice_rows, slice_rows));
-            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, mine, cs, cs, S + c0 * slice_rows, slice_rows, false, dblk + s * INV_ELEMS, IB, false, 1.0,
-                        0.0, S + c0 * slice_rows, slice_rows));
-        }
-    }
+    if (rows_of(me) > 0) FR_TRY(solve_rows(ctx, slices + (int64_t)me * slice_rows * kb, slice_rows, rows_of(me), A, ld, k, kb, dblk));
     FR_TRY(comm_allgather(ctx, slices + (int64_t)me * slice_rows * kb, slices, (size_t)(slice_rows * kb)));
     for (int q = 0; q < W; ++q)
         if (rows_of(q) > 0)
             FR_TRY(launch_copy(ctx, slices + (int64_t)q * slice_rows * kb, slice_rows, A + row0 + (int64_t)q * slice_rows + k * ld, ld,
                                rows_of(q), kb));
+    return FR_OK;
+}
+
+// ---- sharded factorisation, schedule 2: the chain of diagonal blocks first ------------------------------------------------
+// What is serial in a right-looking Cholesky over block columns dealt round-robin to W ranks is the chain of diagonal
+// blocks: D_p needs the row tile p of every earlier panel.  Schedules 0 / 1 put the whole panel step on that chain
+// (factor all rows -> broadcast, or diagonal block -> scatter -> solves -> all-gather, one after the other on one stream and
+// one communicator).  Here the chain carries only what the NEXT diagonal block waits for:
+//   H_p = [D_p, its 128-block inverses]     fan-out from the owner to every rank        (~2.5 MB at nb = 512)
+//   M_p = R1_p = L[panel p + 1's rows, p]   solved by the owner itself, fan-out          (~2 MB)
+// on the panel stream / first communicator; the next owner applies R1_p to its diagonal block at once (u1) and factors D_p+1.
+// The rows below R1_p (the bulk) follow on their own stream and communicator: scatter of the unsolved rows in W slices (one
+// xGMI link each), every rank solves its slice against D_p, one all-gather -- 1 / W of the panel over every link of every GPU.
+// The trailing updates (main stream) take a panel once its bulk has arrived; each rank updates its NEAREST owned block
+// column first (for the next owner: the rows of R1_p+1 before the others), because that is the column the chain waits for.
+// Dependencies between the three streams are HIP events; the critical path per panel is
+//   max( D factor + R1 solve + two fan-outs,  (bulk latency + first look-ahead tile + R1 solve) / 2 )
+// instead of their sum (D_p+1 needs the bulk of panel p - 1, not of panel p).  DESIGN.md section 6 has the model.
+// Every rank issues the same sequence of communication calls in the same host order, and that order is a topological order of
+// the dependency graph -- which is what keeps two communicators used side by side free of deadlock (comm.hip).
+enum { EV_HEAD = 0, EV_MSG = 1, EV_BULK = 2, EV_LA1 = 3, EV_NEAR = 4 };
+
+static int potrf_dist_chain(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t col0, int mode, double sub, double* dinv,
+                            int64_t* info, int64_t nb)
+{
+    const int W = ctx->world, me = ctx->rank;
+    if (nb % IB != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "multi-GPU factorisation needs nb %% 128 == 0");
+    hipStream_t S0 = ctx->stream, S1 = ctx->stream2, S3 = ctx->stream3;
+    for (int kind = 0; kind < 5; ++kind)
+        for (int i = 0; i < 4; ++i)
+            if (!ctx->ev_ring[kind][i]) FR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ring[kind][i], hipEventDisableTiming));
+    const int64_t P = (n + nb - 1) / nb;
+    auto kof = [&](int64_t p) { return imin(p * nb, n); };
+    auto owner = [&](int64_t p) { return (int)(p % W); };
+    auto ev = [&](int kind, int64_t p) { return ctx->ev_ring[kind][p & 3]; };
+    const int64_t kbm = imin(nb, n);
+    const int64_t head_cap = round_up(kbm * kbm + ((kbm + IB - 1) / IB) * INV_ELEMS, kAlign);
+    const int64_t sr_max = round_up((n + W - 1) / W, IB);
+    WsGuard hg(ctx), mg(ctx), sg(ctx);
+    double* hb = hg.get(sizeof(double) * (size_t)head_cap);
+    double* mb = mg.get(sizeof(double) * (size_t)(kbm * kbm));
+    double* sb = sg.get(sizeof(double) * (size_t)W * (size_t)sr_max * (size_t)kbm);
+    // every allocation of this rank is behind it: agree with the peers BEFORE the first exchange, so that a rank that ran
+    // out of memory does not leave the others inside a transfer that never completes
+    bool all_ok = true;
+    FR_TRY(comm_agree(ctx, hb && mb && sb, &all_ok));
+    if (!hb || !mb || !sb) return FR_OUT_OF_MEMORY;
+    if (!all_ok) return set_err(ctx, FR_OUT_OF_MEMORY, "a peer rank could not allocate its panel buffers: sharded factorisation abandoned on every rank");
+    if (ctx->xcd_reserve != 0 && ctx->claim_ring) {
+        FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 2 * kClaimSlots, S0));
+        ctx->claim_next = 0;
+    }
+    int st = FR_OK;
+    auto fail = [&](int code) {
+        comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
+        ctx->ls = S0;
+        ctx->reserve_now = 0;
+        (void)hipStreamSynchronize(S1);
+        (void)hipStreamSynchronize(S3);
+        return code;
+    };
+#define CH_HIP(call)                              \
+    do {                                          \
+        if ((call) != hipSuccess) {               \
+            (void)hipGetLastError();              \
+            return fail(set_err(ctx, FR_HIP_ERROR, "%s failed (%s:%d)", #call, __FILE__, __LINE__)); \
+        }                                         \
+    } while (0)
+#define CH_TRY(call)                              \
+    do {                                          \
+        st = (call);                              \
+        if (st != FR_OK) return fail(st);         \
+    } while (0)
+    // both side streams start after everything already queued on the main stream (Gram assembly)
+    CH_HIP(hipEventRecord(ctx->ev_la, S0));
+    CH_HIP(hipStreamWaitEvent(S1, ctx->ev_la, 0));
+    CH_HIP(hipStreamWaitEvent(S3, ctx->ev_la, 0));
+    ++ctx->panel_epoch;
+    for (int64_t p = 0; p < P; ++p) {
+        const int64_t k = kof(p), k1 = kof(p + 1), k2 = kof(p + 2), k3 = kof(p + 3);
+        const int64_t kb = k1 - k, kb1 = k2 - k1, kb2 = k3 - k2, below = n - k2;
+        const int own = owner(p);
+        const int64_t nblk = (kb + IB - 1) / IB;
+        const int64_t head_count = round_up(kb * kb + nblk * INV_ELEMS, kAlign);
+        double* dblk = dinv + (k / IB) * INV_ELEMS;
+        // The chain bounds a sharded factorisation from the first panel on (a rank's share of a trailing update is 1 / W of it):
+        // the main and bulk streams' products keep off the XCDs of the diagonal-block kernels while a rank's share of the
+        // trailing update is shorter than a chain step (~0.6 ms: (n - k)^2 nb / W flop at 60 TF/s)
+        ctx->reserve_now = 0;
+        if (ctx->claim_ring && kb <= 512) {
+            if (ctx->xcd_reserve < 0) {
+                const double share_ms = (double)(n - k1) * (double)(n - k1) * (double)kb / (double)W / 6.0e10;
+                ctx->reserve_now = share_ms < 0.6 ? 2 : (share_ms < 1.2 ? 1 : 0);
+            } else {
+                ctx->reserve_now = (int)ctx->xcd_reserve;
+            }
+        }
+        // ---- 1. chain: D_p on its owner (its block carries every update: u1 of round p - 1 is ahead on this stream)
+        ctx->ls = S1;
+        if (me == own) {
+            CH_TRY(factor_panel(ctx, A, ld, k1, k, kb, col0, mode, sub, dinv, info, nullptr));  // rows k .. k1 only
+            CH_TRY(launch_copy(ctx, A + k + k * ld, ld, hb, kb, kb, kb));
+            CH_HIP(hipMemcpyAsync(hb + kb * kb, dblk, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, S1));
+        }
+        // ---- 2. H_p
+        CH_TRY(comm_fanout(ctx, hb, (size_t)head_count, own, 0));
+        if (me != own) {
+            CH_TRY(launch_copy(ctx, hb, kb, A + k + k * ld, ld, kb, kb));
+            CH_HIP(hipMemcpyAsync(dblk, hb + kb * kb, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, S1));
+        }
+        CH_HIP(hipEventRecord(ev(EV_HEAD, p), S1));
+        // ---- 3. M_p = R1_p: the rows of the next panel's diagonal block, solved by the owner in place
+        if (kb1 > 0) {
+            double* R1 = A + k1 + k * ld;
+            if (me == own) {
+                if (p > 0) CH_HIP(hipStreamWaitEvent(S1, ev(EV_LA1, p), 0));  // these rows carry panel p - 1's update (main stream)
+                CH_TRY(solve_rows(ctx, R1, ld, kb1, A, ld, k, kb, dblk));
+                CH_TRY(launch_copy(ctx, R1, ld, mb, kb1, kb1, kb));
+            }
+            CH_TRY(comm_fanout(ctx, mb, (size_t)(kb1 * kb), own, 0));
+            if (me != own) CH_TRY(launch_copy(ctx, mb, kb1, R1, ld, kb1, kb));
+            CH_HIP(hipEventRecord(ev(EV_MSG, p), S1));
+            if (me == owner(p + 1)) {
+                // u1: the next diagonal block takes panel p's update here, on the chain; the updates of the panels before
+                // (this rank's main stream, nearest column first) are ordered in front of it
+                if (p > 0) CH_HIP(hipStreamWaitEvent(S1, ev(EV_NEAR, p - 1), 0));
+                CH_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, kb1, kb1, kb, R1, ld, false, R1, ld, false, -1.0, 1.0, A + k1 + k1 * ld, ld, true));
+            }
+        }
+        // ---- 4. bulk: the rows from k2 on, in W slices of whole 128-row blocks
+        if (below > 0) {
+            ctx->ls = S3;
+            const int64_t sr = round_up((below + W - 1) / W, IB);
+            auto rows_of = [&](int q) { return imax(0, imin(sr, below - (int64_t)q * sr)); };
+            if (me == own) {
+                if (p > 0) CH_HIP(hipStreamWaitEvent(S3, ev(EV_NEAR, p - 1), 0));  // column p carries every update of the panels before
+                for (int q = 0; q < W; ++q)
+                    if (rows_of(q) > 0)
+                        CH_TRY(launch_copy(ctx, A + k2 + (int64_t)q * sr + k * ld, ld, sb + (int64_t)q * sr * kb, sr, rows_of(q), kb));
+            }
+            CH_TRY(comm_scatter(ctx, sb, (size_t)(sr * kb), own, 1));
+            CH_HIP(hipStreamWaitEvent(S3, ev(EV_HEAD, p), 0));  // D_p and its inverses are in place on this rank
+            if (rows_of(me) > 0) CH_TRY(solve_rows(ctx, sb + (int64_t)me * sr * kb, sr, rows_of(me), A, ld, k, kb, dblk));
+            CH_TRY(comm_allgather(ctx, sb + (int64_t)me * sr * kb, sb, (size_t)(sr * kb), 1));
+            for (int q = 0; q < W; ++q)
+                if (rows_of(q) > 0)
+                    CH_TRY(launch_copy(ctx, sb + (int64_t)q * sr * kb, sr, A + k2 + (int64_t)q * sr + k * ld, ld, rows_of(q), kb));
+            CH_HIP(hipEventRecord(ev(EV_BULK, p), S3));
+        }
+        // ---- 5. trailing updates with panel p (main stream): the nearest owned block column first
+        if (kb1 > 0) {
+            ctx->ls = S0;
+            CH_HIP(hipStreamWaitEvent(S0, ev(EV_MSG, p), 0));
+            if (below > 0) CH_HIP(hipStreamWaitEvent(S0, ev(EV_BULK, p), 0));
+            const int64_t q = p + 1 + (((int64_t)me - (p + 1)) % W + W) % W;  // nearest panel after p that this rank owns
+            const double* Lp = A + k * ld;  // block column p of the factor: row r at Lp + r
+            if (q == p + 1) {
+                // the next panel is mine: its diagonal block was updated on the chain (u1); the rows of R1_p+1 go first
+                if (kb2 > 0)
+                    CH_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, kb2, kb1, kb, Lp + k2, ld, false, Lp + k1, ld, false, -1.0, 1.0, A + k2 + k1 * ld, ld));
+                CH_HIP(hipEventRecord(ev(EV_LA1, p + 1), S0));
+                if (n > k3)
+                    CH_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - k3, kb1, kb, Lp + k3, ld, false, Lp + k1, ld, false, -1.0, 1.0, A + k3 + k1 * ld, ld));
+            } else if (q < P) {
+                const int64_t kq = kof(q), wq = kof(q + 1) - kq;
+                CH_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, n - kq, wq, kb, Lp + kq, ld, false, Lp + kq, ld, false, -1.0, 1.0, A + kq + kq * ld, ld));
+            }
+            CH_HIP(hipEventRecord(ev(EV_NEAR, p), S0));
+            const int64_t ks = kof(q + 1);  // the owned block columns behind the nearest one
+            if (q < P && n > ks) {
+                GemmDesc g;
+                g.M = n - ks; g.N = n - ks; g.K = kb;
+                g.A = Lp + ks; g.lda = ld; g.a_kmajor = false;
+                g.B = Lp + ks; g.ldb = ld; g.b_kmajor = false;
+                g.D = A + ks + ks * ld; g.ldd = ld;
+                g.Cin = g.D; g.ldcin = ld;
+                g.alpha = -1.0; g.beta = 1.0; g.lower = true; g.prof_cls = FR_PROF_SYRK;
+                g.own_world = W; g.own_rank = me; g.own_nb = nb; g.own_col0 = ks;
+                CH_TRY(launch_gemm(ctx, g));
+            }
+        }
+    }
+    // the factorisation is complete when all three streams are
+    ctx->ls = S1;
+    if (ctx->xcd_reserve != 0) CH_TRY(launch_release_xcds(ctx, ctx->panel_epoch));
+    CH_HIP(hipEventRecord(ctx->ev_panel, S1));
+    CH_HIP(hipEventRecord(ctx->ev_bulk, S3));
+    CH_HIP(hipStreamWaitEvent(S0, ctx->ev_panel, 0));
+    CH_HIP(hipStreamWaitEvent(S0, ctx->ev_bulk, 0));
+#undef CH_HIP
+#undef CH_TRY
+    ctx->ls = S0;
+    ctx->reserve_now = 0;
     return FR_OK;
 }
 
@@ -224,6 +421,8 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     }
     const int world = dist ? ctx->world : 1;
     const int rank = ctx->rank;
+    if (world > 1 && ctx->dist_schedule == 2 && ctx->stream3 && !ctx->refine_now && mode != 3)
+        return potrf_dist_chain(ctx, A, ld, n, col0, mode, sub, dinv, info, nb);
     if (world > 1 && nb % IB != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "multi-GPU factorisation needs nb %% 128 == 0");
     const bool la = (world > 1) || (ctx->lookahead && ctx->stream2 && n > 2 * nb && ctx->ls == ctx->stream);
     if (!la) {

@@ -173,20 +173,50 @@ static int local_scatter(fr_ctx* ctx, char* buf, size_t bytes_per_rank, int root
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------
+// which = 0: the context's first communicator (panel stream: everything the schedules 0 / 1 send, the diagonal chain of
+// schedule 2); which = 1: the second one (bulk stream of schedule 2: scatter / all-gather of the rows below the chain).  Two
+// communicators because operations of ONE communicator execute in issue order whatever stream they are on: the 4.5 MB of
+// the diagonal chain would queue behind the 100 MB bulk transfers of the previous panel.  Every rank issues the operations
+// of BOTH communicators in the same host order (chol.hip, potrf_dist_chain), which is what keeps two concurrently used
+// communicators deadlock-free: the earliest unfinished operation in that order has all its dependencies complete and is at
+// the head of its queue on every rank.
+static inline ncclComm_t pick_comm(fr_ctx* ctx, int which) { return (ncclComm_t)((which == 1 && ctx->comm2) ? ctx->comm2 : ctx->comm); }
+
 // Scatter: slice r (count doubles at buf + r * count) of the ROOT's buffer lands in the same place of rank r's buffer.
 // RCCL: one grouped set of point-to-point sends from the root, each over its own xGMI link.
-int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root)
+int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root, int which)
 {
     if (ctx->world <= 1 || count_per_rank == 0) return FR_OK;
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count_per_rank * (ctx->world - 1));
     if (ctx->local) return local_scatter(ctx, (char*)buf, 8 * count_per_rank, root);
+    ncclComm_t comm = pick_comm(ctx, which);
     FR_NCCL(ctx, g_rccl.GroupStart());
     if (ctx->rank == root) {
         for (int r = 0; r < ctx->world; ++r)
             if (r != root)
-                FR_NCCL(ctx, g_rccl.Send(buf + (size_t)r * count_per_rank, count_per_rank, ncclDouble, r, (ncclComm_t)ctx->comm, ctx->ls));
+                FR_NCCL(ctx, g_rccl.Send(buf + (size_t)r * count_per_rank, count_per_rank, ncclDouble, r, comm, ctx->ls));
     } else {
-        FR_NCCL(ctx, g_rccl.Recv(buf + (size_t)ctx->rank * count_per_rank, count_per_rank, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->ls));
+        FR_NCCL(ctx, g_rccl.Recv(buf + (size_t)ctx->rank * count_per_rank, count_per_rank, ncclDouble, root, comm, ctx->ls));
+    }
+    FR_NCCL(ctx, g_rccl.GroupEnd());
+    return FR_OK;
+}
+
+// Fan-out: the root's buffer to every rank as ONE grouped set of point-to-point sends, each over its own xGMI link (the
+// node is fully connected: 7 links per GPU).  For the few MB of a diagonal block this is the latency-optimal broadcast -- one
+// hop, every link busy at once -- where a ring / tree broadcast forwards through intermediate ranks.
+int comm_fanout(fr_ctx* ctx, double* buf, size_t count, int root, int which)
+{
+    if (ctx->world <= 1 || count == 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count * (ctx->world - 1));
+    if (ctx->local) return local_bcast(ctx, buf, 8 * count, root);
+    ncclComm_t comm = pick_comm(ctx, which);
+    FR_NCCL(ctx, g_rccl.GroupStart());
+    if (ctx->rank == root) {
+        for (int r = 0; r < ctx->world; ++r)
+            if (r != root) FR_NCCL(ctx, g_rccl.Send(buf, count, ncclDouble, r, comm, ctx->ls));
+    } else {
+        FR_NCCL(ctx, g_rccl.Recv(buf, count, ncclDouble, root, comm, ctx->ls));
     }
     FR_NCCL(ctx, g_rccl.GroupEnd());
     return FR_OK;
@@ -213,7 +243,7 @@ int comm_allgather_i64(fr_ctx* ctx, const int64_t* send, int64_t* recv, size_t c
     return FR_OK;
 }
 
-int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_per_rank)
+int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_per_rank, int which)
 {
     if (ctx->world <= 1) {
         if (send != recv)
@@ -222,7 +252,7 @@ int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_p
     }
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count_per_rank * ctx->world);
     if (ctx->local) return local_allgather(ctx, send, recv, 8 * count_per_rank);
-    FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, (ncclComm_t)ctx->comm, ctx->ls));
+    FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, pick_comm(ctx, which), ctx->ls));
     return FR_OK;
 }
 
@@ -250,6 +280,10 @@ int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok)
 // transport) rather than waiting forever.  The context cannot take part in collectives afterwards.
 void comm_abort(fr_ctx* ctx)
 {
+    if (ctx->comm2 && g_rccl.CommAbort) {
+        (void)g_rccl.CommAbort((ncclComm_t)ctx->comm2);
+        ctx->comm2 = nullptr;
+    }
     if (ctx->comm && g_rccl.CommAbort) {
         (void)g_rccl.CommAbort((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
@@ -272,6 +306,10 @@ extern "C" {
 
 void fr_comm_destroy_internal(fr_ctx* ctx)
 {
+    if (ctx->comm2 && g_rccl.CommDestroy) {
+        g_rccl.CommDestroy((ncclComm_t)ctx->comm2);
+        ctx->comm2 = nullptr;
+    }
     if (ctx->comm && g_rccl.CommDestroy) {
         g_rccl.CommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
@@ -325,6 +363,26 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->world = world_size;
+    if (world_size > 1) {
+        // the second communicator (bulk stream of the chain-first schedule): rank 0 draws its id, the first communicator
+        // carries it to the others
+        ncclUniqueId id2;
+        memset(&id2, 0, sizeof(id2));
+        if (rank == 0) FR_NCCL(ctx, g_rccl.GetUniqueId(&id2));
+        void* d = nullptr;
+        FR_HIP(ctx, hipMalloc(&d, sizeof(id2)));
+        hipError_t e = hipMemcpyAsync(d, &id2, sizeof(id2), hipMemcpyHostToDevice, ctx->stream);
+        ncclResult_t r = ncclSuccess;
+        if (e == hipSuccess) r = g_rccl.Broadcast(d, d, sizeof(id2), ncclChar, 0, comm, ctx->stream);
+        if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(&id2, d, sizeof(id2), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d);
+        if (e != hipSuccess) return set_err(ctx, FR_HIP_ERROR, "handing over the second communicator's id failed: %s", hipGetErrorString(e));
+        if (r != ncclSuccess) return set_err(ctx, FR_RCCL_ERROR, "broadcast of the second communicator's id failed: %s", g_rccl.GetErrorString(r));
+        ncclComm_t comm2 = nullptr;
+        FR_NCCL(ctx, g_rccl.CommInitRank(&comm2, world_size, id2, rank));
+        ctx->comm2 = comm2;
+    }
     return FR_OK;
 }
 
@@ -376,7 +434,15 @@ int fr_ctx_comm_selftest(fr_ctx* ctx)
         const int world_saved = ctx->world;
         if (W == 1 && ctx->comm) ctx->world = 2;  // a 1-rank RCCL communicator: still issue the real collectives
         st = comm_bcast(ctx, d, cnt, 0);
-        if (st == FR_OK) st = comm_allgather(ctx, d + cnt, d + 2 * cnt, cnt);
+        if (st == FR_OK) st = comm_allgather(ctx, d + cnt, d + 2 * cnt, cnt, 0);
+        // the chain-first schedule's calls: a fan-out on the first communicator, an (in-place) all-gather on the second
+        if (st == FR_OK && W > 1) st = comm_fanout(ctx, d, cnt, 0, 0);  // (point-to-point: needs a real peer)
+        if (st == FR_OK && ctx->stream3) {
+            if (hipStreamSynchronize(ctx->ls) != hipSuccess) st = FR_HIP_ERROR;
+            ctx->ls = ctx->stream3;
+            if (st == FR_OK) st = comm_allgather(ctx, d + (2 + (size_t)ctx->rank) * cnt, d + 2 * cnt, cnt, 1);
+            if (st == FR_OK && hipStreamSynchronize(ctx->ls) != hipSuccess) st = FR_HIP_ERROR;
+        }
         ctx->world = world_saved;
         if (st != FR_OK) break;
         if (hipStreamSynchronize(ctx->ls) != hipSuccess ||

@@ -118,6 +118,8 @@ struct fr_ctx {
     size_t trsmn_buf_cap = 0;
     // RCCL
     void* comm = nullptr;   // ncclComm_t
+    void* comm2 = nullptr;  // second communicator over the same ranks (bulk stream of the chain-first schedule)
+    hipEvent_t ev_ring[5][4] = {};  // chain-first schedule: head / message / bulk / first look-ahead tile / nearest column, by panel % 4 (created on first use)
     int64_t* agree_buf = nullptr;  // 1 + world slots of the status agreement (comm_agree)
     void* local = nullptr;  // in-process ("local") communicator: ranks are host threads sharing one device
     int rank = 0;
@@ -367,8 +369,10 @@ int solve_retry(fr_ctx* ctx, F&& body)
 // ---- collectives (comm.hip): RCCL over xGMI, or the in-process local transport; enqueue on ctx->ls ----------
 int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root);
 int comm_allgather_i64(fr_ctx* ctx, const int64_t* send, int64_t* recv, size_t count_per_rank);
-int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_per_rank);
-int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root);  // slice r of the root's buffer -> rank r (same offset)
+// which: 0 = the first communicator, 1 = the second one (bulk stream of the chain-first schedule); see comm.hip
+int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_per_rank, int which = 0);
+int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root, int which = 0);  // slice r of the root's buffer -> rank r (same offset)
+int comm_fanout(fr_ctx* ctx, double* buf, size_t count, int root, int which = 0);            // root's buffer -> every rank, grouped point-to-point
 int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok);  // collective: does EVERY rank report ok?  (synchronises)
 void comm_abort(fr_ctx* ctx);                        // failing rank: tear the communicator down so that peers do not wait forever
 

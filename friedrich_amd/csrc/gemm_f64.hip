@@ -269,7 +269,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.nres = ctx->reserve_now;
     g.epoch = ctx->panel_epoch;
     g.tri = d.tri;
-    if (ctx->reserve_now && d.batch <= 1 && d.own_world <= 1) {
+    if (ctx->reserve_now && d.batch <= 1) {
         if (ctx->ls == ctx->stream2) {
             if (!d.lower) g.place = 2;
         } else {

@@ -47,3 +47,33 @@ def split_slices(n, k, kb, world, block=128):
         lo = below0 + r * slice_rows
         out.append((lo, max(0, min(slice_rows, n - lo))))
     return slice_rows, out
+
+
+# ---- schedule 2 (option dist_schedule = 2, the default): the chain of diagonal blocks first (potrf_dist_chain in chol.hip) ----
+def nearest_owned(p, rank, world):
+    """index of the first panel after p that `rank` owns (may lie beyond the last panel)"""
+    return p + 1 + ((rank - (p + 1)) % world)
+
+
+def chain_rounds(n, nb, world):
+    """One dict per panel p, in the host issue order of potrf_dist_chain:
+         k, k1, k2, k3   first column of panels p, p + 1, p + 2, p + 3 (clamped to n)
+         owner, next     ranks owning panels p and p + 1
+         head            (k, k1): the diagonal block D_p, fanned out with its inverse blocks           [chain stream, comm 0]
+         r1              (k1, k2): rows of R1_p = L[panel p + 1's rows, p], solved by the owner, fanned out  [chain stream, comm 0];
+                         the next owner applies them to its diagonal block at once (u1)
+         bulk            slice_rows and [(first row, rows)] per rank for the rows from k2 on: scatter, per-rank solves,
+                         all-gather                                                                    [bulk stream, comm 1]
+         near[rank]      the panel whose block column `rank` updates first with panel p (its nearest owned one)"""
+    P = -(-n // nb)
+    kof = lambda q: min(q * nb, n)
+    for p in range(P):
+        k, k1, k2, k3 = kof(p), kof(p + 1), kof(p + 2), kof(p + 3)
+        below = n - k2
+        sr = -(-(-(-below // world)) // 128) * 128 if below > 0 else 0
+        yield {
+            "p": p, "k": k, "k1": k1, "k2": k2, "k3": k3, "owner": p % world, "next": (p + 1) % world,
+            "head": (k, k1), "r1": (k1, k2),
+            "bulk": (sr, [(k2 + r * sr, max(0, min(sr, below - r * sr))) for r in range(world)]),
+            "near": {r: nearest_owned(p, r, world) for r in range(world)},
+        }

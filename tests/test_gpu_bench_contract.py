@@ -35,3 +35,21 @@ def test_bench_prints_one_contract_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+
+
+def test_bench_multi_process_setup_with_one_rank():
+    """FRIEDRICH_BENCH_FORCE_DIST=1: the N > 1 set-up of bench.py -- torch.distributed process group over RCCL, ncclUniqueId
+    hand-over, both communicators of the context, the collective self-test (broadcast, all-gather, fan-out, bulk-stream
+    all-gather), barrier + MAX-over-ranks timing -- with the single rank a 1-GPU box has.  A multi-GPU node runs the same code
+    with WORLD_SIZE > 1 (tests/test_gpu_rccl_multi.py covers the sharded factor there)."""
+    env = dict(os.environ, FRIEDRICH_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--n", "3072",
+           "--m", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "strong"

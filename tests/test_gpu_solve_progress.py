@@ -157,6 +157,7 @@ def test_timed_out_solve_is_repeated_on_the_recursive_path():
         for c in (cg, cb):
             Bd = torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t()  # column-major n x 5 on the device
             c.solve(Bd)
+            c.ctx.synchronize()  # device operand: the call does not wait for its stream (friedrich_amd.h, conventions)
             outs.append(Bd.cpu().numpy())
         assert rel_err(outs[1], outs[0]) < 1e-10
         # add_rows: the L21 solve (130 right-hand sides in column groups) is repeated, the append is restartable

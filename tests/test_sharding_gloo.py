@@ -173,3 +173,127 @@ def test_split_slices_cover_the_rows_below_once():
         assert slice_rows % 128 == 0 and slice_rows * world >= n
         rows = [r for lo, cnt in slices for r in range(lo, lo + cnt)]
         assert rows == list(range(k + kb, n))
+
+
+def _worker_chain(rank, world, port, n, nb, out_dir):
+    """schedule 2 (dist_schedule = 2): diagonal chain first -- H_p and R1_p fanned out, u1 on the next owner, the bulk rows by
+    scatter / per-rank solves / all-gather, trailing updates with the nearest owned column first; in the host issue order
+    of potrf_dist_chain (friedrich_amd.sharding.chain_rounds)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scipy.linalg as sl
+    import torch
+    import torch.distributed as dist
+
+    from friedrich_amd import sharding
+    from oracle import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k = ("matern2", 0.7, 1.2)
+    X = rand_inputs(n, 3, 42)
+    P = -(-n // nb)
+    kof = lambda q: min(q * nb, n)
+    A = np.full((n, n), np.nan)
+    for q in range(P):  # Gram: owned block columns only
+        if q % world == rank:
+            j, w = kof(q), kof(q + 1) - kof(q)
+            A[j:, j:j + w] = O.make_covariance_matrix(k, X[j:], X[j:j + w])
+            A[j:j + w, j:j + w] += 0.01 * np.eye(w)
+
+    def bcast(block, src):
+        t = torch.from_numpy(np.ascontiguousarray(block))
+        dist.broadcast(t, src=src)
+        return t.numpy()
+
+    for r in sharding.chain_rounds(n, nb, world):
+        kk, k1, k2, k3, owner = r["k"], r["k1"], r["k2"], r["k3"], r["owner"]
+        kb = k1 - kk
+        # 1 + 2: D_p on its owner, fanned out
+        D = np.zeros((kb, kb))
+        if rank == owner:
+            D = sl.cholesky(A[kk:k1, kk:k1], lower=True)
+        D = bcast(D, owner)
+        A[kk:k1, kk:k1] = D
+        # 3: R1_p solved by the owner, fanned out; u1 on the next owner
+        if k2 > k1:
+            R1 = np.zeros((k2 - k1, kb))
+            if rank == owner:
+                R1 = sl.solve_triangular(D, A[k1:k2, kk:k1].T, lower=True).T
+            R1 = bcast(R1, owner)
+            A[k1:k2, kk:k1] = R1
+            if rank == r["next"]:
+                A[k1:k2, k1:k2] -= R1 @ R1.T
+        # 4: bulk
+        sr, slices = r["bulk"]
+        if sr > 0:
+            bufs = []
+            for q, (lo, rows) in enumerate(slices):
+                b = np.zeros((sr, kb))
+                if rank == owner and rows > 0:
+                    b[:rows] = A[lo:lo + rows, kk:k1]
+                bufs.append(torch.from_numpy(b))
+            mine = torch.zeros((sr, kb), dtype=torch.float64)
+            dist.scatter(mine, bufs if rank == owner else None, src=owner)
+            lo, rows = slices[rank]
+            solved = np.zeros((sr, kb))
+            if rows > 0:
+                solved[:rows] = sl.solve_triangular(D, mine.numpy()[:rows].T, lower=True).T
+            gathered = [torch.zeros((sr, kb), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(gathered, torch.from_numpy(solved))
+            for q, (lo, rows) in enumerate(slices):
+                if rows > 0:
+                    A[lo:lo + rows, kk:k1] = gathered[q].numpy()[:rows]
+        # 5: trailing updates, nearest owned column first
+        if k2 > k1:
+            Lp = A[:, kk:k1]
+            q = r["near"][rank]
+            if q == r["p"] + 1:
+                if k3 > k2:
+                    A[k2:k3, k1:k2] -= Lp[k2:k3] @ Lp[k1:k2].T
+                if n > k3:
+                    A[k3:, k1:k2] -= Lp[k3:] @ Lp[k1:k2].T
+            elif q < P:
+                kq, wq = kof(q), kof(q + 1) - kof(q)
+                A[kq:, kq:kq + wq] -= Lp[kq:] @ Lp[kq:kq + wq].T
+            for j in range(q + 1, P):
+                if j % world == rank:
+                    kj, wj = kof(j), kof(j + 1) - kof(j)
+                    A[kj:, kj:kj + wj] -= Lp[kj:] @ Lp[kj:kj + wj].T
+    np.save(os.path.join(out_dir, f"L{rank}.npy"), np.tril(A))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,nb", [(300, 64), (257, 128), (100, 128), (200, 128)])
+def test_two_rank_chain_schedule(tmp_path, n, nb):
+    """the chain-first schedule (the default of a sharded factorisation) over a 2-rank gloo group"""
+    import torch.multiprocessing as tmp_mp
+
+    from oracle import oracle as O
+
+    world = 2
+    port = 32500 + (os.getpid() % 2000) + n % 7
+    tmp_mp.spawn(_worker_chain, args=(world, port, n, nb, str(tmp_path)), nprocs=world, join=True)
+    X = rand_inputs(n, 3, 42)
+    st, L_o, _ = O.make_cholesky_cov_matrix(("matern2", 0.7, 1.2), X, 0.1)
+    for r in range(world):
+        assert rel_err(np.load(tmp_path / f"L{r}.npy"), np.tril(L_o)) < 1e-11
+
+
+def test_chain_rounds_cover_every_tile_once():
+    """every block column p is split into head / R1 / bulk slices that cover its rows exactly once, and every (panel, later
+    block column) pair is updated by exactly one rank: the owner of the column, either as its nearest column or in the rest"""
+    from friedrich_amd import sharding
+
+    for n, nb, world in [(1000, 128, 3), (4096, 512, 8), (100, 256, 4), (32768, 512, 8), (700, 128, 2)]:
+        P = -(-n // nb)
+        rounds = list(sharding.chain_rounds(n, nb, world))
+        assert [r["k"] for r in rounds] == list(range(0, n, nb))
+        for r in rounds:
+            rows = list(range(*r["head"])) + list(range(*r["r1"])) + [x for lo, cnt in r["bulk"][1] for x in range(lo, lo + cnt)]
+            assert rows == list(range(r["k"], n))
+            assert r["owner"] == r["p"] % world and r["next"] == (r["p"] + 1) % world
+            for rank, q in r["near"].items():
+                assert q > r["p"] and q % world == rank and all(j % world != rank for j in range(r["p"] + 1, q))
