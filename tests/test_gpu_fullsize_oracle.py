@@ -123,12 +123,15 @@ def test_config4_n8192_grown_factor_and_sample_at_vs_oracle(ctx):
 
 
 @pytest.mark.parametrize("name,n,d,kernel_name,with_eps,ncols", [
-    ("config2_matern52_eps", 16384, 16, "matern2", True, 4096),
-    ("config3_rbf", 32768, 16, "squared_exp", False, 2048),
+    ("config2_matern52_eps", 16384, 16, "matern2", True, 16384),
+    ("config3_rbf", 32768, 16, "squared_exp", False, 8192),
 ])
-def test_full_size_leading_columns_vs_oracle(ctx, name, n, d, kernel_name, with_eps, ncols):
-    """configs[2] / configs[3]: the leading column block of the full-size factor against the oracle (the columns a
-    left-looking factorisation finishes first; they carry every row of the matrix)."""
+def test_full_size_factor_vs_oracle(ctx, name, n, d, kernel_name, with_eps, ncols):
+    """configs[2]: the WHOLE N = 16384 factor against the oracle (32 panels of 512 columns, both XCD-reservation tiers);
+    configs[3]: the leading 8192 columns of the N = 32768 factor (eight look-ahead panels of 1024 columns, i.e. every column
+    compared has seen up to seven trailing updates; columns of a left-looking factorisation depend only on the columns in
+    front of them, so the oracle stops there -- the remaining 24576 columns would take it ~10 minutes).  The automatic
+    1024 -> 512 panel switch of the last 16384 rows is covered against the oracle by the configs[2]-sized tail test below."""
     X, y, _, hp, k = _problem(ctx, n, d, 3, 0, kernel_name)
     noise = hp["noise"]
     eps = 1e-2 * noise * noise if with_eps else None  # builder.rs:151-style epsilon (SURVEY section 8d cfg 3)
@@ -141,6 +144,28 @@ def test_full_size_leading_columns_vs_oracle(ctx, name, n, d, kernel_name, with_
     L = _leading_columns(chol, n, ncols)
     assert rel_err(L, np.tril(L_o)) < TOL
     chol.free()
+
+
+def test_large_n_schedule_on_n8192_vs_oracle(ctx):
+    """The schedule of a fit at N >= 24576 -- 1024-column panels while the trailing update dominates, 512-column panels with
+    XCDs set aside for the panel chain over the last rows -- forced onto a matrix the oracle factors in full (N = 8192:
+    nb = 1024, switch to 512 columns below 4096 remaining rows): the same factor as the default schedule's, to TOL of the
+    oracle's."""
+    n, d = 8192, 8
+    X, y, _, hp, k = _problem(ctx, n, d, 4, 0, "squared_exp")
+    with O.threads():
+        st, L_o, _ = O.make_cholesky_cov_matrix_cols(k, X, hp["noise"])
+    assert st == 0
+    L_o = np.tril(L_o)
+    ctx.set_option("nb", 1024)
+    ctx.set_option("nb_switch_rows", 4096)
+    try:
+        chol = ctx.cholesky_from_inputs(k, X, hp["noise"])
+        assert rel_err(chol.l(), L_o) < TOL
+        chol.free()
+    finally:
+        ctx.set_option("nb", 0)
+        ctx.set_option("nb_switch_rows", 16384)
 
 
 def _duplicated_rows_problem(n, d, ndup, cfg):
@@ -177,20 +202,32 @@ def test_config2_substitutions_fire_noise0_duplicated_rows(ctx):
         assert np.all(idx >= n - ndup), "a pivot outside the duplicated block was substituted"
         assert np.all(np.diff(idx) > 0)
         report[n] = {"hip": len(idx)}
+        assert 0.85 * ndup <= len(idx) <= ndup  # measured: 242 (N = 4096), 243 (N = 16384)
         if use_oracle:
             with O.threads():
                 st, L_o, idx_o = O.make_cholesky_cov_matrix_cols(k, X, 0.0, eps)
             assert st == 0 and np.all(idx_o >= n - ndup)
             sym = sorted(set(idx.tolist()) ^ set(idx_o.tolist()))
             report[n].update({"oracle": len(idx_o), "symmetric_difference": len(sym)})
-            # the band: both orders substitute a large part of the 256 exact-zero pivots and mostly the same ones
-            assert len(idx_o) > 0 and len(idx) > 0
-            assert len(sym) <= ndup
+            # The band, measured (profiles/r03/parity_band.json: HIP 242, oracle 198, symmetric difference 66 of the 256
+            # exact-zero pivots) and held with a margin: both orders substitute at least 70 % of the duplicated block's
+            # pivots, their counts differ by at most a quarter of the block, and at most 35 % of the block is decided
+            # differently.  (The pivots in question are exact-arithmetic zeros: what each order computes there is pure
+            # round-off of ~4000 accumulated products, so agreement beyond the band would be coincidence.)
+            assert 0.70 * ndup <= len(idx_o) <= ndup and 0.70 * ndup <= len(idx) <= ndup
+            assert abs(len(idx) - len(idx_o)) <= 0.25 * ndup
+            assert len(sym) <= 0.35 * ndup
             # columns in front of the duplicated block are untouched by any substitution: plain parity there
             L = chol.l()
             assert rel_err(L[:, :n - ndup], np.tril(L_o)[:, :n - ndup]) < TOL
         chol.free()
     print("configs[2](ii) substitution counts:", report)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_band.json"), "w") as f:
+        json.dump({"what": "configs[2](ii): noise = 0, 256 duplicated rows, cholesky_epsilon = 1e-2 noise0^2, Matern-5/2, d = 16: substituted "
+                           "pivots of the HIP path (blocked right-looking) and of the oracle (left-looking, the reference's order)",
+                   "counts": {str(k_): v for k_, v in report.items()}}, f, indent=1)
 
 
 @pytest.mark.parametrize("noise", [1e-2, 1e-3, 1e-4, 1e-5, 1e-6])
