@@ -109,6 +109,8 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
                 FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, below, kb, kb, B, ld, false, inv, IB, false, 1.0, 0.0, B, ld));
             }
         }
+        // the look-ahead pipeline asked to be told when the panel's columns up to here are final (see potrf_blocked)
+        if (ctx->cols_final_at == k + kb && ctx->ev_cols) FR_HIP(ctx, hipEventRecord(ctx->ev_cols, ctx->ls));
         return FR_OK;
     }
     const int64_t kb1 = ((kb / IB + 1) / 2) * IB;  // first half, a multiple of 128
@@ -467,6 +469,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         if (world > 1) comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
         ctx->ls = S0;
         ctx->reserve_now = 0;
+        ctx->cols_final_at = -1;
         (void)hipStreamSynchronize(S1);
         return code;
     };
@@ -483,16 +486,42 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         return imin(nb, remaining);
     };
     const int64_t kb0 = width(n);
+    // The look-ahead update of the NEXT panel's columns by the panel being factored sits between two panels on the critical
+    // path (measured at N = 8192: 110 us of the ~600 us per 512 columns).  Most of it does not have to: once all but the last 128
+    // columns of a panel are final (the leaf before the last says so through ev_cols), the main stream applies those columns'
+    // part of the update (K = kb - 128) while the panel stream still factors the last block; what remains between the panels
+    // is the K = 128 part.  Single GPU only (the sharded schedules have their own look-ahead).
+    bool la_split = false;  // the first part of the update by the panel just finished has been issued
+    auto la_hook = [&](int64_t kk, int64_t kbb) {
+        ctx->cols_final_at = -1;
+        if (world == 1 && ctx->ev_cols && kbb > IB && kbb % IB == 0 && n - (kk + kbb) > 0) ctx->cols_final_at = kk + kbb - IB;
+    };
+    auto la_first_part = [&](int64_t kk, int64_t kbb) -> int {  // on S0, behind whatever trailing update is queued there
+        la_split = false;
+        const int64_t after = n - (kk + kbb);
+        if (!(world == 1 && ctx->ev_cols && kbb > IB && kbb % IB == 0 && after > 0)) return FR_OK;
+        FR_HIP(ctx, hipStreamWaitEvent(S0, ctx->ev_cols, 0));
+        const double* Pn = A + (kk + kbb) + kk * ld;
+        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, after, width(after), kbb - IB, Pn, ld, false, Pn, ld, false, -1.0, 1.0,
+                    A + (kk + kbb) + (kk + kbb) * ld, ld));
+        la_split = true;
+        return FR_OK;
+    };
     {
         if (split) {
             st = split_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(0, nb, world));
         } else {
+            la_hook(0, kb0);
             if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T);
+            ctx->cols_final_at = -1;
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
         }
         if (st != FR_OK) return fail(st);
     }
     if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
+    ctx->ls = S0;
+    st = la_first_part(0, kb0);
+    if (st != FR_OK) return fail(st);
     for (int64_t k = 0, kb = kb0, kb_next = 0; k < n; k += kb, kb = kb_next) {
         const int64_t rest = n - (k + kb);
         ctx->ls = S0;
@@ -517,8 +546,12 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
         if (own_next) {
             // (profile class: panel -- the SYRK class times exactly the syrk_lower_f64_kernel launches)
-            st = gemm(ctx, FR_PROF_GEMM_PANEL, rest, kb2, kb, P, ld, false, P, ld, false, -1.0, 1.0,
-                      A + (k + kb) + (k + kb) * ld, ld);
+            if (la_split)  // the first kb - 128 columns' part ran under the panel's last block: the last 128 columns remain
+                st = gemm(ctx, FR_PROF_GEMM_PANEL, rest, kb2, IB, P + (kb - IB) * ld, ld, false, P + (kb - IB) * ld, ld, false, -1.0, 1.0,
+                          A + (k + kb) + (k + kb) * ld, ld);
+            else
+                st = gemm(ctx, FR_PROF_GEMM_PANEL, rest, kb2, kb, P, ld, false, P, ld, false, -1.0, 1.0,
+                          A + (k + kb) + (k + kb) * ld, ld);
             if (st != FR_OK) return fail(st);
         }
         if (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess)
@@ -527,7 +560,9 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         if (split) {
             st = split_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(k + kb, nb, world));
         } else {
+            la_hook(k + kb, kb2);
             if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T);
+            ctx->cols_final_at = -1;
             if (st == FR_OK && ctx->reserve_now) st = launch_release_xcds(ctx, ctx->panel_epoch);  // (on the panel stream)
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
         }
@@ -549,9 +584,12 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             st = launch_gemm(ctx, g);
             if (st != FR_OK) return fail(st);
         }
+        st = la_first_part(k + kb, kb2);  // (behind the trailing update on this stream; waits for the panel stream's ev_cols)
+        if (st != FR_OK) return fail(st);
     }
     ctx->ls = S0;
     ctx->reserve_now = 0;
+    ctx->cols_final_at = -1;
     return FR_OK;
 }
 

@@ -341,6 +341,7 @@ int fr_ctx_create(fr_ctx** out, int device)
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("FRIEDRICH_AMD_TEST_FORCE_SOLVE_TIMEOUT")) ctx->test_force_timeout = e[0] == '1';
     if (const char* e = getenv("FRIEDRICH_AMD_TEST_MAX_WORKGROUPS")) ctx->test_max_wgs = atoi(e);
+    if (const char* e = getenv("FRIEDRICH_AMD_SMALL_TILES")) ctx->small_tiles = atoi(e);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return FR_HIP_ERROR;
@@ -352,7 +353,7 @@ int fr_ctx_create(fr_ctx** out, int device)
     if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, hi) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_bulk, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_diag, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_cols, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_la, hipEventDisableTiming) != hipSuccess) {
         fr_ctx_destroy(ctx);
@@ -394,7 +395,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
         (void)hipStreamDestroy(ctx->stream3);
     }
     if (ctx->ev_bulk) (void)hipEventDestroy(ctx->ev_bulk);
-    if (ctx->ev_diag) (void)hipEventDestroy(ctx->ev_diag);
+    if (ctx->ev_cols) (void)hipEventDestroy(ctx->ev_cols);
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamDestroy(ctx->stream2);

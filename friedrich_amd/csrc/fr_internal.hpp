@@ -48,7 +48,8 @@ struct fr_ctx {
     hipStream_t ls = nullptr;       // stream the kernel launchers enqueue on (== stream except inside look-ahead)
     hipStream_t stream2 = nullptr;  // high-priority panel stream of the look-ahead Cholesky
     hipStream_t stream3 = nullptr;  // sharded factorisation: the bulk rows of a panel (solves + all-gather) off the diagonal chain
-    hipEvent_t ev_panel = nullptr, ev_la = nullptr, ev_diag = nullptr, ev_bulk = nullptr;
+    hipEvent_t ev_panel = nullptr, ev_la = nullptr, ev_cols = nullptr, ev_bulk = nullptr;
+    int64_t cols_final_at = -1;     // factor_panel records ev_cols when the columns up to this one are final (look-ahead pipeline)
     std::string err;
     // grow-only workspace pool (stream-ordered reuse inside one context)
     std::vector<fr::DevBuf> pool;
@@ -76,6 +77,7 @@ struct fr_ctx {
     // product, and the handle keeps refining (factor, add_rows, solves); 0 never; 1 always
     int64_t refine = -1;
     double refine_threshold = 30.0;
+    int64_t small_tiles = 64;  // products of at most this many 128 x 128 tiles use 32-row tiles (gemm_f64.hip; FRIEDRICH_AMD_SMALL_TILES overrides for A/B runs)
     // ---- state ----
     bool potf2_lds_set = false;  // dynamic-LDS attributes applied on this device (per context = per device)
     bool trsv_lds_set = false;

@@ -25,7 +25,7 @@
 
 namespace fr {
 
-template <bool A_KMAJ, bool B_KMAJ>
+template <bool A_KMAJ, bool B_KMAJ, int BMT = BM>
 __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
 {
 
@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
             tn = tlin / g.tiles_m;
         }
     }
-    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const int64_t m0 = tm * BMT, n0 = tn * BN;
     if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) return;
     GemmArgs gt = g;  // (ONE call site of the tile function: a second inlined copy would double the kernel)
     if (g.tri) {
@@ -88,13 +88,16 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
         int64_t kbeg = 0, kend = g.K;
         if ((g.tri & 1) && m0 > kbeg) kbeg = m0;
         if ((g.tri & 2) && n0 > kbeg) kbeg = n0;
-        if ((g.tri & 4) && m0 + BM < kend) kend = m0 + BM;
+        if ((g.tri & 4) && m0 + BMT < kend) kend = m0 + BMT;
         if (kbeg > kend) kbeg = kend;
         gt.A += kbeg * (A_KMAJ ? 1 : g.lda);
         gt.B += kbeg * (B_KMAJ ? 1 : g.ldb);
         gt.K = kend - kbeg;
     }
-    gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
+    if constexpr (BMT == BM)
+        gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
+    else
+        gemm_f64_tile_m32<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
 }
 
 // Two kernel symbols over the same body: the lower-mode launch is the trailing SYRK update of the factorisation (the
@@ -110,6 +113,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(const GemmArgs g0)
     g.Cin += bz * g.batch_c;
     g.D += bz * g.batch_d;
     gemm_f64_body<A_KMAJ, B_KMAJ>(g, lds);
+}
+
+// 32-row tiles: products with too few 128 x 128 tiles to fill the chip (gemm_tile.hpp: gemm_f64_tile_m32)
+template <bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(256, 2) void gemm_f64_m32_kernel(const GemmArgs g0)
+{
+    __shared__ double lds[2 * (TILE_A_S + TILE_ELEMS)];
+    GemmArgs g = g0;
+    const int64_t bz = blockIdx.y;
+    g.A += bz * g.batch_a;
+    g.B += bz * g.batch_b;
+    g.Cin += bz * g.batch_c;
+    g.D += bz * g.batch_d;
+    gemm_f64_body<A_KMAJ, B_KMAJ, BMS>(g, lds);
 }
 
 __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g)
@@ -238,6 +255,18 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.own_col0 = d.own_col0;
     g.tiles_m = (d.M + BM - 1) / BM;
     g.tiles_n = (d.N + BN - 1) / BN;
+    // Few tiles: 32-row tiles instead (four times the workgroups, a quarter of the matrix-core time each).  Measured on the
+    // panel chain, whose products these are (in-process A/B, fits at N = 4096 / 8192 / 16384: 3.92 / 9.11 / 33.7 -> 3.41 / 8.52 /
+    // 32.8 ms with the threshold at 64 tiles; at 160 or 320 tiles N = 16384 loses the gain again; predict_variance of 1024
+    // points at N = 4096 / 8192: 0.86 / 2.15 -> 0.77 / 1.95 ms); the lower-mode and triangular-operand launches keep the large tile.
+    // (a launch of the panel stream under the XCD reservation only has 32 CUs per reserved XCD: there four times the
+    // workgroups pay while the large tiles would not fill those CUs either -- with 1 XCD and small tiles for up to 64 large
+    // ones the fit at N = 8192 went from 9.1 to 10.2 ms)
+    int64_t small_max = ctx->small_tiles;
+    if (ctx->reserve_now && d.batch <= 1 && ctx->ls == ctx->stream2 && small_max > 32 * ctx->reserve_now) small_max = 32 * ctx->reserve_now;
+    const bool small = small_max > 0 && !d.lower && !d.tri && d.M > BMS && d.D != d.B /* in place over op(B) needs ONE tile row */ &&
+                       g.tiles_m * g.tiles_n * (d.batch > 1 ? d.batch : 1) <= small_max;
+    if (small) g.tiles_m = (d.M + BMS - 1) / BMS;
     double flops;
     int64_t ntiles;
     g.sw_log2 = 3;
@@ -260,7 +289,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.per_xcd = (g.nsuper + 7) / 8;
     // measured inside the factorisation (round 1, in-process A/B): super-tiles pay for large shallow full products only; the
     // lower-mode SYRK next to the panel stream is ~4 % faster in plain order
-    bool use_super = !d.lower && g.K <= 2048 && g.nsuper >= 128;
+    bool use_super = !d.lower && !small && g.K <= 2048 && g.nsuper >= 128;
     g.place = 0;
     g.ntiles = ntiles;
     g.xcc_word = nullptr;
@@ -321,7 +350,15 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.batch_d = d.batch_d;
     if (d.batch > 1 && d.lower) return set_err(ctx, FR_INVALID_ARGUMENT, "batched GEMM is full-mode only");
     dim3 grid((unsigned)ntiles, (unsigned)(d.batch > 1 ? d.batch : 1)), block(256);
-    if (d.lower && !d.a_kmajor && !d.b_kmajor)
+    if (small && !d.a_kmajor && !d.b_kmajor)
+        hipLaunchKernelGGL((gemm_f64_m32_kernel<false, false>), grid, block, 0, ctx->ls, g);
+    else if (small && !d.a_kmajor && d.b_kmajor)
+        hipLaunchKernelGGL((gemm_f64_m32_kernel<false, true>), grid, block, 0, ctx->ls, g);
+    else if (small && d.a_kmajor && d.b_kmajor)
+        hipLaunchKernelGGL((gemm_f64_m32_kernel<true, true>), grid, block, 0, ctx->ls, g);
+    else if (small)
+        hipLaunchKernelGGL((gemm_f64_m32_kernel<true, false>), grid, block, 0, ctx->ls, g);
+    else if (d.lower && !d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL(syrk_lower_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, ctx->ls, g);

@@ -362,5 +362,139 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmArgs& g, double* lds, co
     }
 }
 
+// ---- 32 x 128 result tile (the launches of the panel chain) -----------------------------------------------------------------
+// A 128 x 128 tile is 13.6 us of matrix-core time per 128 of contraction depth on ONE CU, and the products between two
+// diagonal-block kernels of a factorisation have a few dozen such tiles (rows below the block x 128 or 256 columns): three
+// quarters of the chip idle while the chain waits for the one busy quarter.  The same product cut into 32-row tiles has four
+// times the workgroups, each a quarter of the matrix-core work, and still ONE tile column for N <= 128 -- which the in-place
+// "B <- B W^T" of the panel solves needs.  Four waves side by side along n, each 32 x 32 (2 x 2 accumulators); op(B) tiles in
+// the layouts of the large kernel, the 32-wide op(A) tile as [k][48] (m-major: 2 * 48 = 32 mod 64 banks, conflict-free
+// fragment reads) or [m][18] (k-major).  No pinned schedule: these launches are bound by latency, not by issue slots.
+constexpr int BMS = 32;
+constexpr int S_MMAJ_S = 48;
+constexpr int TILE_A_S = 16 * S_MMAJ_S;  // 768 >= 32 * 18
+
+template <bool KMAJ>
+__device__ __forceinline__ int lds_idx_s(int x, int k)
+{
+    return KMAJ ? x * S_KMAJ + k : k * S_MMAJ_S + x;
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void load_tile_s(const double* __restrict__ P, int64_t ld, int64_t x0, int64_t X, int64_t k0, int64_t K,
+                                            int t, double (&reg)[2])
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int x = KMAJ ? (t >> 4) + 16 * i : (t & 31);
+        const int k = KMAJ ? (t & 15) : (t >> 5) + 8 * i;
+        const bool ok = (x0 + x) < X && (k0 + k) < K;
+        const double* p = KMAJ ? P + (k0 + k) + (x0 + x) * ld : P + (x0 + x) + (k0 + k) * ld;
+        reg[i] = ok ? *p : 0.0;
+    }
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void store_tile_s(double* __restrict__ S, int t, const double (&reg)[2])
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int x = KMAJ ? (t >> 4) + 16 * i : (t & 31);
+        const int k = KMAJ ? (t & 15) : (t >> 5) + 8 * i;
+        S[lds_idx_s<KMAJ>(x, k)] = reg[i];
+    }
+}
+
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds, const int64_t m0, const int64_t n0)
+{
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wn = t >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    d4_t acc[2][2];  // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    const int64_t nk = (g.K + BK - 1) / BK;
+    const int64_t nk_full = g.K / BK;
+    const bool b_fast = (n0 + BN) <= g.N;
+    const double* pb = tile_thread_base<B_KMAJ>(g.B, g.ldb, n0, t);
+    const int64_t step_b = B_KMAJ ? BK : BK * g.ldb;
+    constexpr int STAGE = TILE_A_S + TILE_ELEMS;
+    double ra[2], rb[8];
+    if (nk > 0) {
+        load_tile_s<A_KMAJ>(g.A, g.lda, m0, g.M, 0, g.K, t, ra);
+        if (b_fast && nk_full > 0)
+            load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+        else
+            load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, 0, g.K, t, rb);
+        store_tile_s<A_KMAJ>(lds, t, ra);
+        store_tile<B_KMAJ>(lds + TILE_A_S, t, rb);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) {
+            pb += step_b;
+            load_tile_s<A_KMAJ>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, t, ra);
+            if (b_fast && (kt + 1) < nk_full)
+                load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+            else
+                load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, t, rb);
+        }
+        const double* As = lds + cur * STAGE;
+        const double* Bs = As + TILE_A_S;
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            const int kq = ks * 4 + lq;
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = As[lds_idx_s<A_KMAJ>(i * 16 + l15, kq)];
+                bf[i] = Bs[lds_idx<B_KMAJ>(wn * 32 + i * 16 + l15, kq)];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+        if (more) {
+            double* An = lds + (cur ^ 1) * STAGE;
+            store_tile_s<A_KMAJ>(An, t, ra);
+            store_tile<B_KMAJ>(An + TILE_A_S, t, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // epilogue: register r of tile (nt, mt) holds D[m0 + 16 mt + (lane & 15)][n0 + 32 wn + 16 nt + (lane >> 4) + 4 r];
+    // all 16 values of C are loaded before the first store (D may alias Cin: one round trip, not sixteen)
+    const bool use_c = g.beta != 0.0;
+    double cv[16];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int64_t n = n0 + wn * 32 + nt * 16 + lq + 4 * r, m = m0 + mt * 16 + l15;
+                cv[(nt * 4 + r) * 2 + mt] = (use_c && n < g.N && m < g.M) ? g.Cin[m + n * g.ldcin] : 0.0;
+            }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int64_t n = n0 + wn * 32 + nt * 16 + lq + 4 * r, m = m0 + mt * 16 + l15;
+                double v = g.alpha * acc[nt][mt][r];
+                if (use_c) v += g.beta * cv[(nt * 4 + r) * 2 + mt];
+                if (n < g.N && m < g.M) g.D[m + n * g.ldd] = v;
+            }
+}
+
 
 }  // namespace fr
