@@ -268,6 +268,9 @@ int launch_gram_sym(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t 
 // out[i] = k(x_i, x_i) (+ add)
 int launch_gram_diag(fr_ctx* ctx, const fr_kprog& prog, const double* X, int64_t n, int64_t ldx, int64_t d,
                      double add, double* out);
+// out[j] = k(xq_j, xq_j) - U[:, j] . V[:, j]  (epilogue of predict_variance / predict_mean_variance, one launch)
+int launch_variance_epilogue(fr_ctx* ctx, const fr_kprog& prog, const double* Xq, int64_t m, int64_t ldq, int64_t d, const double* U,
+                             int64_t ldu, const double* V, int64_t ldv, int64_t n, double* out);
 int launch_pairwise_distance_sum(fr_ctx* ctx, const double* X, int64_t n, int64_t ldx, int64_t d, double* out_dev);
 int kprog_check(fr_ctx* ctx, const fr_kprog* p);
 

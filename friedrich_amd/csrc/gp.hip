@@ -187,14 +187,9 @@ static int fr_predict_variance_impl(fr_chol* c, const fr_kprog* kernel, const do
     FR_TRY(zero_diag_status(c, "predict_covariance"));  // mod.rs:263
     Staged var(ctx);
     FR_TRY(stage_vec_out(ctx, var, out_var, m));
-    WsGuard w(ctx);
-    double* pred = w.get(sizeof(double) * (size_t)(m > 0 ? m : 1));
-    if (!pred) return FR_OUT_OF_MEMORY;
-    // kl = L^-1 K*  (mod.rs:260-263); var_i = k(x_i, x_i) - ||kl[:, i]||^2  (:266-270)
+    // kl = L^-1 K*  (mod.rs:260-263); var_i = k(x_i, x_i) - ||kl[:, i]||^2  (:266-270): the solve, then ONE epilogue launch
     FR_TRY(trsm_lower_fwd(ctx, c, c->n, q.K, m, q.ldk, FR_PROF_GEMM_SOLVE));
-    FR_TRY(launch_col_norm2(ctx, q.K, c->n, m, q.ldk, pred));
-    FR_TRY(launch_gram_diag(ctx, *kernel, q.xq.dev, m, q.xq.ld, c->d, 0.0, var.dev));
-    FR_TRY(launch_axpby_vec(ctx, m, -1.0, pred, 1.0, var.dev));
+    FR_TRY(launch_variance_epilogue(ctx, *kernel, q.xq.dev, m, q.xq.ld, c->d, q.K, q.ldk, q.K, q.ldk, c->n, var.dev));
     return var.commit();
 }
 
@@ -210,10 +205,9 @@ static int fr_predict_mean_variance_impl(fr_chol* c, const fr_kprog* kernel, con
     FR_TRY(stage_vec_in(ctx, ys, y, c->n));
     FR_TRY(stage_vec_out(ctx, mean, out_mean, m));
     FR_TRY(stage_vec_out(ctx, var, out_var, m));
-    WsGuard w(ctx), w2(ctx);
+    WsGuard w(ctx);
     double* W = w.get(sizeof(double) * (size_t)q.ldk * (size_t)(m > 0 ? m : 1));
-    double* pred = w2.get(sizeof(double) * (size_t)(m > 0 ? m : 1));
-    if (!W || !pred) return FR_OUT_OF_MEMORY;
+    if (!W) return FR_OUT_OF_MEMORY;
     // weights = covmat_cholesky.solve(&cov_train_inputs)  (clone + solve_mut, mod.rs:298)
     FR_TRY(launch_copy(ctx, q.K, q.ldk, W, q.ldk, c->n, m));
     FR_TRY(trsm_lower_fwd(ctx, c, c->n, W, m, q.ldk, FR_PROF_GEMM_SOLVE));
@@ -221,9 +215,7 @@ static int fr_predict_mean_variance_impl(fr_chol* c, const fr_kprog* kernel, con
     FR_TRY(init_with_prior(ctx, mean.dev, prior_q, m));
     FR_TRY(launch_gemv_t(ctx, W, c->n, m, q.ldk, ys.dev, 1.0, 1.0, mean.dev));  // :306
     // var_i = k(x_i,x_i) - K*[:,i] . W[:,i]   (:313-319)
-    FR_TRY(launch_col_dot(ctx, q.K, q.ldk, W, q.ldk, c->n, m, pred));
-    FR_TRY(launch_gram_diag(ctx, *kernel, q.xq.dev, m, q.xq.ld, c->d, 0.0, var.dev));
-    FR_TRY(launch_axpby_vec(ctx, m, -1.0, pred, 1.0, var.dev));
+    FR_TRY(launch_variance_epilogue(ctx, *kernel, q.xq.dev, m, q.xq.ld, c->d, q.K, q.ldk, W, q.ldk, c->n, var.dev));
     FR_TRY(mean.commit());
     return var.commit();
 }

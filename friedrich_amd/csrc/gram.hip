@@ -48,9 +48,11 @@ __device__ __forceinline__ void sym_tile(int64_t t, int64_t& bi, int64_t& tj)
     tj = t - b * (b + 1);
 }
 
-// (three waves per SIMD for the one-accumulator modes: 168 VGPRs and a few spilled values, measured 2.93 -> 2.66 ms at
-// N = 32768 -- the kernel waits on LDS broadcasts and dependent f64 chains, more waves hide more of it; four waves spill: 4.2 ms)
-template <int MODE>
+// (three waves per SIMD for the one-accumulator modes: measured 2.93 -> 2.66 ms at N = 32768 -- the kernel waits on LDS
+// broadcasts and dependent f64 chains, more waves hide more of it; four waves spill: 4.2 ms)
+// LEAF >= 0: the program is that single built-in kernel -- the epilogue is then straight-line code (no program dispatch, no
+// rotation of the accumulators, nothing in scratch); LEAF = -1: any program, evaluated by the stack machine.
+template <int MODE, int LEAF>
 __global__ __launch_bounds__(256, (MODE == (NEED_S | NEED_U)) ? 2 : 3) void gram_kernel(const GramArgs a)
 {
 #pragma clang fp contract(off)
@@ -114,10 +116,6 @@ __global__ __launch_bounds__(256, (MODE == (NEED_S | NEED_U)) ? 2 : 3) void gram
         __syncthreads();
     }
 
-    // Epilogue: the kernel program is evaluated per pair.  Its body (a switch over nine leaf kinds, exp / pow inside) is too
-    // large for the compiler to unroll 32 times, and a rolled loop that indexes s[h][b] dynamically sends the accumulators
-    // through scratch memory (measured: 4x the algorithmic bytes written, 2x fetched, per launch).  So the loop over the 16
-    // columns stays rolled but always consumes element 0 and then rotates the register arrays (static indices only).
     double av[2] = {0.0, 0.0};
     if (a.dot_vec) {
 #pragma unroll
@@ -126,44 +124,55 @@ __global__ __launch_bounds__(256, (MODE == (NEED_S | NEED_U)) ? 2 : 3) void gram
             av[h] = gi < a.n1 ? a.dot_vec[gi] : 0.0;
         }
     }
-    // Two columns (four pairs) per turn, evaluated unconditionally and only STORED under the bounds test: the program's chain
-    // of dependent f64 operations (exp / pow) then overlaps four ways instead of sitting alone inside a divergent branch
-    // (padding rows / columns hold zeros: finite inputs, results discarded).
-#pragma unroll 1
-    for (int b = 0; b < 16; b += 2) {
-        double k[2][2];
+    // one output column (two pairs) of the tile: the values are computed unconditionally and only STORED under the bounds
+    // test (padding rows / columns hold zeros: finite inputs, results discarded)
+    auto emit = [&](int b, double k0, double k1) {
+        const int64_t gj = j0 + g * 16 + b;
+        double dotv = 0.0;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) k[e][h] = kprog_eval(a.prog, s[h][e], u[h][e]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int64_t gj = j0 + g * 16 + b + e;
-            double dotv = 0.0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int64_t gi = i0 + r + 64 * h;
-                if (gi < a.n1 && gj < a.n2) {
-                    double kv = k[e][h];
-                    if (a.sym && gi == gj) kv = kv + a.noise2;  // algebra/mod.rs:78
-                    if (a.dot_vec)
-                        dotv = dotv + kv * av[h];
-                    else
-                        a.out[gi + gj * a.ldo] = kv;
-                }
-            }
-            if (a.dot_vec) {  // (uniform) the wave's 128 rows of column gj: fixed-order tree over the 64 lanes
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) dotv = dotv + __shfl_xor(dotv, off, 64);
-                if (r == 0 && gj < a.n2) a.dot_part[ti * a.n2 + gj] = dotv;
+        for (int h = 0; h < 2; ++h) {
+            const int64_t gi = i0 + r + 64 * h;
+            if (gi < a.n1 && gj < a.n2) {
+                double kv = h ? k1 : k0;
+                if (a.sym && gi == gj) kv = kv + a.noise2;  // algebra/mod.rs:78
+                if (a.dot_vec)
+                    dotv = dotv + kv * av[h];
+                else
+                    a.out[gi + gj * a.ldo] = kv;
             }
         }
+        if (a.dot_vec) {  // (uniform) the wave's 128 rows of column gj: fixed-order tree over the 64 lanes
 #pragma unroll
-        for (int i = 0; i < 14; ++i) {
-            s[0][i] = s[0][i + 2];
-            s[1][i] = s[1][i + 2];
-            u[0][i] = u[0][i + 2];
-            u[1][i] = u[1][i + 2];
+            for (int off = 32; off > 0; off >>= 1) dotv = dotv + __shfl_xor(dotv, off, 64);
+            if (r == 0 && gj < a.n2) a.dot_part[ti * a.n2 + gj] = dotv;
+        }
+    };
+    if constexpr (LEAF >= 0) {
+        // single built-in kernel: 32 independent straight-line evaluations, static register indices
+#pragma unroll
+        for (int b = 0; b < 16; ++b)
+            emit(b, kprog_eval_k<LEAF>(a.prog, s[0][b], u[0][b]), kprog_eval_k<LEAF>(a.prog, s[1][b], u[1][b]));
+    } else {
+        // Any program: its body (the stack machine over nine leaf kinds) is too large to unroll 32 times, and a rolled loop that
+        // indexes s[h][b] dynamically sends the accumulators through scratch memory (measured: 4x the algorithmic bytes written).
+        // So the loop stays rolled, always consumes elements 0 and 1, and then rotates the register arrays (static indices only);
+        // two columns (four pairs) per turn so that the chains of dependent f64 operations overlap four ways.
+#pragma unroll 1
+        for (int b = 0; b < 16; b += 2) {
+            double k[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) k[e][h] = kprog_eval(a.prog, s[h][e], u[h][e]);
+            emit(b, k[0][0], k[0][1]);
+            emit(b + 1, k[1][0], k[1][1]);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) {
+                s[0][i] = s[0][i + 2];
+                s[1][i] = s[1][i + 2];
+                u[0][i] = u[0][i + 2];
+                u[1][i] = u[1][i + 2];
+            }
         }
     }
 }
@@ -182,6 +191,49 @@ __global__ __launch_bounds__(256) void gram_diag_kernel(const fr_kprog prog, con
         u = u + x * x;
     }
     out[i] = kprog_eval(prog, s, u) + add;
+}
+
+// The epilogue of predict_variance / predict_mean_variance in ONE launch (mod.rs:266-270, 313-319):
+//   out[j] = k(x*_j, x*_j) - sum_i U[i, j] V[i, j]        (U == V = L^-1 K*: the column's squared norm)
+// one workgroup per query point: the column dot product in a fixed order, the prior variance by the kernel program.
+// (Round 2 ran this as three launches -- column norms, gram_diag, axpby -- and a temporary.)
+__global__ __launch_bounds__(256) void variance_epilogue_kernel(const fr_kprog prog, const double* __restrict__ Xq, int64_t ldq, int64_t d,
+                                                                const double* __restrict__ U, int64_t ldu, const double* __restrict__ V,
+                                                                int64_t ldv, int64_t n, double* __restrict__ out)
+{
+#pragma clang fp contract(off)
+    __shared__ double red[4];
+    const int64_t j = blockIdx.x;
+    const double* u = U + j * ldu;
+    const double* v = V + j * ldv;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += u[i] * v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 4; ++w) tot += red[w];
+        double s2 = 0.0, uu = 0.0;
+        for (int64_t c = 0; c < d; ++c) {
+            const double x = Xq[j + c * ldq];
+            const double diff = x - x;
+            s2 = s2 + diff * diff;
+            uu = uu + x * x;
+        }
+        out[j] = kprog_eval(prog, s2, uu) - tot;
+    }
+}
+
+int launch_variance_epilogue(fr_ctx* ctx, const fr_kprog& prog, const double* Xq, int64_t m, int64_t ldq, int64_t d, const double* U,
+                             int64_t ldu, const double* V, int64_t ldv, int64_t n, double* out)
+{
+    if (m <= 0) return FR_OK;
+    ProfScope ps(ctx, FR_PROF_REDUCE, 2.0 * (double)n * m, 8.0 * (double)n * m * (U == V ? 1.0 : 2.0));
+    hipLaunchKernelGGL(variance_epilogue_kernel, dim3((unsigned)m), dim3(256), 0, ctx->ls, prog, Xq, ldq, d, U, ldu, V, ldv, n, out);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
 }
 
 // K3: sum over strictly-lower pairs of ||x_i - x_j||; per-block partials, then one reducing block
@@ -293,12 +345,28 @@ static int launch_gram(fr_ctx* ctx, const GramArgs& a, int64_t nblocks, int need
     if (nblocks > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "Gram grid too large");
     ProfScope ps(ctx, FR_PROF_GRAM, pairs * (3.0 * (double)a.d + 20.0), pairs * 8.0);
     dim3 grid((unsigned)nblocks), block(256);
-    if (needs == NEED_S)
-        hipLaunchKernelGGL(gram_kernel<NEED_S>, grid, block, 0, ctx->ls, a);
-    else if (needs == NEED_U)
-        hipLaunchKernelGGL(gram_kernel<NEED_U>, grid, block, 0, ctx->ls, a);
-    else
-        hipLaunchKernelGGL(gram_kernel<NEED_S | NEED_U>, grid, block, 0, ctx->ls, a);
+    const int leaf = a.prog.nops == 1 ? a.prog.ops[0].kind : -1;
+#define FR_GRAM_LEAF(KIND, MODE_)                                                            \
+    case KIND: hipLaunchKernelGGL((gram_kernel<MODE_, KIND>), grid, block, 0, ctx->ls, a); break;
+    switch (leaf) {
+        FR_GRAM_LEAF(FR_K_LINEAR, NEED_U)
+        FR_GRAM_LEAF(FR_K_POLYNOMIAL, NEED_U)
+        FR_GRAM_LEAF(FR_K_SQUAREDEXP, NEED_S)
+        FR_GRAM_LEAF(FR_K_EXPONENTIAL, NEED_S)
+        FR_GRAM_LEAF(FR_K_MATERN1, NEED_S)
+        FR_GRAM_LEAF(FR_K_MATERN2, NEED_S)
+        FR_GRAM_LEAF(FR_K_HYPERTAN, NEED_U)
+        FR_GRAM_LEAF(FR_K_MULTIQUADRIC, NEED_S)
+        FR_GRAM_LEAF(FR_K_RATIONALQUADRATIC, NEED_S)
+    default:
+        if (needs == NEED_S)
+            hipLaunchKernelGGL((gram_kernel<NEED_S, -1>), grid, block, 0, ctx->ls, a);
+        else if (needs == NEED_U)
+            hipLaunchKernelGGL((gram_kernel<NEED_U, -1>), grid, block, 0, ctx->ls, a);
+        else
+            hipLaunchKernelGGL((gram_kernel<NEED_S | NEED_U, -1>), grid, block, 0, ctx->ls, a);
+    }
+#undef FR_GRAM_LEAF
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

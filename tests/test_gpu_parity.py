@@ -42,6 +42,26 @@ def test_gram_matches_oracle(ctx, kernel, n1, n2, d):
     assert rel_err(got, want) < TOL_GRAM
 
 
+def test_gram_exp_and_division_over_the_whole_argument_range(ctx):
+    """The in-tree exp (Cody-Waite reduction + degree-13 polynomial + ldexp) and the three-instruction division by a
+    launch-uniform divisor (kprog_device.hpp) against the oracle's libm over the whole range of arguments: exp(-t) for
+    t = 0 ... 760 (gradual underflow and the flush to zero included) through the squared-exponential, exponential and
+    Matern kernels on 1-D inputs.  An error of e ulps in the argument shows as e |t| 2^-53 relative in the value, so the
+    bound is (4 + 2 t) ulps: both divisions are within 1 ulp of the correctly rounded quotient, both exps within 1 ulp."""
+    t = np.concatenate([np.linspace(0.0, 760.0, 3001), np.array([1e-300, 1e-17, 0.5, 708.3, 709.78, 744.4, 745.13, 745.2, 746.0, 800.0, 1e4])])
+    for spec, to_dist in ((("squared_exp", 0.7, 1.3), lambda tt: np.sqrt(2.0 * 0.7 * 0.7 * tt)),
+                          (("exponential", 0.9, 0.7), lambda tt: 2.0 * 0.9 * 0.9 * tt),
+                          (("matern1", 1.1, 0.9), lambda tt: tt * 1.1 / np.sqrt(3.0)),
+                          (("matern2", 0.7, 1.2), lambda tt: tt * 0.7 / np.sqrt(5.0))):
+        Y = np.asfortranarray(to_dist(t).reshape(-1, 1))
+        X0 = np.zeros((1, 1), order="F")
+        got = ctx.gram(spec, X0, Y)[0]
+        want = O.make_covariance_matrix(spec, X0, Y)[0]
+        ulp = np.spacing(np.maximum(np.abs(want), 5e-324))
+        assert np.all(np.abs(got - want) <= (4.0 + 2.0 * t) * ulp), (spec, float(np.max(np.abs(got - want) / ulp)))
+        assert np.all((want == 0.0) <= (got <= 5e-324 * 8))  # what the reference flushes to zero stays (sub)denormal-small
+
+
 def test_gram_strided_inputs(ctx):
     # EMatrix::as_matrix(): leading dimension = capacity != nrows (extendable_matrix.rs:52-55)
     big = rand_inputs(300, 4, 3)
