@@ -24,11 +24,13 @@ __device__ __forceinline__ double signum_d(double x) { return (x != x) ? x : cop
 __device__ __forceinline__ double pow3(double x) { return x * (x * x); }  // powi(3): x * x^2 (compiler-rt __powidf2)
 
 // gradient of one leaf; returns the number of values written (kernel.rs `gradient` bodies)
-__device__ inline int leaf_grad(const fr_kernel_op& op, double s, double u, double* g)
+template <int KIND>
+__device__ __forceinline__ int leaf_grad_k(const fr_kernel_op& op, double s, double u, double* g)
 {
 #pragma clang fp contract(off)
     const double p0 = op.params[0], p1 = op.params[1], p2 = op.params[2];
-    switch (op.kind) {
+    const int kind = KIND >= 0 ? KIND : op.kind;
+    switch (kind) {
     case FR_K_LINEAR:  // :384-391
         g[0] = 1.0;
         return 1;
@@ -41,31 +43,32 @@ __device__ inline int leaf_grad(const fr_kernel_op& op, double s, double u, doub
         return 3;
     }
     case FR_K_SQUAREDEXP: {  // :563-576
-        const double e = exp(-s / (2.0 * p0 * p0));
-        g[0] = (s * fabs(p1) * e) / pow3(p0);
+        const double e = exp_fast(-div_uniform(s, 2.0 * p0 * p0));
+        g[0] = div_uniform(s * fabs(p1) * e, pow3(p0));
         g[1] = signum_d(p1) * e;
         return 2;
     }
     case FR_K_EXPONENTIAL: {  // :668-681
         const double r = sqrt(s);
-        const double e = exp(-r / (2.0 * p0 * p0));
-        g[0] = (r * fabs(p1) * e) / pow3(p0);
+        const double e = exp_fast(-div_uniform(r, 2.0 * p0 * p0));
+        g[0] = div_uniform(r * fabs(p1) * e, pow3(p0));
         g[1] = signum_d(p1) * e;
         return 2;
     }
     case FR_K_MATERN1: {  // :774-788
         const double l = fabs(p0), r = sqrt(s);
-        const double x = sqrt(3.0) * r / l;
-        g[0] = (3.0 * fabs(p1) * (r * r) * exp(-x)) / pow3(p0);
-        g[1] = signum_d(p1) * (1.0 + x) * exp(-x);
+        const double x = div_uniform(sqrt(3.0) * r, l);
+        const double e = exp_fast(-x);
+        g[0] = div_uniform(3.0 * fabs(p1) * (r * r) * e, pow3(p0));
+        g[1] = signum_d(p1) * (1.0 + x) * e;
         return 2;
     }
     case FR_K_MATERN2: {  // :881-900 (x uses the signed ls; grad_ls as written in the reference)
         const double l = fabs(p0), r = sqrt(s);
-        const double x = sqrt(5.0) * r / p0;
-        g[0] = signum_d(p0) * fabs(p1) * ((2.0 * l / 3.0 + 1.0) + r * sqrt(5.0) * (((l * l) / 3.0 + l + 1.0) / (l * l))) *
-               exp(-x);
-        g[1] = signum_d(p1) * (1.0 + x + (5.0 * r * r) / (3.0 * l * l)) * exp(-x);
+        const double x = div_uniform(sqrt(5.0) * r, p0);
+        const double e = exp_fast(-x);
+        g[0] = signum_d(p0) * fabs(p1) * ((2.0 * l / 3.0 + 1.0) + r * sqrt(5.0) * (((l * l) / 3.0 + l + 1.0) / (l * l))) * e;
+        g[1] = signum_d(p1) * (1.0 + x + div_uniform(5.0 * r * r, 3.0 * l * l)) * e;
         return 2;
     }
     case FR_K_HYPERTAN: {  // :979-989
@@ -89,6 +92,11 @@ __device__ inline int leaf_grad(const fr_kernel_op& op, double s, double u, doub
     default: return 0;
     }
 }
+
+__device__ inline int leaf_grad(const fr_kernel_op& op, double s, double u, double* g) { return leaf_grad_k<-1>(op, s, u, g); }
+
+// number of gradient values of a leaf kind (compile-time twin of leaf_nvalues)
+constexpr int leaf_ng(int kind) { return kind == FR_K_POLYNOMIAL ? 3 : ((kind == FR_K_LINEAR || kind == FR_K_MULTIQUADRIC) ? 1 : 2); }
 
 // gradient of a whole program: leaves write in program order (= k1-then-k2 concatenation, kernel.rs:168-171);
 // Prod applies the product rule g1*k2, g2*k1 (:252-262)
@@ -144,7 +152,8 @@ __device__ __forceinline__ void grad_sym_tile(int64_t t, int64_t& bi, int64_t& t
 
 // MODE: which pair statistics the kernel program needs (kprog_needs): squared distance (NEED_S), dot product (NEED_U) or both
 // -- as in K1, a kernel without the other accumulator saves its VALU work and the spills of 64 more accumulator registers.
-template <int MODE>
+// LEAF >= 0: the program is that single built-in kernel: straight-line epilogue, static accumulator count (as in gram.hip).
+template <int MODE, int LEAF>
 __global__ __launch_bounds__(256, 2) void grad_reduce_kernel(const GradArgs a)
 {
 #pragma clang fp contract(off)
@@ -194,45 +203,69 @@ __global__ __launch_bounds__(256, 2) void grad_reduce_kernel(const GradArgs a)
         }
         __syncthreads();
     }
-    double acc[MAXG];
+    constexpr int NG = LEAF >= 0 ? leaf_ng(LEAF) : MAXG;
+    double acc[NG];
 #pragma unroll
-    for (int q = 0; q < MAXG; ++q) acc[q] = 0.0;
-    // The gradient program is too large to be unrolled 32 times; a rolled loop indexing s[h][b] dynamically would send the
-    // accumulators through scratch memory (see gram.hip).  The column loop stays rolled, consumes element 0 and rotates the
-    // register arrays; the per-parameter loops are unrolled with a guard so that acc / gv keep static indices.
+    for (int q = 0; q < NG; ++q) acc[q] = 0.0;
     double ai[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int64_t gi = i0 + r + 64 * h;
         ai[h] = (gi < a.n) ? a.alpha[gi] : 0.0;
     }
-#pragma unroll 1
-    for (int b = 0; b < 16; ++b) {
-        const int64_t gj = j0 + g * 16 + b;
+    if constexpr (LEAF >= 0) {
+        // gradients evaluated unconditionally (padding rows / columns hold zeros: finite inputs), the pair's weight is zero
+        // outside the lower triangle; the coefficient's loads are issued for all 32 pairs before the first evaluation
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t gi = i0 + r + 64 * h;
-            if (gi < a.n && gj <= gi) {  // lower triangle incl. diagonal (algebra/mod.rs:142-151)
-                double gv[MAXG];
-                const int ng = kprog_grad(a.prog, s[h][0], u[h][0], gv);
+        for (int b = 0; b < 16; ++b) {
+            const int64_t gj = j0 + g * 16 + b;
+            const double aj = gj < a.n ? a.alpha[gj] : 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t gi = i0 + r + 64 * h;
+                const bool in = gi < a.n && gj <= gi;  // lower triangle incl. diagonal (algebra/mod.rs:142-151)
+                double gv[NG];
+                (void)leaf_grad_k<LEAF>(a.prog.ops[0], s[h][b], u[h][b], gv);
+                const double kinv = in ? a.Kinv[gi + gj * a.ldk] : 0.0;
                 const double w = (gi == gj) ? 1.0 : 2.0;
-                const double coef = w * (ai[h] * a.alpha[gj] * a.inv_scale - a.Kinv[gi + gj * a.ldk]);
+                const double coef = w * (ai[h] * aj * a.inv_scale - kinv);
 #pragma unroll
-                for (int q = 0; q < MAXG; ++q)
-                    if (q < ng) acc[q] += coef * gv[q];
+                for (int q = 0; q < NG; ++q)
+                    if (in) acc[q] += coef * gv[q];
             }
         }
+    } else {
+        // The gradient program is too large to be unrolled 32 times; a rolled loop indexing s[h][b] dynamically would send the
+        // accumulators through scratch memory (see gram.hip).  The column loop stays rolled, consumes element 0 and rotates the
+        // register arrays; the per-parameter loops are unrolled with a guard so that acc / gv keep static indices.
+#pragma unroll 1
+        for (int b = 0; b < 16; ++b) {
+            const int64_t gj = j0 + g * 16 + b;
 #pragma unroll
-        for (int i = 0; i < 15; ++i) {
-            s[0][i] = s[0][i + 1];
-            s[1][i] = s[1][i + 1];
-            u[0][i] = u[0][i + 1];
-            u[1][i] = u[1][i + 1];
+            for (int h = 0; h < 2; ++h) {
+                const int64_t gi = i0 + r + 64 * h;
+                if (gi < a.n && gj <= gi) {  // lower triangle incl. diagonal (algebra/mod.rs:142-151)
+                    double gv[MAXG];
+                    const int ng = kprog_grad(a.prog, s[h][0], u[h][0], gv);
+                    const double w = (gi == gj) ? 1.0 : 2.0;
+                    const double coef = w * (ai[h] * a.alpha[gj] * a.inv_scale - a.Kinv[gi + gj * a.ldk]);
+#pragma unroll
+                    for (int q = 0; q < MAXG; ++q)
+                        if (q < ng) acc[q] += coef * gv[q];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                s[0][i] = s[0][i + 1];
+                s[1][i] = s[1][i + 1];
+                u[0][i] = u[0][i + 1];
+                u[1][i] = u[1][i + 1];
+            }
         }
     }
     // block reduction of the ng accumulators
 #pragma unroll
-    for (int q = 0; q < MAXG; ++q) {
+    for (int q = 0; q < NG; ++q) {
         if (q < a.ng) {
             double v = acc[q];
 #pragma unroll
@@ -369,12 +402,29 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
     {
         ProfScope ps(ctx, FR_PROF_GRAM, 0.5 * (double)n * (double)n * (3.0 * (double)c->d + 60.0), 4.0 * (double)n * (double)n);
         const int needs = kprog_needs(*kernel);
-        if (needs == NEED_S)
-            hipLaunchKernelGGL(grad_reduce_kernel<NEED_S>, dim3((unsigned)nblocks), dim3(256), 0, ctx->ls, a);
-        else if (needs == NEED_U)
-            hipLaunchKernelGGL(grad_reduce_kernel<NEED_U>, dim3((unsigned)nblocks), dim3(256), 0, ctx->ls, a);
-        else
-            hipLaunchKernelGGL(grad_reduce_kernel<NEED_S | NEED_U>, dim3((unsigned)nblocks), dim3(256), 0, ctx->ls, a);
+        const int leaf = kernel->nops == 1 ? kernel->ops[0].kind : -1;
+        const dim3 grid((unsigned)nblocks), block(256);
+#define FR_GRAD_LEAF(KIND, MODE_)                                                                   \
+    case KIND: hipLaunchKernelGGL((grad_reduce_kernel<MODE_, KIND>), grid, block, 0, ctx->ls, a); break;
+        switch (leaf) {
+            FR_GRAD_LEAF(FR_K_LINEAR, NEED_U)
+            FR_GRAD_LEAF(FR_K_POLYNOMIAL, NEED_U)
+            FR_GRAD_LEAF(FR_K_SQUAREDEXP, NEED_S)
+            FR_GRAD_LEAF(FR_K_EXPONENTIAL, NEED_S)
+            FR_GRAD_LEAF(FR_K_MATERN1, NEED_S)
+            FR_GRAD_LEAF(FR_K_MATERN2, NEED_S)
+            FR_GRAD_LEAF(FR_K_HYPERTAN, NEED_U)
+            FR_GRAD_LEAF(FR_K_MULTIQUADRIC, NEED_S)
+            FR_GRAD_LEAF(FR_K_RATIONALQUADRATIC, NEED_S)
+        default:
+            if (needs == NEED_S)
+                hipLaunchKernelGGL((grad_reduce_kernel<NEED_S, -1>), grid, block, 0, ctx->ls, a);
+            else if (needs == NEED_U)
+                hipLaunchKernelGGL((grad_reduce_kernel<NEED_U, -1>), grid, block, 0, ctx->ls, a);
+            else
+                hipLaunchKernelGGL((grad_reduce_kernel<NEED_S | NEED_U, -1>), grid, block, 0, ctx->ls, a);
+        }
+#undef FR_GRAD_LEAF
         FR_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(256), 0, ctx->ls, (const double*)partials, nblocks, ng,
                            (const double*)Kinv, ld, (const double*)alpha, n, outs);

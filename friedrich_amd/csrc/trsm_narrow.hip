@@ -236,7 +236,23 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArg
     }
 }
 
-// ---- one column group (m <= 16): whole-tile register buffers, the next tile always in flight
+// ---- one column group (m <= 16) ------------------------------------------------------------------------------------------
+// The solve is a chain of n / 128 hand-offs; what one step costs is what the whole solve costs.  Round 2's step was: flag poll,
+// payload fetch, the product with the neighbouring tile (1.7 us: 64 MFMAs per SIMD), a transposition through LDS, the closing
+// product with the inverse block (1.7 us), payload stores, their acknowledgement, the flag -- ~9 us.  Now:
+//   * the last dependency of block r is its NEIGHBOUR x_{r-1}; everything that does not need it is done before it arrives:
+//       t' = b_r - sum_{q < r-1} L[r, q] x_q  (as before, behind flags),   y' = W_r t',   M = W_r L[r, r-1]  (128^3 on the matrix
+//     core, while the workgroup would otherwise wait: the tile goes through LDS in eight 16-column chunks, and the accumulator
+//     layout of v_mfma_f64_16x16x4 is exactly the operand layout of the next product, so M never leaves the registers);
+//   * when x_{r-1} arrives ONE product is left on the chain:  x_r = y' - M x_{r-1};
+//   * x_{r-1} is awaited on the payload itself: the hand-off buffer is filled with a NaN bit pattern no computation produces
+//     before every launch, a lane polls its four doubles until none is the pattern (8-byte stores are single-copy atomic, each
+//     element is written once) -- no flag round trip, no acknowledgement wait on the producer's side.  Only the ONE workgroup
+//     whose last dependency is pending polls this way; the others wait for flags as before (the flag is still published,
+//     behind the acknowledged stores, off the critical path).
+constexpr unsigned SENT32 = 0x7FF7A5A5u;  // both halves: hipMemsetD32 fills the payload with the (NaN) double 0x7FF7A5A57FF7A5A5
+__device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == 0x7FF7A5A57FF7A5A5ull; }
+
 __device__ __forceinline__ void mma_block(const double (&buf)[32], const double* xs, int l15, int lq, d4n_t& acc)
 {
 #pragma unroll
@@ -244,6 +260,39 @@ __device__ __forceinline__ void mma_block(const double (&buf)[32], const double*
         const double xf = xs[(4 * u + lq) * MR + l15];  // element (k = 4 u + lq, q = l15)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, buf[u], acc, 0, 0, 0);
     }
+}
+
+// the payload of block `blk`, awaited on the data itself -> xs ([col][q]); false after a timeout
+__device__ __forceinline__ bool poll_payload(const TrsmnArgs& a, int blk, double* xs, int t)
+{
+    const double* src = a.xg + (int64_t)blk * (NB * MR);
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned pending = 0xFu;
+    int ok = 1;
+    unsigned long long t0 = 0;
+    unsigned spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (pending & (1u << i)) {
+                v[i] = __hip_atomic_load((gdbl*)(src + t + NTH * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!is_sentinel(v[i])) pending &= ~(1u << i);
+            }
+        if (!pending) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins == 0) t0 = wall_clock64();
+        if ((++spins & 255u) == 0) {
+            const bool dead = __hip_atomic_load((hgu32*)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+            if (dead || wall_clock64() - t0 > HANDOFF_TIMEOUT_TICKS) {
+                __hip_atomic_store((hgu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = 0;
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs[t + NTH * i] = v[i];
+    return __builtin_amdgcn_readfirstlane(__syncthreads_and(ok)) != 0;
 }
 
 __global__ __launch_bounds__(NTH, 2) void trsm_narrow_kernel(const TrsmnArgs a0)
@@ -254,63 +303,127 @@ __global__ __launch_bounds__(NTH, 2) void trsm_narrow_kernel(const TrsmnArgs a0)
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int last = a0.nblk - 1;
-    // column group: 16 right-hand sides with their own solution blocks and flags -- the groups are independent chains that
-    // stream the same tiles (served from L2 / Infinity Cache after the first reader)
-    TrsmnArgs a = a0;
-    {
-        const int grp = blockIdx.y;
-        a.B += (int64_t)grp * MR * a.ldb;
-        a.m = a.m - grp * MR < MR ? a.m - grp * MR : MR;
-        a.xg += (int64_t)grp * a.nblk * (NB * MR);
-        a.flags += (int64_t)grp * a.nblk;
-        a.tickets += grp;
-    }
+    TrsmnArgs a = a0;  // (one column group: blockIdx.y == 0)
     __shared__ int claim_slot;
 #pragma nounroll
     for (;;) {
         const int bi = claim_block(a.tickets, a.nblk, &claim_slot);
         if (bi < 0) return;
         const int blk = a.bwd ? last - bi : bi;
-        const int cnt = a.bwd ? last - blk : blk;  // tiles; item q uses the solution block dep(q)
+        const int cnt = a.bwd ? last - blk : blk;  // dependencies: blocks dep(0) .. dep(cnt - 1), the neighbour last
         const int64_t b0 = (int64_t)blk * NB;
         const int64_t row = b0 + 16 * w + l15;
         double bv[4];  // this lane's right-hand side entries: (row, q = lq + 4 i)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bv[i] = (row < a.n && lq + 4 * i < a.m) ? a.B[row + (int64_t)(lq + 4 * i) * a.ldb] : 0.0;
-        d4n_t acc = {0.0, 0.0, 0.0, 0.0};
-        double F0[32], F1[32];
-        // items 0 .. cnt - 1: tiles, item cnt: the inverse block; two register buffers, the next item always in flight
-        load_frag(item_frag(a, blk, a.bwd ? last : 0, cnt == 0), w, l15, lq, F0);
-#pragma nounroll
-        for (int q = 0; q < cnt; q += 2) {
-            load_frag(item_frag(a, blk, a.bwd ? last - q - 1 : q + 1, q + 1 >= cnt), w, l15, lq, F1);
-            if (!fetch_block(a, a.bwd ? last - q : q, xs[0], t)) return;
-            mma_block(F0, xs[0], l15, lq, acc);
-            if (q + 1 >= cnt) break;
-            load_frag(item_frag(a, blk, a.bwd ? last - q - 2 : q + 2, q + 2 >= cnt), w, l15, lq, F0);
-            if (!fetch_block(a, a.bwd ? last - q - 1 : q + 1, xs[1], t)) return;
-            mma_block(F1, xs[1], l15, lq, acc);
+        // the inverse block's fragments stay in registers for the whole block
+        double Wf[32];
+        load_frag(item_frag(a, blk, 0, true), w, l15, lq, Wf);
+        // ---- M = W L[blk, neighbour], off the chain: the tile through LDS in 16-column chunks [k][16]
+        double Mf[32];
+        if (cnt > 0) {
+            const Frag f = item_frag(a, blk, a.bwd ? blk + 1 : blk - 1, false);
+            const int kk = t & 127, cc = t >> 7;
+            // address = one per-lane pointer + wave-uniform column offsets; the loads are unconditional (the addresses exist: see
+            // load_frag), what lies outside the valid extent of a last, partial block is replaced by zeros afterwards
+            const double* pl = f.base + kk + (int64_t)cc * f.stride;
+            auto load_chunk = [&](int j, double (&reg)[4]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) reg[i] = pl[(int64_t)(16 * j + 4 * i) * f.stride];
+                if (f.mrows < NB || f.kcols < NB) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) reg[i] = (kk < f.mrows && 16 * j + cc + 4 * i < f.kcols) ? reg[i] : 0.0;
+                }
+            };
+            double cr[4];
+            load_chunk(0, cr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xs[0][kk * MR + cc + 4 * i] = cr[i];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j + 1 < 8) load_chunk(j + 1, cr);
+                d4n_t am = {0.0, 0.0, 0.0, 0.0};
+                mma_block(Wf, xs[j & 1], l15, lq, am);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Mf[4 * j + i] = am[i];  // accumulator (m = l15, n = 16 j + lq + 4 i) == fragment slot u = 4 j + i
+                if (j + 1 < 8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xs[(j + 1) & 1][kk * MR + cc + 4 * i] = cr[i];
+                }
+                __syncthreads();
+            }
         }
-        // t = b - acc, as the [col][q] operand of the closing product with the inverse block
+        // ---- the dependencies in front of the neighbour: tiles in QUARTER-tile register buffers (16 rows x 32 columns, 8 doubles
+        //      per lane), the next quarter always in flight -- W and M hold 128 of the 256 registers
+        d4n_t acc = {0.0, 0.0, 0.0, 0.0};
+        if (cnt > 1) {
+            double Q0[8], Q1[8];
+            auto load_quarter = [&](const Frag& f, int Hq, double (&buf)[8]) {
+                const unsigned lane_off = (unsigned)(16 * w + l15) + (unsigned)lq * (unsigned)f.stride;
+                const double* base = f.base + (int64_t)(32 * Hq) * f.stride;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) buf[u] = (base + (int64_t)(4 * u) * f.stride)[lane_off];
+                if (f.mrows < NB || f.kcols < NB) {  // last block only: zeros outside the valid extent (the addresses exist)
+                    const bool mok = 16 * w + l15 < f.mrows;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) buf[u] = (mok && 32 * Hq + 4 * u + lq < f.kcols) ? buf[u] : 0.0;
+                }
+            };
+            auto mma_quarter = [&](const double (&buf)[8], int Hq) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[0][(32 * Hq + 4 * u + lq) * MR + l15], buf[u], acc, 0, 0, 0);
+            };
+            load_quarter(item_frag(a, blk, a.bwd ? last : 0, false), 0, Q0);
+#pragma nounroll
+            for (int q = 0; q < cnt - 1; ++q) {
+                const int dep = a.bwd ? last - q : q;
+                const Frag f = item_frag(a, blk, dep, false);
+                load_quarter(f, 1, Q1);
+                // (the barrier inside the wait: every wave is done with the block before; the dependency next to the neighbour is
+                // awaited on its payload as well -- its flag follows the payload by an acknowledgement round trip, and this
+                // block has y' = W t' to form between the two arrivals)
+                if (q == cnt - 2) {
+                    __syncthreads();
+                    if (!poll_payload(a, dep, xs[0], t)) return;
+                } else if (!fetch_block(a, dep, xs[0], t))
+                    return;
+                mma_quarter(Q0, 0);
+                load_quarter(f, 2, Q0);
+                mma_quarter(Q1, 1);
+                load_quarter(f, 3, Q1);
+                mma_quarter(Q0, 2);
+                if (q + 1 < cnt - 1) load_quarter(item_frag(a, blk, a.bwd ? last - q - 1 : q + 1, false), 0, Q0);
+                mma_quarter(Q1, 3);
+            }
+        }
+        // ---- y' = W (b - acc): everything that does not need the neighbour
 #pragma unroll
         for (int i = 0; i < 4; ++i) tv[(16 * w + l15) * MR + lq + 4 * i] = bv[i] - acc[i];
         __syncthreads();
         d4n_t x = {0.0, 0.0, 0.0, 0.0};
-        if (cnt & 1)
-            mma_block(F1, tv, l15, lq, x);  // an odd number of tiles leaves the inverse in the second buffer
-        else
-            mma_block(F0, tv, l15, lq, x);
-        // publish (write-through), then the caller's copy
+        mma_block(Wf, tv, l15, lq, x);
+        // ---- the neighbour, awaited on its payload; ONE product on the chain
+        if (cnt > 0) {
+            if (!poll_payload(a, a.bwd ? blk + 1 : blk - 1, xs[1], t)) return;
+            d4n_t z = {0.0, 0.0, 0.0, 0.0};
+            mma_block(Mf, xs[1], l15, lq, z);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] -= z[i];
+        }
+        // publish (write-through: the next owner polls these very words), then the caller's copy; the flag for the workgroups
+        // that take this block as an earlier dependency follows the acknowledged stores, off the chain
         double* dst = a.xg + (int64_t)blk * (NB * MR);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __hip_atomic_store((gdbl*)(dst + (16 * w + l15) * MR + lq + 4 * i), x[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) __hip_atomic_store((hgi32*)(a.flags + blk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (row < a.n && lq + 4 * i < a.m) a.B[row + (int64_t)(lq + 4 * i) * a.ldb] = x[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store((hgi32*)(a.flags + blk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();  // tv / xs are reused by the next block of this workgroup
     }
 }
@@ -419,6 +532,8 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     if (ctx->test_max_wgs > 0 && G > ctx->test_max_wgs) G = ctx->test_max_wgs;
     a.bwd = fwd ? 0 : 1;
     FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)(nblk + 1) * (size_t)ngroups, ctx->ls));
+    if (nq == 1 && ngroups == 1)  // the single-group kernel awaits the neighbour's block on the payload itself: fill it with the sentinel
+        FR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)a.xg, (int)SENT32, (size_t)nblk * NB * MR * 2, ctx->ls));
     ProfScope ps(ctx, prof_cls, (double)n * (double)n * (double)m, 4.0 * (double)n * (double)n);
     if (nq == 2)
         hipLaunchKernelGGL(trsm_narrow_half_kernel<2>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
