@@ -11,9 +11,10 @@ N = 32768, d = 16, RBF kernel with friedrich's default hyper-parameters, m = 409
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 3 --warmup 1
 
-N > 1: one process per GPU.  The factorisation is sharded (block-cyclic column panels, RCCL panel broadcast
-over xGMI, every rank ends with the full factor); the m query rows are split across ranks.  Total work is
-fixed => "scaling": "strong".  Inputs (X, y, X*) are resident in HBM before the timed region starts.
+N > 1: one process per GPU.  The factorisation is sharded (block-cyclic column panels; the chain of diagonal
+blocks travels by point-to-point fan-out, the rows below by scatter / per-rank solves / all-gather over xGMI,
+every rank ends with the full factor: DESIGN.md section 6); the m query rows are split across ranks.  Total work
+is fixed => "scaling": "strong".  Inputs (X, y, X*) are resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the FP64-MFMA trailing SYRK update) with
 HIP events recorded inside the library on the stream the kernel runs on; `cpu_baseline` times the CPU oracle
@@ -30,7 +31,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_NB = 1024  # block size of the run profiles/r02/fit32k_counters.json was collected with
+PMC_NB = 1024  # block size of the run profiles/r03/fit32k_counters.json was collected with
+PMC_FILE = os.path.join("profiles", "r03", "fit32k_counters.json")
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; scripts/mfma_f64_peak measures 77.0-77.6 on the box
 
 
@@ -56,8 +58,9 @@ def host_description():
 
 
 def strong_cpu_line(n):
-    """A LAPACK-class blocked multi-thread Cholesky on every host core (scipy / OpenBLAS dpotrf) -- NOT the reference's
-    algorithm, reported next to it so that the GPU number can be read against a well-used CPU as well."""
+    """A LAPACK blocked multi-thread Cholesky (scipy / OpenBLAS dpotrf) -- NOT the reference's algorithm and NOT a tuned CPU
+    baseline: an untuned reference point on the cores of ONE socket (the process is pinned to the first 32 hardware threads
+    for the call: round 2 ran it unpinned on 64 threads of a two-socket host and got less than an 8-vCPU container does)."""
     try:
         import scipy.linalg as sl
     except Exception:
@@ -65,7 +68,13 @@ def strong_cpu_line(n):
     rng = np.random.default_rng(0)
     Q = rng.standard_normal((n, 64))
     A = Q @ Q.T + n * np.eye(n)
-    threads = min(os.cpu_count() or 1, 64)  # one thread per physical core of a socket: more only adds contention at this size
+    threads = min(os.cpu_count() or 1, 32)
+    old_aff = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(sorted(old_aff)[:threads]))
+    except (AttributeError, OSError):
+        old_aff = None
     try:
         from threadpoolctl import threadpool_limits
         limit = threadpool_limits(limits=threads)
@@ -79,8 +88,10 @@ def strong_cpu_line(n):
     finally:
         if limit is not None:
             limit.restore_original_limits()
-    return {"what": f"scipy.linalg.cholesky (LAPACK dpotrf, {threads} threads) of a {n} x {n} matrix", "seconds": dt,
-            "GFLOP/s": n ** 3 / 3.0 / dt / 1e9, "threads": threads}
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
+    return {"what": f"UNTUNED reference point: scipy.linalg.cholesky (OpenBLAS dpotrf, {threads} threads pinned to the first {threads} "
+                    f"hardware threads) of a {n} x {n} matrix", "seconds": dt, "GFLOP/s": n ** 3 / 3.0 / dt / 1e9, "threads": threads}
 
 
 def cpu_baseline(n, d, m, cfg):
@@ -108,7 +119,7 @@ def cpu_baseline(n, d, m, cfg):
         "sample": f"N={n} d={d} m={m} same generator/kernel, oracle fit {t1 - t0:.1f}s + predict {t2 - t1:.1f}s, 1 thread "
                   f"(the reference's nalgebra path is single-threaded) on a host with {cores} hardware threads: {model}",
         "host": {"cpu_model": model, "hardware_threads": cores},
-        "strong_cpu": strong_cpu_line(8192),
+        "strong_cpu": strong_cpu_line(6144),
     }
 
 
@@ -246,9 +257,12 @@ def main():
                 b = min(b, time.perf_counter() - t0)
             return 1e3 * b
 
-        for mm in (1, 16):
+        for mm in (1, 16, 32, 64):
+            if mm > m_loc:
+                continue
             q = Xq_d[:mm]
-            extras[f"predict_m{mm}_ms"] = best_ms(lambda: chol.predict_mean(kernel, y_d, q, prior_d[:mm], out=mean_d[:mm]))
+            if mm <= 16:
+                extras[f"predict_m{mm}_ms"] = best_ms(lambda: chol.predict_mean(kernel, y_d, q, prior_d[:mm], out=mean_d[:mm]))
             var_d = torch.empty((mm,), dtype=torch.float64, device=dev)
             extras[f"predict_variance_m{mm}_ms"] = best_ms(lambda: chol.predict_variance(kernel, q, out=var_d))
         extras["likelihood_ms"] = best_ms(lambda: chol.likelihood(kernel, y_d, noise))
@@ -283,11 +297,11 @@ def main():
         # PMC counters cannot be read from inside the process: the figure is the committed rocprofv3 --pmc summary of the
         # same workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction); null for any other size
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02", "fit32k_counters.json")
+        pmc_path = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc_path) and (n, d, nb_eff, world) == (32768, 16, PMC_NB, 1):
             with open(pmc_path) as f:
-                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: regenerate (scripts/profile_r02.sh) whenever gemm_f64.hip / gemm_tile.hpp change
-            traffic_src = "profiles/r02/fit32k_counters.json"
+                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: regenerate (scripts/profile_r03.sh) whenever gemm_f64.hip / gemm_tile.hpp change
+            traffic_src = PMC_FILE
         out = {
             "metric": "gp_fit_predict_gflops",
             "value": total_flops / (ms_per_step * 1e-3) / 1e9,

@@ -1,9 +1,44 @@
 // ctx.hip -- context, error reporting, workspace pool, host<->device staging, event-based profiling.
 #include <cstdarg>
+#include <dlfcn.h>
 
 #include "fr_internal.hpp"
 
 namespace fr {
+
+// ---- roctx ranges (tracing) --------------------------------------------------------------------------------
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static std::once_flag g_roctx_once;
+
+static void roctx_load()
+{
+    const char* e = getenv("FRIEDRICH_AMD_ROCTX");
+    if (!e || e[0] != '1') return;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) return;
+        g_roctx_push = nullptr;
+        g_roctx_pop = nullptr;
+    }
+}
+
+TraceScope::TraceScope(const char* name) : on(false)
+{
+    std::call_once(g_roctx_once, roctx_load);
+    if (g_roctx_push) {
+        (void)g_roctx_push(name);
+        on = true;
+    }
+}
+
+TraceScope::~TraceScope()
+{
+    if (on && g_roctx_pop) (void)g_roctx_pop();
+}
 
 int set_err(fr_ctx* ctx, int status, const char* fmt, ...)
 {

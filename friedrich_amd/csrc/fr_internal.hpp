@@ -13,7 +13,19 @@
 #include "friedrich_amd.h"
 #include <mutex>
 
-#define FR_LOCK(ctxptr) std::lock_guard<std::recursive_mutex> fr_lock_guard__((ctxptr)->mu)
+namespace fr {
+// roctx range around an entry point (rocprofv3 --marker-trace shows the fr_* calls above their kernels).  Off unless the
+// process sets FRIEDRICH_AMD_ROCTX=1: the marker library (librocprofiler-sdk-roctx / libroctx64) is dlopen'ed on first use.
+struct TraceScope {
+    bool on;
+    explicit TraceScope(const char* name);
+    ~TraceScope();
+};
+}  // namespace fr
+
+#define FR_LOCK(ctxptr)                                                       \
+    std::lock_guard<std::recursive_mutex> fr_lock_guard__((ctxptr)->mu);      \
+    fr::TraceScope fr_trace_scope__(__func__)
 
 namespace fr {
 
