@@ -149,19 +149,12 @@ static int exchange_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t
 }
 
 // rows x kb block S (leading dimension lds) of still unsolved rows of the panel at column k  ->  S L_kk^-T, against the factored
-// kb x kb diagonal block in A and its 128-block inverses: left-looking over the 128-column sub-panels,
-// S_s <- (S_s - S_{<s} L[s, <s]^T) W_s^T.  Every element's arithmetic is independent of how the rows are cut into blocks.
+// kb x kb diagonal block in A and its 128-block inverses: ONE launch, a workgroup takes 32 rows through the left-looking
+// sweep over the 128-column sub-panels (gemm_f64.hip: rows_solve_kernel).
 static int solve_rows(fr_ctx* ctx, double* S, int64_t lds, int64_t rows, const double* A, int64_t ld, int64_t k, int64_t kb,
                       const double* dblk)
 {
-    const int64_t nblk = (kb + IB - 1) / IB;
-    for (int64_t s = 0; s < nblk; ++s) {
-        const int64_t c0 = s * IB, cs = imin(IB, kb - c0);
-        if (s > 0)
-            FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, rows, cs, c0, S, lds, false, A + (k + c0) + k * ld, ld, false, -1.0, 1.0, S + c0 * lds, lds));
-        FR_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, rows, cs, cs, S + c0 * lds, lds, false, dblk + s * INV_ELEMS, IB, false, 1.0, 0.0, S + c0 * lds, lds));
-    }
-    return FR_OK;
+    return launch_rows_solve(ctx, S, lds, rows, A + k + k * ld, ld, kb, dblk);
 }
 
 // The split variant of a panel step (option dist_schedule = 1): the owner factors the kb x kb DIAGONAL block only and
@@ -211,15 +204,16 @@ static int split_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k,
 // blocks: D_p needs the row tile p of every earlier panel.  Schedules 0 / 1 put the whole panel step on that chain
 // (factor all rows -> broadcast, or diagonal block -> scatter -> solves -> all-gather, one after the other on one stream and
 // one communicator).  Here the chain carries only what the NEXT diagonal block waits for:
-//   H_p = [D_p, its 128-block inverses]     fan-out from the owner to every rank        (~2.5 MB at nb = 512)
-//   M_p = R1_p = L[panel p + 1's rows, p]   solved by the owner itself, fan-out          (~2 MB)
-// on the panel stream / first communicator; the next owner applies R1_p to its diagonal block at once (u1) and factors D_p+1.
-// The rows below R1_p (the bulk) follow on their own stream and communicator: scatter of the unsolved rows in W slices (one
-// xGMI link each), every rank solves its slice against D_p, one all-gather -- 1 / W of the panel over every link of every GPU.
+//   M_p = R1_p = L[panel p + 1's rows, p]   solved by the owner itself (one launch), fanned out to every rank   (~2 MB at nb = 512)
+// on the panel stream / first communicator; the next owner applies R1_p to its diagonal block at once (u1) and factors D_p+1 --
+// it needs nothing else of panel p.  Everything else follows on the bulk stream and the second communicator:
+//   H_p = [D_p, its 128-block inverses]     fan-out from the owner to every rank        (~2.5 MB)
+//   the rows below R1_p: scatter of the unsolved rows in W slices (one xGMI link each), every rank solves its slice against
+//   D_p (one launch), one all-gather -- 1 / W of the panel over every link of every GPU.
 // The trailing updates (main stream) take a panel once its bulk has arrived; each rank updates its NEAREST owned block
 // column first (for the next owner: the rows of R1_p+1 before the others), because that is the column the chain waits for.
 // Dependencies between the three streams are HIP events; the critical path per panel is
-//   max( D factor + R1 solve + two fan-outs,  (bulk latency + first look-ahead tile + R1 solve) / 2 )
+//   max( D factor + R1 solve + one fan-out + u1,  (bulk latency + first look-ahead tile + R1 solve + fan-out + u1) / 2 )
 // instead of their sum (D_p+1 needs the bulk of panel p - 1, not of panel p).  DESIGN.md section 6 has the model.
 // Every rank issues the same sequence of communication calls in the same host order, and that order is a topological order of
 // the dependency graph -- which is what keeps two communicators used side by side free of deadlock (comm.hip).
@@ -304,17 +298,10 @@ static int potrf_dist_chain(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64
         ctx->ls = S1;
         if (me == own) {
             CH_TRY(factor_panel(ctx, A, ld, k1, k, kb, col0, mode, sub, dinv, info, nullptr));  // rows k .. k1 only
-            CH_TRY(launch_copy(ctx, A + k + k * ld, ld, hb, kb, kb, kb));
-            CH_HIP(hipMemcpyAsync(hb + kb * kb, dblk, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, S1));
+            CH_HIP(hipEventRecord(ev(EV_HEAD, p), S1));
         }
-        // ---- 2. H_p
-        CH_TRY(comm_fanout(ctx, hb, (size_t)head_count, own, 0));
-        if (me != own) {
-            CH_TRY(launch_copy(ctx, hb, kb, A + k + k * ld, ld, kb, kb));
-            CH_HIP(hipMemcpyAsync(dblk, hb + kb * kb, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, S1));
-        }
-        CH_HIP(hipEventRecord(ev(EV_HEAD, p), S1));
-        // ---- 3. M_p = R1_p: the rows of the next panel's diagonal block, solved by the owner in place
+        // ---- 2. M_p = R1_p: the rows of the next panel's diagonal block, solved by the owner in place and fanned out -- the
+        //      ONE message of the chain: the next diagonal block needs nothing else of panel p
         if (kb1 > 0) {
             double* R1 = A + k1 + k * ld;
             if (me == own) {
@@ -332,9 +319,20 @@ static int potrf_dist_chain(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64
                 CH_TRY(gemm(ctx, FR_PROF_GEMM_PANEL, kb1, kb1, kb, R1, ld, false, R1, ld, false, -1.0, 1.0, A + k1 + k1 * ld, ld, true));
             }
         }
-        // ---- 4. bulk: the rows from k2 on, in W slices of whole 128-row blocks
+        // ---- 3. bulk stream / second communicator: H_p = [D_p, inverses] to every rank (the slices are solved against it; the
+        //      next owner does NOT wait for it), then the rows from k2 on in W slices of whole 128-row blocks
+        ctx->ls = S3;
+        if (me == own) {
+            CH_HIP(hipStreamWaitEvent(S3, ev(EV_HEAD, p), 0));
+            CH_TRY(launch_copy(ctx, A + k + k * ld, ld, hb, kb, kb, kb));
+            CH_HIP(hipMemcpyAsync(hb + kb * kb, dblk, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, S3));
+        }
+        CH_TRY(comm_fanout(ctx, hb, (size_t)head_count, own, 1));
+        if (me != own) {
+            CH_TRY(launch_copy(ctx, hb, kb, A + k + k * ld, ld, kb, kb));
+            CH_HIP(hipMemcpyAsync(dblk, hb + kb * kb, sizeof(double) * (size_t)(nblk * INV_ELEMS), hipMemcpyDeviceToDevice, S3));
+        }
         if (below > 0) {
-            ctx->ls = S3;
             const int64_t sr = round_up((below + W - 1) / W, IB);
             auto rows_of = [&](int q) { return imax(0, imin(sr, below - (int64_t)q * sr)); };
             if (me == own) {
@@ -344,19 +342,18 @@ static int potrf_dist_chain(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64
                         CH_TRY(launch_copy(ctx, A + k2 + (int64_t)q * sr + k * ld, ld, sb + (int64_t)q * sr * kb, sr, rows_of(q), kb));
             }
             CH_TRY(comm_scatter(ctx, sb, (size_t)(sr * kb), own, 1));
-            CH_HIP(hipStreamWaitEvent(S3, ev(EV_HEAD, p), 0));  // D_p and its inverses are in place on this rank
             if (rows_of(me) > 0) CH_TRY(solve_rows(ctx, sb + (int64_t)me * sr * kb, sr, rows_of(me), A, ld, k, kb, dblk));
             CH_TRY(comm_allgather(ctx, sb + (int64_t)me * sr * kb, sb, (size_t)(sr * kb), 1));
             for (int q = 0; q < W; ++q)
                 if (rows_of(q) > 0)
                     CH_TRY(launch_copy(ctx, sb + (int64_t)q * sr * kb, sr, A + k2 + (int64_t)q * sr + k * ld, ld, rows_of(q), kb));
-            CH_HIP(hipEventRecord(ev(EV_BULK, p), S3));
         }
+        CH_HIP(hipEventRecord(ev(EV_BULK, p), S3));
         // ---- 5. trailing updates with panel p (main stream): the nearest owned block column first
         if (kb1 > 0) {
             ctx->ls = S0;
             CH_HIP(hipStreamWaitEvent(S0, ev(EV_MSG, p), 0));
-            if (below > 0) CH_HIP(hipStreamWaitEvent(S0, ev(EV_BULK, p), 0));
+            if (below > 0) CH_HIP(hipStreamWaitEvent(S0, ev(EV_BULK, p), 0));  // (H_p alone is of no interest to the updates)
             const int64_t q = p + 1 + (((int64_t)me - (p + 1)) % W + W) % W;  // nearest panel after p that this rank owns
             const double* Lp = A + k * ld;  // block column p of the factor: row r at Lp + r
             if (q == p + 1) {

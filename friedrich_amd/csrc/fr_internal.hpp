@@ -318,6 +318,8 @@ struct GemmDesc {
     bool dynamic = false;
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
+// S (rows x kb, ld lds_) <- S L^-T against a factored kb x kb diagonal block and its 128-block inverses: one launch (gemm_f64.hip)
+int launch_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const double* L, int64_t ldl, int64_t kb, const double* dinv);
 int launch_release_xcds(fr_ctx* ctx, unsigned epoch);  // on ctx->ls: the chain of panel `epoch` is finished
 
 // K4: factor one diagonal block (nbk <= 128) and emit its explicit inverse (inv may be NULL).

@@ -149,6 +149,21 @@ __global__ __launch_bounds__(256, (MODE == (NEED_S | NEED_U)) ? 2 : 3) void gram
     };
     if constexpr (LEAF >= 0) {
         // single built-in kernel: 32 independent straight-line evaluations, static register indices
+        const bool interior = !a.dot_vec && i0 + GT_M <= a.n1 && j0 + GT_N <= a.n2 && !(a.sym && j0 + GT_N > i0 && j0 < i0 + GT_M);
+        if (interior) {
+            // whole tile inside the matrix and off the diagonal (all but O(n) of the n^2 / 8192 tiles): no bounds tests, no
+            // diagonal test; a column's address is a wave-uniform base (scalar registers) + the lane's row -- measured with
+            // SQ_INSTS_VALU: the tests and 64-bit address arithmetic were a third of the epilogue's instructions
+            const int gw = __builtin_amdgcn_readfirstlane(g);
+            double* col = a.out + i0 + (j0 + gw * 16) * a.ldo;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                col[(unsigned)r] = kprog_eval_k<LEAF>(a.prog, s[0][b], u[0][b]);
+                col[(unsigned)r + 64u] = kprog_eval_k<LEAF>(a.prog, s[1][b], u[1][b]);
+                col += a.ldo;
+            }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < 16; ++b)
             emit(b, kprog_eval_k<LEAF>(a.prog, s[0][b], u[0][b]), kprog_eval_k<LEAF>(a.prog, s[1][b], u[1][b]));

@@ -59,9 +59,9 @@ def chain_rounds(n, nb, world):
     """One dict per panel p, in the host issue order of potrf_dist_chain:
          k, k1, k2, k3   first column of panels p, p + 1, p + 2, p + 3 (clamped to n)
          owner, next     ranks owning panels p and p + 1
-         head            (k, k1): the diagonal block D_p, fanned out with its inverse blocks           [chain stream, comm 0]
          r1              (k1, k2): rows of R1_p = L[panel p + 1's rows, p], solved by the owner, fanned out  [chain stream, comm 0];
-                         the next owner applies them to its diagonal block at once (u1)
+                         the next owner applies them to its diagonal block at once (u1) -- the chain's only message
+         head            (k, k1): the diagonal block D_p, fanned out with its inverse blocks           [bulk stream, comm 1]
          bulk            slice_rows and [(first row, rows)] per rank for the rows from k2 on: scatter, per-rank solves,
                          all-gather                                                                    [bulk stream, comm 1]
          near[rank]      the panel whose block column `rank` updates first with panel p (its nearest owned one)"""

@@ -71,7 +71,10 @@ for k in (0, 8192, 16384, 24576):
     Cn = cm(rest, nb)
     la2 = best(lambda: ctx.gemm(P, P[:nb], Cn, trans_b=True, alpha=-1.0, beta=1.0), 5)
     src, dst = cm(sl, nb), cm(sl, nb)
-    cp = best(lambda: dst.copy_(src) and None, 5)
+    def do_copy():
+        dst.copy_(src)
+        torch.cuda.synchronize()
+    cp = best(do_copy, 5)
     share = rest * rest * nb / W / 6.2e13 * 1e6
     print(f"k = {k}: rest {rest} rows | LA2 {la2:.0f} us | slice of {sl} rows: solve {solve_rows(sl):.0f} us, copy {cp:.0f} us "
           f"({2 * 8 * sl * nb / cp / 1e3:.0f} GB/s) | a rank's share of the trailing update at 62 TF/s: {share:.0f} us")

@@ -210,13 +210,12 @@ def _worker_chain(rank, world, port, n, nb, out_dir):
     for r in sharding.chain_rounds(n, nb, world):
         kk, k1, k2, k3, owner = r["k"], r["k1"], r["k2"], r["k3"], r["owner"]
         kb = k1 - kk
-        # 1 + 2: D_p on its owner, fanned out
+        # 1: D_p on its owner
         D = np.zeros((kb, kb))
         if rank == owner:
             D = sl.cholesky(A[kk:k1, kk:k1], lower=True)
-        D = bcast(D, owner)
-        A[kk:k1, kk:k1] = D
-        # 3: R1_p solved by the owner, fanned out; u1 on the next owner
+            A[kk:k1, kk:k1] = D
+        # 2: R1_p solved by the owner, fanned out (the one message of the chain); u1 on the next owner
         if k2 > k1:
             R1 = np.zeros((k2 - k1, kb))
             if rank == owner:
@@ -225,7 +224,9 @@ def _worker_chain(rank, world, port, n, nb, out_dir):
             A[k1:k2, kk:k1] = R1
             if rank == r["next"]:
                 A[k1:k2, k1:k2] -= R1 @ R1.T
-        # 4: bulk
+        # 3: bulk stream: D_p to every rank, then the rows below R1_p
+        D = bcast(D, owner)
+        A[kk:k1, kk:k1] = D
         sr, slices = r["bulk"]
         if sr > 0:
             bufs = []
