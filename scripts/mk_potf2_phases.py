@@ -1,7 +1,7 @@
 """Developer tool: per-phase s_memtime instrumentation of the diagonal-block kernel (writes scripts/potf2_bench_phases.hip).
 Wave 0 stamps: start | block loaded | after each F_b | after each stage's last barrier | inverse stored."""
 src = open('friedrich_amd/csrc/potf2.hip').read()
-kern = src[src.index("constexpr int PB = 128;"):src.index("// ---- the diagonal-block SERVER")]
+kern = src[src.index("constexpr int PB = 128;"):src.index("int launch_potf2(")]
 # potf2_block: one more argument, stamps by wave 0 and by update wave 0
 kern = kern.replace("int64_t* __restrict__ info, double* __restrict__ cest = nullptr)\n{",
                     "int64_t* __restrict__ info, double* __restrict__ cest = nullptr, long long* ts = nullptr)\n{\n    if (ts && threadIdx.x == 0) ts[0] = __builtin_amdgcn_s_memtime();", 1)
@@ -23,7 +23,8 @@ for idx in range(3):
     body += "        lds_barrier();\n        if (ts && w == 1 && lane == 0) ts[16 + 8 * b + %d] = __builtin_amdgcn_s_memtime();\n" % idx + parts[idx + 1]
 kern = head + "    const int u = w - 1;\n" + body + "    // ---- store the inverse" + rest
 # the kernel wrapper passes the stamp buffer on and stamps the end
-kern = kern.replace("unsigned* __restrict__ yield_word, unsigned* __restrict__ xcc_word)\n{", "unsigned* __restrict__ yield_word, unsigned* __restrict__ xcc_word, long long* ts)\n{", 1)
+kern = kern.replace("unsigned* __restrict__ xcc_word)\n{", "unsigned* __restrict__ xcc_word, long long* ts)\n{", 1)
+assert "long long* ts)" in kern
 call = "    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);\n"
 assert kern.count(call) == 1
 kern = kern.replace(call, "    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest, ts);\n    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n", 1)
@@ -35,7 +36,6 @@ prog = '''#include <hip/hip_runtime.h>
 #include <unistd.h>
 #include "friedrich_amd.h"
 #include "fr_internal.hpp"
-#include "handoff.hpp"
 namespace fr {
 ''' + kern + '''}
 int main(int argc, char** argv){
@@ -54,7 +54,7 @@ int main(int argc, char** argv){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
     if (noise) { for (int g = 0; g < 6; ++g) fr_gemm(ctx, 0, 1, NM, NM, NK, -1.0, NA, NM, NA, NM, 1.0, NC, NM); usleep(6000); }
     hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,hs);
-    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,(double*)nullptr,(unsigned*)nullptr,(unsigned*)nullptr,ts); (void)hipEventRecord(e1,hs); (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,(double*)nullptr,(unsigned*)nullptr,ts); (void)hipEventRecord(e1,hs); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms,e0,e1);
     long long t[64]; (void)hipMemcpy(t,ts,8*64,hipMemcpyDeviceToHost);
     if (rep==2) { printf("event %.1f us; shader-clock cycles: load %lld", ms*1e3, t[1]-t[0]);

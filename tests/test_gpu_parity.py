@@ -611,6 +611,72 @@ def test_refinement_policy_and_forced_modes(ctx):
     assert rel_err(Ls[0], Ls[2]) < 1e-13 and np.array_equal(Ls[0], Ls[1])
 
 
+def test_conditioning_tracked_through_add_rows_from_matrix_and_upload(ctx):
+    """The conditioning estimate and the refinement decision follow EVERY way a factor comes into being or changes (round-2
+    advisor: only fr_chol_from_inputs / refactor refreshed them).  Fixture: RBF, d = 1, length scale 0.05, sorted points --
+    every 128 x 128 diagonal block is ill-conditioned (estimates ~1e3 at noise 1e-3).
+      * add_rows: a well-conditioned factor (spread points, noise 0.3) takes 300 ill-conditioned rows: the appended blocks'
+        estimates raise max_estimate above the threshold, the append is repeated with refinement, the handle refines from
+        then on, and the grown factor matches the oracle's to the conditioning-limited accuracy of the refined path;
+      * fr_chol_from_matrix on the explicit covariance matrix and fr_chol_upload_l of the oracle's factor: both report the
+        estimate and switch refinement on; with option refine = 0 nothing refines and the estimate is still reported."""
+    rng = np.random.default_rng(11)
+    k = ("squared_exp", 0.05, 1.0)
+    noise = 1e-3
+    n0, n1 = 400, 300
+    X = np.asfortranarray(np.concatenate([5.0 + 0.1 * np.arange(n0).reshape(-1, 1), np.sort(rng.random((n1, 1)), axis=0)]))  # a grid two length scales apart, then a dense cluster
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, noise)
+    assert st == 0
+    K = O.make_covariance_matrix(k, X, X) + noise * noise * np.eye(n0 + n1)
+    ku = np.linalg.cond(K) * 2.2e-16
+    chol = ctx.cholesky_from_inputs(k, X[:n0], noise, capacity_hint=n0 + n1)
+    est0, ref0 = chol.conditioning()
+    assert not ref0 and est0 < 30.0  # grid points two length scales apart: nearly diagonal
+    chol.add_rows(k, X, n1, noise)
+    est1, ref1 = chol.conditioning()
+    assert ref1 and est1 > 100.0, (est1, ref1)
+    assert rel_err(chol.l(), np.tril(L_o)) < max(1e-9, 0.1 * ku)
+    B = np.asfortranarray(rng.standard_normal((n0 + n1, 3)))
+    assert rel_err(chol.solve(B), O.chol_solve(L_o, B)) < max(1e-9, 2.0 * ku)
+    chol.free()
+    for mode in (-1, 0):
+        ctx.set_option("refine", mode)
+        try:
+            c2 = ctx.cholesky_from_matrix(K)
+            est2, ref2 = c2.conditioning()
+            assert est2 > 100.0 and ref2 == (mode == -1)
+            if mode == -1:
+                assert rel_err(c2.l(), np.tril(L_o)) < max(1e-9, 0.1 * ku)
+            c2.free()
+            c3 = ctx.cholesky_upload(np.asfortranarray(np.tril(L_o)), X)
+            est3, ref3 = c3.conditioning()
+            assert est3 > 100.0 and ref3 == (mode == -1)
+            assert rel_err(c3.solve(B), O.chol_solve(L_o, B)) < (max(1e-9, 2.0 * ku) if mode == -1 else 1e-4)
+            c3.free()
+        finally:
+            ctx.set_option("refine", -1)
+
+
+def test_roctx_ranges_do_not_disturb_a_run():
+    """FRIEDRICH_AMD_ROCTX=1: every entry point opens a roctx range (marker library dlopen'ed on first use); a fit + predict in
+    a fresh process behaves exactly as without it (the ranges only show in a tool: rocprofv3 --marker-trace)."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from friedrich_amd.device import Context; c = Context(); "
+            "X = np.asfortranarray(np.random.default_rng(0).random((300, 3))); ch = c.cholesky_from_inputs(('squared_exp', 0.8, 1.3), X, 0.1); "
+            "print(float(ch.predict_variance(('squared_exp', 0.8, 1.3), X[:2])[0])); ch.free(); c.close()") % ROOT
+    outs = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FRIEDRICH_AMD_ROCTX=flag), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
+
+
 def test_degenerate_sizes(ctx):
     """One training row, one query, no query at all, a row-append of zero rows, a single right-hand side of length 1: the
     launches that would be empty are skipped, the answers are the oracle's (mod.rs:234-241, 260-263; algebra/mod.rs:97-126)."""
