@@ -185,3 +185,61 @@ def test_rccl_single_rank_communicator():
         chol.free()
     finally:
         ctx.close()
+
+
+def test_config3_full_size_sharded_over_eight_ranks():
+    """BASELINE configs[3] as it is sharded: N = 32768, d = 16, RBF, block columns of 512 dealt to EIGHT ranks, the default
+    (chain-first) schedule -- eight thread-ranks on the one GPU a test box has (8 x 8 GiB factors + the reference's), the
+    in-process transport instead of RCCL, everything else the code path of an 8-GPU node: ownership filters in the Gram and
+    trailing-update kernels, 64 rounds of the chain / bulk / update streams with their events, the merged substitution log.
+    Every rank's factor is compared ON THE DEVICE with the single-rank factor of the same build, which
+    tests/test_gpu_fullsize_oracle.py compares with the oracle at this size; rank 0 also predicts its share of 512 queries."""
+    import ctypes
+    import threading as th
+
+    import torch
+
+    from friedrich_amd import synth
+    from friedrich_amd.device import Context
+
+    n, d, m, world = 32768, 16, 512, 8
+    X, y, Xq = synth.make_problem(n, d, cfg=3, m=m)
+    c0 = Context()
+    ls = c0.mean_pairwise_distance(X)
+    hp = synth.default_hyperparameters(X, y, ls)
+    k = ("squared_exp", hp["ls"], hp["ampl"])
+    dev = torch.device("cuda", 0)
+
+    def factor_on_device(chol):
+        buf = torch.empty((n, n), dtype=torch.float64, device=dev).t()
+        chol.ctx.check(chol.lib.fr_chol_download_l(chol.h, ctypes.c_void_p(buf.data_ptr()), n, 0))
+        chol.ctx.synchronize()
+        return buf
+
+    ref = c0.cholesky_from_inputs(k, X, hp["noise"])
+    Lref = factor_on_device(ref)
+    yres = y - hp["prior"]
+    mean_ref = ref.predict_mean(k, yres, Xq, np.full(m, hp["prior"]))
+    ref.free()
+    scale = float(Lref.abs().max())
+    lock = th.Lock()
+
+    def fn(ctx, rank):
+        chol = ctx.cholesky_from_inputs(k, X, hp["noise"])
+        info = chol.info()
+        with lock:  # one 8 GiB comparison buffer at a time
+            L = factor_on_device(chol)
+            err = float((L - Lref).abs().max()) / scale
+            del L
+            torch.cuda.empty_cache()
+        lo, hi = (m * rank) // world, (m * (rank + 1)) // world
+        mean = chol.predict_mean(k, yres, Xq[lo:hi], np.full(hi - lo, hp["prior"]))
+        chol.free()
+        return err, info, mean
+
+    res = run_ranks(world, fn)
+    c0.close()
+    for err, info, _ in res:
+        assert err < 1e-12, err
+        assert info["n_subst"] == 0 and info["fail_col"] == -1
+    assert rel_err(np.concatenate([r[2] for r in res]), mean_ref) < 1e-10
