@@ -489,6 +489,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     // part of the update (K = kb - 128) while the panel stream still factors the last block; what remains between the panels
     // is the K = 128 part.  Single GPU only (the sharded schedules have their own look-ahead).
     bool la_split = false;  // the first part of the update by the panel just finished has been issued
+    bool la_on_panel = false;  // ... and its remainder too, on the panel stream: the update is complete in that stream's order
     auto la_hook = [&](int64_t kk, int64_t kbb) {
         ctx->cols_final_at = -1;
         if (world == 1 && ctx->ev_cols && kbb > IB && kbb % IB == 0 && n - (kk + kbb) > 0) ctx->cols_final_at = kk + kbb - IB;
@@ -541,7 +542,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         }
         const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
-        if (own_next) {
+        if (own_next && !la_on_panel) {
             // (profile class: panel -- the SYRK class times exactly the syrk_lower_f64_kernel launches)
             if (la_split)  // the first kb - 128 columns' part ran under the panel's last block: the last 128 columns remain
                 st = gemm(ctx, FR_PROF_GEMM_PANEL, rest, kb2, IB, P + (kb - IB) * ld, ld, false, P + (kb - IB) * ld, ld, false, -1.0, 1.0,
@@ -551,7 +552,8 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
                           A + (k + kb) + (k + kb) * ld, ld);
             if (st != FR_OK) return fail(st);
         }
-        if (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess)
+        // (with the whole look-ahead update already applied on the panel stream itself there is nothing to wait for: no hop)
+        if (!la_on_panel && (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess))
             return fail(FR_HIP_ERROR);
         ctx->ls = S1;
         if (split) {
@@ -564,7 +566,6 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
         }
         if (st != FR_OK) return fail(st);
-        if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
         ctx->ls = S0;
         const int64_t rest2 = rest - kb2;
         if (rest2 > 0) {
@@ -583,6 +584,32 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         }
         st = la_first_part(k + kb, kb2);  // (behind the trailing update on this stream; waits for the panel stream's ev_cols)
         if (st != FR_OK) return fail(st);
+        la_on_panel = false;
+        if (la_split && ctx->reserve_now > 0) {
+            // Chain-bound: the K = 128 remainder of the look-ahead update goes on the PANEL stream, right behind the panel it
+            // completes and in front of ev_panel -- the next panel then starts in stream order, without the two stream hops
+            // (18 + 14 us per panel at N = 8192).  The trailing update of the panel before was launched at the start of this
+            // round and is long done (chain-bound), so the product has the chip to itself; and the trailing update with THIS
+            // panel starts behind ev_panel, i.e. behind it.  (Round 3's first attempt put it on the panel stream AFTER
+            // ev_panel: it then raced the trailing update for the CUs and the fit got slower.)
+            if (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess) return fail(FR_HIP_ERROR);
+            ctx->ls = S1;
+            const int64_t kk = k + kb, after = n - (kk + kb2);
+            GemmDesc g;
+            g.M = after; g.N = width(after); g.K = IB;
+            g.A = A + (kk + kb2) + (kk + kb2 - IB) * ld; g.lda = ld; g.a_kmajor = false;
+            g.B = g.A; g.ldb = ld; g.b_kmajor = false;
+            g.D = A + (kk + kb2) + (kk + kb2) * ld; g.ldd = ld;
+            g.Cin = g.D; g.ldcin = ld;
+            g.alpha = -1.0; g.beta = 1.0; g.lower = false; g.prof_cls = FR_PROF_GEMM_PANEL;
+            g.whole_chip = true;
+            st = launch_gemm(ctx, g);
+            if (st != FR_OK) return fail(st);
+            la_on_panel = true;
+            la_split = false;
+            ctx->ls = S0;
+        }
+        if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
     }
     ctx->ls = S0;
     ctx->reserve_now = 0;

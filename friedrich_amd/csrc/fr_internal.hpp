@@ -312,6 +312,7 @@ struct GemmDesc {
     int64_t own_nb = 1, own_col0 = 0;
     // batched launch: `batch` independent problems of the same shape, operands `batch_*` elements apart
     int64_t batch = 1, batch_a = 0, batch_b = 0, batch_c = 0, batch_d = 0;
+    bool whole_chip = false;  // ignore the XCD reservation for this launch (a panel-stream product while no diagonal-block kernel runs)
     int tri = 0;  // triangular operands: see GemmArgs::tri (gemm_tile.hpp)
     // tiles claimed in dispatch order instead of dealt per XCD: for launches whose tiles differ in length (tri), where equal
     // tile counts per XCD are unequal work

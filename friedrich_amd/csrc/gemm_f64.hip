@@ -323,7 +323,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     // workgroups pay while the large tiles would not fill those CUs either -- with 1 XCD and small tiles for up to 64 large
     // ones the fit at N = 8192 went from 9.1 to 10.2 ms)
     int64_t small_max = ctx->small_tiles;
-    if (ctx->reserve_now && d.batch <= 1 && ctx->ls == ctx->stream2 && small_max > 32 * ctx->reserve_now) small_max = 32 * ctx->reserve_now;
+    if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip && ctx->ls == ctx->stream2 && small_max > 32 * ctx->reserve_now) small_max = 32 * ctx->reserve_now;
     const bool small = small_max > 0 && !d.lower && !d.tri && d.M > BMS && d.D != d.B /* in place over op(B) needs ONE tile row */ &&
                        g.tiles_m * g.tiles_n * (d.batch > 1 ? d.batch : 1) <= small_max;
     if (small) g.tiles_m = (d.M + BMS - 1) / BMS;
@@ -358,7 +358,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.nres = ctx->reserve_now;
     g.epoch = ctx->panel_epoch;
     g.tri = d.tri;
-    if (ctx->reserve_now && d.batch <= 1) {
+    if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip) {
         if (ctx->ls == ctx->stream2) {
             if (!d.lower) g.place = 2;
         } else {
