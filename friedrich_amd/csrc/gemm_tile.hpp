@@ -405,6 +405,13 @@ __device__ __forceinline__ void store_tile_s(double* __restrict__ S, int t, cons
     }
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the global loads
+// that were issued precisely in order to stay in flight across the barrier.
+__device__ __forceinline__ void lds_only_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <bool A_KMAJ, bool B_KMAJ>
 __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds, const int64_t m0, const int64_t n0)
 {
@@ -423,28 +430,27 @@ __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds
     const double* pb = tile_thread_base<B_KMAJ>(g.B, g.ldb, n0, t);
     const int64_t step_b = B_KMAJ ? BK : BK * g.ldb;
     constexpr int STAGE = TILE_A_S + TILE_ELEMS;
-    double ra[2], rb[8];
-    if (nk > 0) {
-        load_tile_s<A_KMAJ>(g.A, g.lda, m0, g.M, 0, g.K, t, ra);
-        if (b_fast && nk_full > 0)
-            load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
+    // The loads run TWO K-steps ahead of the MFMAs (registers: the slice for step kt + 1 waits to be stored, the one for
+    // kt + 2 is in flight): these launches have one workgroup per CU and 16 MFMAs per wave and K-step, so a K-step costs a
+    // memory round trip unless two are outstanding.
+    auto load_slice = [&](int64_t kt, double (&ra)[2], double (&rb)[8]) {
+        load_tile_s<A_KMAJ>(g.A, g.lda, m0, g.M, kt * BK, g.K, t, ra);
+        if (b_fast && kt < nk_full)
+            load_tile_fast<B_KMAJ>(pb + kt * step_b, g.ldb, rb);
         else
-            load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, 0, g.K, t, rb);
-        store_tile_s<A_KMAJ>(lds, t, ra);
-        store_tile<B_KMAJ>(lds + TILE_A_S, t, rb);
+            load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, kt * BK, g.K, t, rb);
+    };
+    double ra1[2], rb1[8], ra2[2], rb2[8];
+    if (nk > 0) {
+        load_slice(0, ra1, rb1);
+        store_tile_s<A_KMAJ>(lds, t, ra1);
+        store_tile<B_KMAJ>(lds + TILE_A_S, t, rb1);
+        if (nk > 1) load_slice(1, ra1, rb1);
     }
     __syncthreads();
     int cur = 0;
     for (int64_t kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            pb += step_b;
-            load_tile_s<A_KMAJ>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, t, ra);
-            if (b_fast && (kt + 1) < nk_full)
-                load_tile_fast<B_KMAJ>(pb, g.ldb, rb);
-            else
-                load_tile<B_KMAJ>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, t, rb);
-        }
+        if (kt + 2 < nk) load_slice(kt + 2, ra2, rb2);
         const double* As = lds + cur * STAGE;
         const double* Bs = As + TILE_A_S;
 #pragma unroll
@@ -462,13 +468,17 @@ __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds
                 for (int mt = 0; mt < 2; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
         }
-        if (more) {
+        if (kt + 1 < nk) {
             double* An = lds + (cur ^ 1) * STAGE;
-            store_tile_s<A_KMAJ>(An, t, ra);
-            store_tile<B_KMAJ>(An + TILE_A_S, t, rb);
+            store_tile_s<A_KMAJ>(An, t, ra1);
+            store_tile<B_KMAJ>(An + TILE_A_S, t, rb1);
         }
-        __syncthreads();
+        lds_only_barrier();  // (the slice in flight stays in flight)
         cur ^= 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra1[i] = ra2[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb1[i] = rb2[i];
     }
     // epilogue: register r of tile (nt, mt) holds D[m0 + 16 mt + (lane & 15)][n0 + 32 wn + 16 nt + (lane >> 4) + 4 r];
     // all 16 values of C are loaded before the first store (D may alias Cin: one round trip, not sixteen)
