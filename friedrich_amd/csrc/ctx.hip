@@ -429,6 +429,9 @@ void fr_ctx_destroy(fr_ctx* ctx)
         (void)hipStreamSynchronize(ctx->stream3);
         (void)hipStreamDestroy(ctx->stream3);
     }
+    for (auto& kind : ctx->ev_ring)
+        for (hipEvent_t e : kind)
+            if (e) (void)hipEventDestroy(e);
     if (ctx->ev_bulk) (void)hipEventDestroy(ctx->ev_bulk);
     if (ctx->ev_cols) (void)hipEventDestroy(ctx->ev_cols);
     if (ctx->stream2) {
