@@ -253,6 +253,19 @@ int Staged::commit()
     // A persistent solve launched since the last status check may have given up on a hand-off: the caller must learn that
     // BEFORE its memory is overwritten with a partial result (the entry point then repeats the work from the caller's intact
     // operand, solve_retry) -- and also when the destination is device memory, where there is otherwise nothing to wait for.
+    const bool to_host = owns && host && rows > 0 && cols > 0 && !is_device_ptr(host);
+    if (ctx->persistent_pending && to_host) {
+        // one synchronisation instead of two: the result travels to the pinned bounce buffer first, the status is read, and
+        // only then does the CPU copy it into the caller's memory
+        double* pin = (double*)pinned_get(ctx, sizeof(double) * (size_t)rows * (size_t)cols);
+        if (pin) {
+            FR_HIP(ctx, hipMemcpy2DAsync(pin, sizeof(double) * rows, dev, sizeof(double) * ld, sizeof(double) * rows, cols, hipMemcpyDeviceToHost, ctx->stream));
+            FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            FR_TRY(check_status_word(ctx));
+            for (int64_t j = 0; j < cols; ++j) memcpy(host + j * host_ld, pin + j * rows, sizeof(double) * (size_t)rows);
+            return FR_OK;
+        }
+    }
     if (ctx->persistent_pending) {
         FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         FR_TRY(check_status_word(ctx));

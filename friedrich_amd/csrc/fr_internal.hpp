@@ -180,6 +180,10 @@ struct fr_chol {
     int64_t targets_n = -1;   // rows the targets were set for (-1: never)
     int64_t targets_cap = 0;
     uint64_t gen = 1, alpha_gen = 0;
+    // result of the zero-diagonal check of the checked solves (mod.rs:203, 263, 345), valid for generation diag_gen: the factor does
+    // not change between two predicts, so the check (a launch, a read-back, a synchronisation) runs once per factor
+    uint64_t diag_gen = 0;
+    bool diag_zero = false;
     // host mirror of info after the last factorisation
     int64_t fail_col = -1;
     int64_t n_subst = 0;

@@ -61,12 +61,16 @@ static int init_with_prior(fr_ctx* ctx, double* out_dev, const double* prior_q, 
 static int zero_diag_status(fr_chol* c, const char* what)
 {
     fr_ctx* ctx = c->ctx;
-    FR_HIP(ctx, hipMemsetAsync(c->info + 2, 0, sizeof(int64_t), ctx->stream));
-    FR_TRY(launch_diag_check_zero(ctx, c->A, c->n, c->ld_a, c->info + 2));
-    int64_t flag = 0;
-    FR_HIP(ctx, hipMemcpyAsync(&flag, c->info + 2, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (flag) return set_err(ctx, FR_SINGULAR_SOLVE, "%s : solve failed", what);
+    if (c->diag_gen != c->gen) {
+        FR_HIP(ctx, hipMemsetAsync(c->info + 2, 0, sizeof(int64_t), ctx->stream));
+        FR_TRY(launch_diag_check_zero(ctx, c->A, c->n, c->ld_a, c->info + 2));
+        int64_t flag = 0;
+        FR_HIP(ctx, hipMemcpyAsync(&flag, c->info + 2, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        c->diag_zero = flag != 0;
+        c->diag_gen = c->gen;
+    }
+    if (c->diag_zero) return set_err(ctx, FR_SINGULAR_SOLVE, "%s : solve failed", what);
     return FR_OK;
 }
 
