@@ -390,6 +390,10 @@ int fr_ctx_create(fr_ctx** out, int device)
     if (const char* e = getenv("FRIEDRICH_AMD_TEST_FORCE_SOLVE_TIMEOUT")) ctx->test_force_timeout = e[0] == '1';
     if (const char* e = getenv("FRIEDRICH_AMD_TEST_MAX_WORKGROUPS")) ctx->test_max_wgs = atoi(e);
     if (const char* e = getenv("FRIEDRICH_AMD_SMALL_TILES")) ctx->small_tiles = atoi(e);
+    if (const char* e = getenv("FRIEDRICH_AMD_DIST_SCHEDULE")) {  // operator override of the sharded schedule (0, 1, 2) without touching the host program
+        const int v = atoi(e);
+        if (v >= 0 && v <= 2) ctx->dist_schedule = v;
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return FR_HIP_ERROR;
