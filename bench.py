@@ -168,7 +168,7 @@ def main():
     ctx.set_option("nb", args.nb)
     if args.dist_schedule >= 0:
         ctx.set_option("dist_schedule", args.dist_schedule)
-    dist_sched = args.dist_schedule if args.dist_schedule >= 0 else 2
+    dist_sched = args.dist_schedule if args.dist_schedule >= 0 else int(os.environ.get("FRIEDRICH_AMD_DIST_SCHEDULE", "2"))
     nb_eff = args.nb if args.nb > 0 else (1024 if (world == 1 and args.n >= 24576) else 512)
     if use_dist:
         ids = [ctx.comm_unique_id() if rank == 0 else None]
