@@ -45,7 +45,7 @@ constexpr int SB = 32;   // sub-block
 constexpr int SBE = SB * SB;
 constexpr int PT = 512;  // 8 waves; <= 128 VGPRs so that they fit beside ONE resident GEMM workgroup
 constexpr int NSLOT = 10;
-constexpr size_t POTF2_LDS = (size_t)NSLOT * SBE * sizeof(double) + 16;  // + the column counter of the panel wave
+constexpr size_t POTF2_LDS = (size_t)NSLOT * SBE * sizeof(double) + 16 + SB * sizeof(double);  // + the column counter of the panel wave + 32 dummy words (see f_step)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every
 // outstanding factor-column store to be acknowledged by memory (microseconds under GEMM load).
@@ -132,6 +132,7 @@ __device__ __forceinline__ void col_load(ColBcast& cb, const double* bufh)
 struct FState {
     double* gptr;       // &A[row r, current column]
     double* cptr;       // &image[r]: where the owner half writes its element of the current column
+    double* dummy;      // a word of this lane's own: where the OTHER half's lanes write instead (no branch in the step)
     const double* bufh; // &image[16 h]: base of this lane's broadcast reads
     int* flag;          // LDS counter: number of factor columns published so far (all stages)
     int flag_base;      // 32 b
@@ -195,12 +196,12 @@ __device__ __forceinline__ void pivot_select(const FState& st, double d, int j, 
     excmask |= bad ? (1u << j) : 0u;
 }
 
-// pairs P .. of step J: a(r, c) -= L(r, J) L(c, J) for the lane's slots.  Slots whose column is already final are dead
+// pairs P .. P_END - 1 of step J: a(r, c) -= L(r, J) L(c, J) for the lane's slots.  Slots whose column is already final are dead
 // registers in this routine: they are updated along with the others (no predicate).
-template <int J, int P>
+template <int J, int P, int P_END>
 __device__ __forceinline__ void f_pairs(double (&a)[HB], double l, const ColBcast& cb)
 {
-    if constexpr (P < HB / 2) {
+    if constexpr (P < P_END) {
         if constexpr (2 * P >= first_live_slot(J)) {
             a[2 * P] = __builtin_fma(-l, cb.v[P].x, a[2 * P]);
             pin(a[2 * P]);
@@ -209,15 +210,23 @@ __device__ __forceinline__ void f_pairs(double (&a)[HB], double l, const ColBcas
             a[2 * P + 1] = __builtin_fma(-l, cb.v[P].y, a[2 * P + 1]);
             pin(a[2 * P + 1]);
         }
-        f_pairs<J, P + 1>(a, l, cb);
+        f_pairs<J, P + 1, P_END>(a, l, cb);
     }
 }
 
 // one elimination step; J is a compile-time constant so that every register index and lane select is static
 // (template recursion instead of `#pragma unroll`: the body is beyond clang's pragma-unroll budget).
 // d = the diagonal value of column J, ip = its reciprocal pivot after the pivot rule.
-template <bool M3, int J>
-__device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double d, double ip, unsigned& excmask)
+//
+// The step is bound by INSTRUCTION ISSUE (round 3: ~100 instructions per column at ~5.6 cycles each on a SIMD shared with an
+// update wave -- not by the LDS round trip of the column broadcast, which was tested), so what does not have to happen per
+// column does not: the factor's columns are no longer stored to global memory here (the stored diagonal sqrt(d) with its
+// Heron correction, the pivot-exception selects and a predicated store were ~16 instructions of every step) -- the step only
+// records d in lane J of a register pair and factor_subblock writes the whole 32 x 32 sub-block from its LDS image afterwards,
+// every lane computing ITS row's diagonal entry once; the image write is branch-free (the half that does not own the column
+// writes to a dummy word); FULL blocks (n = 128) drop the padding predicates.
+template <bool M3, bool FULL, int J>
+__device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double d, double ip, unsigned& excmask, int& dlo, int& dhi)
 {
     constexpr int hJ = J / HB, kJ = J % HB;
     constexpr int hN = (J + 1) / HB, kN = (J + 1) % HB;
@@ -237,8 +246,8 @@ __device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double d, do
     __builtin_amdgcn_sched_barrier(0);
     // ---- L(r, J) in both halves.  Padding rows / columns (block smaller than 128) are forced to stay the identity:
     // 0 * inf = NaN would otherwise leak from an overflowing substituted factor into the log
-    const bool live = st.row_ok && J < st.ncols_ok;
-    const double l_own = (st.r > J && live) ? q : 0.0;
+    const bool keep = FULL ? (st.r > J) : (st.r > J && st.row_ok && J < st.ncols_ok);
+    const double l_own = keep ? q : 0.0;
     const double l = bcast_half<hJ>(l_own);
     if constexpr (next && hN != hJ) {  // the pivot lane sits in the other half (J = 15): it needs the exchange first
         double dn = a[kN];
@@ -248,10 +257,17 @@ __device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double d, do
     }
     if constexpr (next && 1 < NST) chain_stage<M3, 1>(ch);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- the LDS image of column J (owner half): 1 / pivot on the diagonal, L below, zeros above; then the counter
-    if (st.h == hJ) {
-        st.cptr[SB * J] = (st.r == J) ? ip : l_own;
+    // ---- the LDS image of column J: 1 / pivot on the diagonal, L below, zeros above (the owner half into the image, the other
+    // half into its dummy words: no branch); then the counter.  d_J goes into lane J of (dlo, dhi) for the store pass.
+    {
+        double* wp = (st.h == hJ) ? st.cptr + SB * J : st.dummy;
+        *wp = (st.r == J) ? ip : l_own;
         *st.flag = st.flag_base + J + 1;  // after the column in this wave's LDS order: the solves of P1 may consume it
+    }
+    if constexpr (!M3) {
+        // (v_writelane_b32: lane J of the pair takes the wave-uniform d; inline asm -- this hipcc has no builtin for it)
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dlo) : "s"(__builtin_amdgcn_readfirstlane(__double2loint(d))), "n"(J));
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dhi) : "s"(__builtin_amdgcn_readfirstlane(__double2hiint(d))), "n"(J));
     }
     if constexpr (next && 2 < NST) chain_stage<M3, 2>(ch);
     __builtin_amdgcn_sched_barrier(0);
@@ -259,34 +275,26 @@ __device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double d, do
     if constexpr (!M3) col_load<J, 0>(cb, st.bufh);
     if constexpr (next && 3 < NST) chain_stage<M3, 3>(ch);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- off the chain: the diagonal entry sqrt(d) = d ip with one Heron correction, and the column to global memory
     if constexpr (!M3) {
-        double pq = d * ip;
         if constexpr (next && 4 < NST) chain_stage<M3, 4>(ch);
-        __builtin_amdgcn_sched_barrier(0);
-        const double pe = __builtin_fma(-pq, pq, d);
         if constexpr (next && 5 < NST) chain_stage<M3, 5>(ch);
         __builtin_amdgcn_sched_barrier(0);
-        pq = __builtin_fma(0.5 * ip, pe, pq);
-        pq = (d == 0.0) ? 0.0 : pq;                            // plain-sqrt mode, d == 0
-        pq = ((excmask >> J) & 1u) ? st.p_exc : pq;            // substituted / failed pivot
-        if (st.h == hJ && st.r >= J && live) *st.gptr = (st.r == J) ? pq : q;
-        st.gptr += st.lda;
+        f_pairs<J, 0, HB / 4>(a, l, cb);
         if constexpr (next && 6 < NST) chain_stage<M3, 6>(ch);
-        if constexpr (next && 7 < NST) chain_stage<M3, 7>(ch);
         __builtin_amdgcn_sched_barrier(0);
-        f_pairs<J, 0>(a, l, cb);
+        f_pairs<J, HB / 4, HB / 2>(a, l, cb);
+        if constexpr (next && 7 < NST) chain_stage<M3, 7>(ch);
     } else {
         if constexpr (next && 4 < NST) chain_stage<M3, 4>(ch);
     }
     if constexpr (next) {
         double ipn = ch.r;
         if constexpr (!M3) pivot_select(st, ch.d, J + 1, ipn, excmask);
-        f_step<M3, J + 1>(a, st, ch.d, ipn, excmask);
+        f_step<M3, FULL, J + 1>(a, st, ch.d, ipn, excmask, dlo, dhi);
     }
 }
 
-template <bool M3>
+template <bool M3, bool FULL>
 __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, double* __restrict__ A, int64_t lda, int n,
                                                 int64_t col0, int mode, double sub, int64_t* __restrict__ info)
 {
@@ -298,6 +306,7 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, do
     st.h = lane >> 5;
     double* image = lds + slot_of(b, b);
     st.cptr = image + st.r;
+    st.dummy = lds + NSLOT * SBE + 2 + st.r;  // behind the counter's 16 bytes
     st.bufh = image + HB * st.h;
     st.gptr = A + (SB * b + st.r) + (int64_t)(SB * b) * lda;
     st.row_ok = SB * b + st.r < n;
@@ -323,7 +332,28 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, do
         sqrt_rsqrt(d0, p, ip);
         pivot_select(st, d0, 0, ip, excmask);
     }
-    f_step<M3, 0>(a, st, d0, ip, excmask);
+    int dlo = 0, dhi = 0;  // lane J: the diagonal value d_J the pivot of column J was taken from
+    f_step<M3, FULL, 0>(a, st, d0, ip, excmask, dlo, dhi);
+    if constexpr (!M3) {
+        // ---- the factored sub-block to global memory, from its image (L below the diagonal, 1 / pivot on it): every lane
+        // forms the diagonal entry of ITS row, sqrt(d) = d ip with one Heron correction (the pivot rule's replacement where
+        // it fired), and stores its 16 slots of the lower triangle.  (The image is overwritten in P2: this runs in front of
+        // the stage's first barrier; the update waves are still a column behind.)
+        const double dr = bcast_half<0>(__hiloint2double(dhi, dlo));  // d of row r (recorded in lane r of the lower half)
+        const double ipr = image[st.r + SB * st.r];
+        double pq = dr * ipr;
+        pq = __builtin_fma(0.5 * ipr, __builtin_fma(-pq, pq, dr), pq);
+        pq = (dr == 0.0) ? 0.0 : pq;                        // plain-sqrt mode, d == 0
+        pq = ((excmask >> st.r) & 1u) ? st.p_exc : pq;      // substituted / failed pivot
+        double vals[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) vals[k] = image[st.r + SB * (HB * st.h + k)];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const int c = HB * st.h + k;
+            if (st.r >= c && st.row_ok && c < st.ncols_ok) st.gptr[(int64_t)c * lda] = (st.r == c) ? pq : vals[k];
+        }
+    }
     if (st.ncols_ok < SB) excmask &= (1u << (st.ncols_ok > 0 ? st.ncols_ok : 0)) - 1u;
     if (excmask != 0 && lane == 0) {  // the log: substituted columns in order, or the first failing column
         if (substitute) {
@@ -459,9 +489,11 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
         __builtin_amdgcn_s_setprio(3);
         for (int b = 0; b < nblk; ++b) {
             if (m3)
-                factor_subblock<true>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+                factor_subblock<true, false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+            else if (n == PB)
+                factor_subblock<false, true>(lds, b, lane, A, lda, n, col0, mode, sub, info);
             else
-                factor_subblock<false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+                factor_subblock<false, false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
             lds_barrier();
             lds_barrier();
             lds_barrier();
