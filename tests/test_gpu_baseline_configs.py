@@ -56,6 +56,29 @@ def test_full_size_fit_properties(ctx, name, n, d, kernel_name, eps):
     err = float(torch.linalg.norm(KZ - V) / torch.linalg.norm(V))
     assert err < 1e-8, err  # north_star: <= 1e-8 relative error
 
+    # the three solve paths agree at full size: 8 columns went through the matrix-core persistent kernel (K9: one product per
+    # chain step, payload polling; more blocks than CUs at N = 65536); column 0 alone takes the single-column kernels (K8), 40
+    # columns the column groups of the half-tile kernel, and with option trsv = 0 the recursion of GEMM launches
+    Z1 = V[:, :1].t().clone().t()
+    W40 = _col_major(torch, np.random.default_rng(3).standard_normal((n, 40)), dev)
+    W40[:, :nprobe] = V
+    Z40 = W40.t().clone().t()
+    Zr = V.t().clone().t()
+    torch.cuda.synchronize()
+    chol.solve(Z1)
+    chol.solve(Z40)
+    ctx.set_option("trsv", 0)
+    try:
+        chol.solve(Zr)
+    finally:
+        ctx.set_option("trsv", 1)
+    ctx.synchronize()
+    zs = float(torch.max(torch.abs(Z)))
+    assert float(torch.max(torch.abs(Z1 - Z[:, :1]))) / zs < 1e-10
+    assert float(torch.max(torch.abs(Z40[:, :nprobe] - Z))) / zs < 1e-10
+    assert float(torch.max(torch.abs(Zr - Z))) / zs < 1e-10
+    assert ctx.counter("solve_retries") == 0
+
     # the two halves of solve() agree with each other: with U = L^-1 V,  v^T K^-1 v = u^T u  for every probe column
     U = V.t().clone().t()
     torch.cuda.synchronize()
