@@ -202,7 +202,8 @@ int fr_chol_add_rows(fr_chol* chol, const fr_kprog* kernel, const double* Xall, 
 /* n, capacity (row capacity of the device buffers), d, number of substituted pivots, failing column (-1) */
 int fr_chol_info(const fr_chol* chol, int64_t* n, int64_t* capacity, int64_t* d, int64_t* n_subst,
                  int64_t* fail_col);
-/* Conditioning report of the last factorisation: *max_estimate = the largest estimate max|W_ij| * max L_jj over the
+/* Conditioning report of the factor as it stands (refreshed by every way a factor comes into being or changes: from_inputs,
+ * refactor, from_matrix, upload_l, add_rows; not available -- 0 -- for sharded factors): *max_estimate = the largest estimate max|W_ij| * max L_jj over the
  * 128 x 128 diagonal blocks (W = explicit inverse of the block), *refined = 1 when the handle applies a step of iterative
  * refinement behind every product with an inverse block (option "refine": -1 automatic, the default: on when an estimate
  * exceeds "refine_threshold", 30).  No reference counterpart: nalgebra substitutes, which needs no such step. */
