@@ -101,7 +101,7 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
  *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
  *   "xcd_reserve"    -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
- *                    the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, nb <= 512 only: DESIGN.md
+ *                    the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, 4 below 4096, nb <= 512 only: DESIGN.md
  *                    section 5); 0: never; 1..4: that many XCDs for the whole factorisation
  *   "dist_schedule"  sharded (multi-GPU) factorisation, how a panel step travels: 0 = the owner solves the whole panel, one
  *                    broadcast; 1 = diagonal block broadcast, rows below scattered / solved per rank / all-gathered;
