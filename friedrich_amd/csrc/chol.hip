@@ -952,6 +952,12 @@ static void chol_release(fr_chol* c)
     c->dinvt = nullptr;
     c->dinvt_cap = 0;
     c->ut_gen = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (c->mchain[i]) (void)hipFree(c->mchain[i]);
+        c->mchain[i] = nullptr;
+        c->mchain_cap[i] = 0;
+        c->mchain_gen[i] = 0;
+    }
     if (c->yt) (void)hipFree(c->yt);
     if (c->alpha) (void)hipFree(c->alpha);
     c->yt = c->alpha = nullptr;

@@ -93,6 +93,7 @@ struct fr_ctx {
     // ---- state ----
     bool potf2_lds_set = false;  // dynamic-LDS attributes applied on this device (per context = per device)
     bool trsv_lds_set = false;
+    bool trsmn_lds_set = false;
     bool prior_lds_set = false;
     // profiling
     bool prof = false;
@@ -167,6 +168,11 @@ struct fr_chol {
     double* dinvt = nullptr;
     int64_t dinvt_cap = 0;
     uint64_t ut_gen = 0;
+    // K9's chain products M_b = W_b L[b, b - 1] (forward, [0]) and W_b^T L[b + 1, b]^T (backward, [1]), one 128 x 128 block per
+    // block row, valid for generation mchain_gen (trsm_narrow.hip: ensure_chain_products)
+    double* mchain[2] = {nullptr, nullptr};
+    int64_t mchain_cap[2] = {0, 0};
+    uint64_t mchain_gen[2] = {0, 0};
     // conditioning estimates of the 128 x 128 diagonal blocks (device, one double per block), their maximum after the
     // last factorisation, and whether this handle applies iterative refinement (fr_ctx::refine)
     double* cest = nullptr;

@@ -12,10 +12,10 @@
 // in it (and the transposed inverse blocks next to the inverse blocks), rebuilt lazily after the factor changed
 // (~2 ms at n = 32768).  With it "L^T x = b" reads rows-along-lanes exactly like "L x = b".
 //
-// Hand-off of a solution block (128 x 16 doubles): write-through (sc1) stores -> every wave drains -> barrier -> flag
-// (tagged 8-byte granules as in trsv.hip, measured on this payload of 16 KiB: 2.43 -> 3.83 ms per direction at n = 32768);
-// the consumer polls the flag and reads the block with sc1 loads (cdna_hip_programming.md Guideline 16, R1).  Every
-// spin is bounded (handoff.hpp).
+// Hand-off of a solution block (128 x 16 doubles).  Column-group kernel (m > 16): write-through (sc1) stores -> every wave
+// drains -> barrier -> flag; the consumer polls the flag and reads the block with sc1 loads (cdna_hip_programming.md
+// Guideline 16, R1).  Single-group kernel (m <= 16): the payload is its own flag (sentinel-filled buffer; see the kernel).
+// Every spin is bounded (handoff.hpp); a timed-out launch is repeated on the recursive path by the entry point (solve_retry).
 #include "fr_internal.hpp"
 #include "handoff.hpp"
 
@@ -32,6 +32,7 @@ struct TrsmnArgs {
     const double* A;    // factor buffer: lower triangle L; strict upper off-diagonal blocks hold L^T (backward)
     int64_t ld, n;
     const double* inv;  // inverse blocks (forward) or transposed inverse blocks (backward)
+    const double* mchain;  // single-group kernel: the chain products M_b = inv_b * (tile next to the diagonal), block b at b * 128 * 128
     double* B;          // n x m right-hand sides in, solutions out
     int64_t ldb;
     int m;
@@ -110,19 +111,6 @@ __device__ __forceinline__ Frag item_frag(const TrsmnArgs& a, int blk, int other
         f.kcols = oleft < NB ? (int)oleft : NB;
     }
     return f;
-}
-
-// solution block `blk` -> xs ([col][q]); false after a timeout.  ONE buffer: the barrier inside the wait also tells that
-// every wave is done with the block before.
-__device__ __forceinline__ bool fetch_block(const TrsmnArgs& a, int blk, double* xs, int t)
-{
-    if (!handoff_wait_ge<false>(a.flags + blk, 1, a.status)) return false;  // no acquire fence: sc1 stores, sc1 loads
-    const double* src = a.xg + (int64_t)blk * (NB * MR);
-#pragma unroll
-    for (int i = 0; i < (NB * MR) / NTH; ++i)
-        xs[t + NTH * i] = __hip_atomic_load((gdbl*)(src + t + NTH * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    return true;
 }
 
 // The kernel for TWO OR MORE column groups (m > 16): half-tile register buffers, one LDS buffer -- 128 VGPRs and 16 KiB, so two
@@ -239,194 +227,272 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArg
 // ---- one column group (m <= 16) ------------------------------------------------------------------------------------------
 // The solve is a chain of n / 128 hand-offs; what one step costs is what the whole solve costs.  Round 2's step was: flag poll,
 // payload fetch, the product with the neighbouring tile (1.7 us: 64 MFMAs per SIMD), a transposition through LDS, the closing
-// product with the inverse block (1.7 us), payload stores, their acknowledgement, the flag -- ~9 us.  Now:
+// product with the inverse block (1.7 us), payload stores, their acknowledgement, the flag -- ~9 us.  Now (timed with
+// s_memrealtime stamps per stage and per wave; the numbers are in DESIGN.md section 5):
 //   * the last dependency of block r is its NEIGHBOUR x_{r-1}; everything that does not need it is done before it arrives:
-//       t' = b_r - sum_{q < r-1} L[r, q] x_q  (as before, behind flags),   y' = W_r t',   M = W_r L[r, r-1]  (128^3 on the matrix
-//     core, while the workgroup would otherwise wait: the tile goes through LDS in eight 16-column chunks, and the accumulator
-//     layout of v_mfma_f64_16x16x4 is exactly the operand layout of the next product, so M never leaves the registers);
-//   * when x_{r-1} arrives ONE product is left on the chain:  x_r = y' - M x_{r-1};
-//   * x_{r-1} is awaited on the payload itself: the hand-off buffer is filled with a NaN bit pattern no computation produces
-//     before every launch, a lane polls its four doubles until none is the pattern (8-byte stores are single-copy atomic, each
-//     element is written once) -- no flag round trip, no acknowledgement wait on the producer's side.  Only the ONE workgroup
-//     whose last dependency is pending polls this way; the others wait for flags as before (the flag is still published,
-//     behind the acknowledged stores, off the critical path).
+//       t' = b_r - sum_{q < r-1} L[r, q] x_q,   y' = W_r t',   and   M_r = W_r L[r, r-1],
+//     the chain product: it depends on the factor only, so it is formed once per factor (ensure_chain_products: one batched
+//     128^3 product, cached like the transposed copy) and sits in LDS while the block is worked on;
+//   * when x_{r-1} arrives ONE product is left on the chain:  x_r = y' - M_r x_{r-1};
+//   * EVERY solution block is awaited on the payload itself: the hand-off buffer is filled with a NaN bit pattern no
+//     computation produces before every launch, a lane polls its two 16-byte pieces until no double is the pattern (aligned
+//     8-byte halves are single-copy atomic, each element is written once) -- no flag, no acknowledgement wait on the
+//     producer's side, and the block of the NEXT dependency is fetched while the current one is multiplied (a flag would have
+//     to be seen first: two dependent round trips per dependency, which is what bounded every block's progress before);
+//   * the two waits on the chain (x_{r-2}: the last tile and the closing product follow it; x_{r-1}) poll with several samples
+//     in flight;
+//   * a block travels as 128 full cache lines (see below).
 constexpr unsigned SENT32 = 0x7FF7A5A5u;  // both halves: hipMemsetD32 fills the payload with the (NaN) double 0x7FF7A5A57FF7A5A5
 __device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == 0x7FF7A5A57FF7A5A5ull; }
 
-__device__ __forceinline__ void mma_block(const double (&buf)[32], const double* xs, int l15, int lq, d4n_t& acc)
+// ---- the payload of a solution block, awaited on the data itself ------------------------------------------------------------
+// A block travels as 128 full cache lines ([col k][16 right-hand sides], 16 KiB): the producer's waves transpose their 16 rows
+// through LDS and write them with 16-byte stores (two instructions of 1 KiB per wave; the accumulator layout would scatter 512
+// quarter-lines per workgroup, and the consumer's barrier waits for the LAST of them); a consumer lane owns two 16-byte pieces
+// (doubles 2 t, 2 t + 1 and 1024 + 2 t, 1024 + 2 t + 1).  Volatile accesses: system-scope (sc0 sc1) loads and write-through
+// stores, which need no fence (Guideline 16, R1); every double is written once and none can be the sentinel.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) volatile d2_t gvd2;
+struct Piece {
+    d2_t lo, hi;
+};
+// blockbase: the block's 16 KiB (wave-uniform: a scalar base, the lane's offset is one 32-bit register)
+__device__ __forceinline__ void issue_payload(const double* blockbase, int t, Piece& v)
 {
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        const double xf = xs[(4 * u + lq) * MR + l15];  // element (k = 4 u + lq, q = l15)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, buf[u], acc, 0, 0, 0);
+    const gvd2* p = (const gvd2*)blockbase;
+    v.lo = p[t];
+    v.hi = p[NTH + t];
+}
+__device__ __forceinline__ bool payload_complete(const Piece& v)
+{
+    return !(is_sentinel(v.lo.x) || is_sentinel(v.lo.y) || is_sentinel(v.hi.x) || is_sentinel(v.hi.y));
+}
+__device__ __forceinline__ void payload_to_lds(double* xb, int t, const Piece& v)
+{
+    *reinterpret_cast<d2_t*>(xb + 2 * t) = v.lo;
+    *reinterpret_cast<d2_t*>(xb + 2 * NTH + 2 * t) = v.hi;
+}
+__device__ __forceinline__ bool handoff_dead(const TrsmnArgs& a, unsigned long long t0)
+{
+    const bool dead = __hip_atomic_load((hgu32*)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+    if (dead || wall_clock64() - t0 > HANDOFF_TIMEOUT_TICKS) {
+        __hip_atomic_store((hgu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return true;
+    }
+    return false;
+}
+// v: a sample already issued (possibly incomplete).  Returns 0 after a timeout (per lane: combine with a barrier vote).
+__device__ __forceinline__ int await_payload(const TrsmnArgs& a, const double* src, int t, Piece& v)
+{
+    if (payload_complete(v)) return 1;
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    for (;;) {
+        issue_payload(src, t, v);
+        if (payload_complete(v)) return 1;
+        if ((++spins & 127u) == 0 && handoff_dead(a, t0)) return 0;
     }
 }
-
-// the payload of block `blk`, awaited on the data itself -> xs ([col][q]); false after a timeout
-__device__ __forceinline__ bool poll_payload(const TrsmnArgs& a, int blk, double* xs, int t)
+// The same with DEPTH samples in flight: the memory is sampled DEPTH times per round trip (a poll's round trip is 1.5 - 2 us
+// while the chip streams the factor -- scripts/handoff_probe.hip -- and a serial poll loop adds on average a whole round trip to
+// the hand-off: half of one until the next sample is taken, half for its way back; and the barrier behind the wait makes that
+// the LATEST of eight waves).  For the two hand-offs on the chain.
+template <int DEPTH>
+__device__ __forceinline__ int await_payload_pipelined(const TrsmnArgs& a, const double* src, int t, Piece& v)
 {
-    const double* src = a.xg + (int64_t)blk * (NB * MR);
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
-    unsigned pending = 0xFu;
-    int ok = 1;
-    unsigned long long t0 = 0;
+    if (payload_complete(v)) return 1;
+    Piece ring[DEPTH];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) issue_payload(src, t, ring[i]);
+    const unsigned long long t0 = wall_clock64();
     unsigned spins = 0;
     for (;;) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (pending & (1u << i)) {
-                v[i] = __hip_atomic_load((gdbl*)(src + t + NTH * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!is_sentinel(v[i])) pending &= ~(1u << i);
+        for (int i = 0; i < DEPTH; ++i) {
+            if (payload_complete(ring[i])) {
+                v = ring[i];
+                return 1;
             }
-        if (!pending) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (spins == 0) t0 = wall_clock64();
-        if ((++spins & 255u) == 0) {
-            const bool dead = __hip_atomic_load((hgu32*)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-            if (dead || wall_clock64() - t0 > HANDOFF_TIMEOUT_TICKS) {
-                __hip_atomic_store((hgu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                ok = 0;
-                break;
-            }
+            issue_payload(src, t, ring[i]);
         }
+        if ((++spins & 63u) == 0 && handoff_dead(a, t0)) return 0;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xs[t + NTH * i] = v[i];
-    return __builtin_amdgcn_readfirstlane(__syncthreads_and(ok)) != 0;
 }
+
+// LDS (dynamic, 160 KiB = all of a CU's): two solution-block buffers and the block's chain product M, stored fragment-major
+// (wave w, slot u, lane: the lane's MFMA operand (m = 16 w + l15, k = 4 u + lq) -- consecutive lanes, consecutive words).  M in
+// LDS rather than in 64 registers per lane: the registers hold tile quarters in flight instead (the solve is latency-bound
+// on exactly those), and the end of the row can hold the last tile AND the inverse block before the solution block it waits
+// for arrives.
+constexpr size_t TRSMN_LDS = sizeof(double) * (2 * NB * MR + NB * NB);
 
 __global__ __launch_bounds__(NTH, 2) void trsm_narrow_kernel(const TrsmnArgs a0)
 {
-    __shared__ double xs[2][NB * MR];
-    __shared__ double tv[NB * MR];
+    extern __shared__ __attribute__((aligned(16))) double k9_lds[];
+    double* const xs0 = k9_lds;
+    double* const xs1 = k9_lds + NB * MR;
+    double* const Ml = k9_lds + 2 * NB * MR;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int last = a0.nblk - 1;
     TrsmnArgs a = a0;  // (one column group: blockIdx.y == 0)
-    __shared__ int claim_slot;
+    // A timed-out wait raises the host-visible status word and goes on with whatever it has: every later wait then gives up
+    // within a few polls, the launch drains, and the host repeats the solve on the recursive path (solve_retry) -- no vote,
+    // no early exit.
 #pragma nounroll
     for (;;) {
-        const int bi = claim_block(a.tickets, a.nblk, &claim_slot);
+        // claim (the slot aliases the first solution-block buffer: free between blocks; the second barrier keeps a fast wave's
+        // next write to the buffer behind everybody's read of the slot)
+        if (t == 0) {
+            const unsigned i = __hip_atomic_fetch_add((hgu32*)a.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<int*>(xs0) = i < (unsigned)a.nblk ? (int)i : -1;
+        }
+        __syncthreads();
+        const int bi = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(xs0));
+        __syncthreads();
         if (bi < 0) return;
         const int blk = a.bwd ? last - bi : bi;
         const int cnt = a.bwd ? last - blk : blk;  // dependencies: blocks dep(0) .. dep(cnt - 1), the neighbour last
         const int64_t b0 = (int64_t)blk * NB;
         const int64_t row = b0 + 16 * w + l15;
-        double bv[4];  // this lane's right-hand side entries: (row, q = lq + 4 i)
+        // the accumulator starts at -b (this lane's right-hand side entries (row, q = lq + 4 i)): after the tiles it holds
+        // -(b - sum L x) = -t'
+        d4n_t acc;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = (row < a.n && lq + 4 * i < a.m) ? a.B[row + (int64_t)(lq + 4 * i) * a.ldb] : 0.0;
-        // the inverse block's fragments stay in registers for the whole block
-        double Wf[32];
-        load_frag(item_frag(a, blk, 0, true), w, l15, lq, Wf);
-        // ---- M = W L[blk, neighbour], off the chain: the tile through LDS in 16-column chunks [k][16]
-        double Mf[32];
+        for (int i = 0; i < 4; ++i) acc[i] = (row < a.n && lq + 4 * i < a.m) ? -a.B[row + (int64_t)(lq + 4 * i) * a.ldb] : 0.0;
+        // ---- M = W L[blk, neighbour]: the chain product, one per block row of the factor (ensure_chain_products) -> LDS
         if (cnt > 0) {
-            const Frag f = item_frag(a, blk, a.bwd ? blk + 1 : blk - 1, false);
-            const int kk = t & 127, cc = t >> 7;
-            // address = one per-lane pointer + wave-uniform column offsets; the loads are unconditional (the addresses exist: see
-            // load_frag), what lies outside the valid extent of a last, partial block is replaced by zeros afterwards
-            const double* pl = f.base + kk + (int64_t)cc * f.stride;
-            auto load_chunk = [&](int j, double (&reg)[4]) {
+            Frag fm;
+            fm.base = a.mchain + (int64_t)blk * (NB * NB);
+            fm.stride = NB;
+            fm.mrows = fm.kcols = NB;  // (rows / columns outside a last, partial block: see ensure_chain_products)
+            double Mf[32];
+            load_frag(fm, w, l15, lq, Mf);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) reg[i] = pl[(int64_t)(16 * j + 4 * i) * f.stride];
-                if (f.mrows < NB || f.kcols < NB) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) reg[i] = (kk < f.mrows && 16 * j + cc + 4 * i < f.kcols) ? reg[i] : 0.0;
-                }
-            };
-            double cr[4];
-            load_chunk(0, cr);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xs[0][kk * MR + cc + 4 * i] = cr[i];
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j + 1 < 8) load_chunk(j + 1, cr);
-                d4n_t am = {0.0, 0.0, 0.0, 0.0};
-                mma_block(Wf, xs[j & 1], l15, lq, am);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) Mf[4 * j + i] = am[i];  // accumulator (m = l15, n = 16 j + lq + 4 i) == fragment slot u = 4 j + i
-                if (j + 1 < 8) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xs[(j + 1) & 1][kk * MR + cc + 4 * i] = cr[i];
-                }
-                __syncthreads();
-            }
+            for (int u = 0; u < 32; ++u) Ml[(w * 32 + u) * 64 + lane] = Mf[u];  // (read back by the same wave only)
         }
-        // ---- the dependencies in front of the neighbour: tiles in QUARTER-tile register buffers (16 rows x 32 columns, 8 doubles
-        //      per lane), the next quarter always in flight -- W and M hold 128 of the 256 registers
-        d4n_t acc = {0.0, 0.0, 0.0, 0.0};
-        if (cnt > 1) {
-            double Q0[8], Q1[8];
-            auto load_quarter = [&](const Frag& f, int Hq, double (&buf)[8]) {
-                const unsigned lane_off = (unsigned)(16 * w + l15) + (unsigned)lq * (unsigned)f.stride;
-                const double* base = f.base + (int64_t)(32 * Hq) * f.stride;
+        // ---- the items in front of the neighbour: the tiles L[blk, dep(it)], it < ndep, then the inverse block (operand t').
+        //      QUARTER-tile register buffers (16 rows x 32 columns, 8 doubles per lane), loaded three quarters ahead (48 KiB per
+        //      workgroup in flight: what the CU's share of the HBM rate needs at 2 us of latency); the solution block of the
+        //      NEXT item is already being fetched while this one is multiplied -- every block is awaited on its payload
+        //      (sentinel), so fetching ahead of time needs no flag
+        const int ndep = cnt > 0 ? cnt - 1 : 0;
+        auto dep_frag = [&](int it) { return item_frag(a, blk, a.bwd ? last - it : it, false); };
+        auto payload_of = [&](int it) { return a.xg + (int64_t)(a.bwd ? last - it : it) * (NB * MR); };
+        auto load_quarter = [&](const Frag& f, int Hq, double (&buf)[8]) {
+            const unsigned lane_off = (unsigned)(16 * w + l15) + (unsigned)lq * (unsigned)f.stride;
+            const double* base = f.base + (int64_t)(32 * Hq) * f.stride;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) buf[u] = (base + (int64_t)(4 * u) * f.stride)[lane_off];
-                if (f.mrows < NB || f.kcols < NB) {  // last block only: zeros outside the valid extent (the addresses exist)
-                    const bool mok = 16 * w + l15 < f.mrows;
+            for (int u = 0; u < 8; ++u) buf[u] = (base + (int64_t)(4 * u) * f.stride)[lane_off];
+            if (f.mrows < NB || f.kcols < NB) {  // last block only: zeros outside the valid extent (the addresses exist)
+                const bool mok = 16 * w + l15 < f.mrows;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) buf[u] = (mok && 32 * Hq + 4 * u + lq < f.kcols) ? buf[u] : 0.0;
-                }
-            };
-            auto mma_quarter = [&](const double (&buf)[8], int Hq) {
+                for (int u = 0; u < 8; ++u) buf[u] = (mok && 32 * Hq + 4 * u + lq < f.kcols) ? buf[u] : 0.0;
+            }
+        };
+        auto mma_quarter = [&](const double (&buf)[8], int Hq, const double* xb) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[0][(32 * Hq + 4 * u + lq) * MR + l15], buf[u], acc, 0, 0, 0);
-            };
-            load_quarter(item_frag(a, blk, a.bwd ? last : 0, false), 0, Q0);
-#pragma nounroll
-            for (int q = 0; q < cnt - 1; ++q) {
-                const int dep = a.bwd ? last - q : q;
-                const Frag f = item_frag(a, blk, dep, false);
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[(32 * Hq + 4 * u + lq) * MR + l15], buf[u], acc, 0, 0, 0);
+        };
+        {
+            double Q0[8], Q1[8], Q2[8], Q3[8];
+            Piece xv;
+            Frag f = dep_frag(0);
+            if (ndep > 0) {
+                issue_payload(payload_of(0), t, xv);
+                load_quarter(f, 0, Q0);
                 load_quarter(f, 1, Q1);
-                // (the barrier inside the wait: every wave is done with the block before; the dependency next to the neighbour is
-                // awaited on its payload as well -- its flag follows the payload by an acknowledgement round trip, and this
-                // block has y' = W t' to form between the two arrivals)
-                if (q == cnt - 2) {
-                    __syncthreads();
-                    if (!poll_payload(a, dep, xs[0], t)) return;
-                } else if (!fetch_block(a, dep, xs[0], t))
-                    return;
-                mma_quarter(Q0, 0);
-                load_quarter(f, 2, Q0);
-                mma_quarter(Q1, 1);
-                load_quarter(f, 3, Q1);
-                mma_quarter(Q0, 2);
-                if (q + 1 < cnt - 1) load_quarter(item_frag(a, blk, a.bwd ? last - q - 1 : q + 1, false), 0, Q0);
-                mma_quarter(Q1, 3);
+                load_quarter(f, 2, Q2);
             }
-        }
-        // ---- y' = W (b - acc): everything that does not need the neighbour
+            // steady part: every dependency but the last
+#pragma nounroll
+            for (int it = 0; it + 1 < ndep; ++it) {
+                double* xb = (it & 1) ? xs1 : xs0;  // (two buffers: the barrier of item it - 1 lies between the reads of item it - 2 and these writes)
+                await_payload(a, payload_of(it), t, xv);
+                payload_to_lds(xb, t, xv);
+                issue_payload(payload_of(it + 1), t, xv);
+                __syncthreads();
+                const Frag fn = dep_frag(it + 1);
+                load_quarter(f, 3, Q3);
+                mma_quarter(Q0, 0, xb);
+                load_quarter(fn, 0, Q0);
+                mma_quarter(Q1, 1, xb);
+                load_quarter(fn, 1, Q1);
+                mma_quarter(Q2, 2, xb);
+                load_quarter(fn, 2, Q2);
+                mma_quarter(Q3, 3, xb);
+                f = fn;
+            }
+            // the end of the row is on the chain (the last dependency arrives one step before the neighbour): its last quarter and
+            // the whole inverse block are in registers before it arrives
+            double W0[8], W1[8], W2[8], W3[8];
+            const Frag fw = item_frag(a, blk, 0, true);
+            if (ndep > 0) load_quarter(f, 3, Q3);
+            load_quarter(fw, 0, W0);
+            load_quarter(fw, 1, W1);
+            load_quarter(fw, 2, W2);
+            load_quarter(fw, 3, W3);
+            if (ndep > 0) {
+                double* xb = ((ndep - 1) & 1) ? xs1 : xs0;
+                await_payload_pipelined<2>(a, payload_of(ndep - 1), t, xv);
+                payload_to_lds(xb, t, xv);
+                __syncthreads();
+                mma_quarter(Q0, 0, xb);
+                mma_quarter(Q1, 1, xb);
+                mma_quarter(Q2, 2, xb);
+                mma_quarter(Q3, 3, xb);
+            }
+            // closing product y' = W t':  t' = -acc in the [col][q] layout of a solution block
+            double* xb = (ndep & 1) ? xs1 : xs0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tv[(16 * w + l15) * MR + lq + 4 * i] = bv[i] - acc[i];
-        __syncthreads();
-        d4n_t x = {0.0, 0.0, 0.0, 0.0};
-        mma_block(Wf, tv, l15, lq, x);
-        // ---- the neighbour, awaited on its payload; ONE product on the chain
+            for (int i = 0; i < 4; ++i) {
+                xb[(16 * w + l15) * MR + lq + 4 * i] = -acc[i];
+                acc[i] = 0.0;
+            }
+            __syncthreads();
+            mma_quarter(W0, 0, xb);
+            mma_quarter(W1, 1, xb);
+            mma_quarter(W2, 2, xb);
+            mma_quarter(W3, 3, xb);
+        }
+        d4n_t x = acc;  // y'
+        // ---- the neighbour; ONE product on the chain:  x = y' - M x_neighbour
         if (cnt > 0) {
-            if (!poll_payload(a, a.bwd ? blk + 1 : blk - 1, xs[1], t)) return;
+            double* xb = ((ndep + 1) & 1) ? xs1 : xs0;
+            const double* src = a.xg + (int64_t)(a.bwd ? blk + 1 : blk - 1) * (NB * MR);
+            Piece xv;
+            issue_payload(src, t, xv);
+            await_payload_pipelined<3>(a, src, t, xv);
+            payload_to_lds(xb, t, xv);
+            __syncthreads();
             d4n_t z = {0.0, 0.0, 0.0, 0.0};
-            mma_block(Mf, xs[1], l15, lq, z);
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                z = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[(4 * u + lq) * MR + l15], Ml[(w * 32 + u) * 64 + lane], z, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] -= z[i];
         }
-        // publish (write-through: the next owner polls these very words), then the caller's copy; the flag for the workgroups
-        // that take this block as an earlier dependency follows the acknowledged stores, off the chain
-        double* dst = a.xg + (int64_t)blk * (NB * MR);
+        // publish: this wave's 16 rows through LDS (the closing operand's buffer: every wave read it before the neighbour's
+        // barrier; a wave reads back only what it wrote itself, and a wave's LDS operations complete in order) -> two 16-byte
+        // write-through stores per lane, full cache lines.  No flag: every consumer of this kernel awaits the payload.
+        {
+            double* xo = ((ndep & 1) ? xs1 : xs0) + 256 * w;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __hip_atomic_store((gdbl*)(dst + (16 * w + l15) * MR + lq + 4 * i), x[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 4; ++i) xo[l15 * MR + lq + 4 * i] = x[i];
+            const d2_t p0 = *reinterpret_cast<const d2_t*>(xo + 2 * lane);
+            const d2_t p1 = *reinterpret_cast<const d2_t*>(xo + 128 + 2 * lane);
+            gvd2* dst = (gvd2*)(a.xg + (int64_t)blk * (NB * MR) + 256 * w);
+            dst[lane] = p0;
+            dst[64 + lane] = p1;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (row < a.n && lq + 4 * i < a.m) a.B[row + (int64_t)(lq + 4 * i) * a.ldb] = x[i];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) __hip_atomic_store((hgi32*)(a.flags + blk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();  // tv / xs are reused by the next block of this workgroup
+        __syncthreads();  // the buffers are reused by the next block of this workgroup
     }
 }
+
 
 // ---- the transposed copy ---------------------------------------------------------------------------------------------
 // upper off-diagonal blocks := transposes of the lower ones (the diagonal 128-blocks keep their zeroed upper triangle: the
@@ -484,6 +550,82 @@ static int ensure_transposed(fr_ctx* ctx, fr_chol* c)
     return FR_OK;
 }
 
+// The chain products of the single-group kernel: M_b = W_b L[b, b - 1] (forward) / W_b^T L[b + 1, b]^T (backward; both operands
+// from the transposed copy), b = every block with a neighbour -- ONE batched product of 128^3 per block row (n = 32768: 1 GFLOP,
+// 32 MiB per direction), cached with the factor's generation like the transposed copy.  (Round 3 first formed M inside the solve,
+// 31 us at the start of every block's life and 64 more live registers next to it.)
+static int ensure_chain_products(fr_ctx* ctx, fr_chol* c, bool fwd, int prof_cls)
+{
+    const int dir = fwd ? 0 : 1;
+    const int64_t nblk = (c->n + NB - 1) / NB;
+    if (nblk < 2) return FR_OK;
+    if (c->mchain_gen[dir] == c->gen && c->mchain[dir]) return FR_OK;
+    const int64_t cap_blk = (c->capacity + NB - 1) / NB;
+    if (c->mchain_cap[dir] < cap_blk) {
+        if (c->mchain[dir]) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(c->mchain[dir]);
+            c->mchain[dir] = nullptr;
+            c->mchain_cap[dir] = 0;
+        }
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->mchain[dir], sizeof(double) * (size_t)cap_blk * NB * NB));
+        c->mchain_cap[dir] = cap_blk;
+    }
+    // full blocks as ONE batched product; a last, partial block (rem rows) separately, restricted to what is valid: forward, its
+    // tile L[last, last - 1] has rem rows (K = rem; rows >= rem of M only reach solution entries nobody reads); backward, the
+    // upper-copy block (last - 1, last) has rem columns (N = rem, the other columns of M zero: they meet the zero entries of
+    // the last solution block)
+    const int64_t ld = c->ld_a;
+    const int64_t nfull = c->n / NB, rem = c->n - nfull * NB;
+    GemmDesc g;
+    g.M = NB; g.N = NB; g.K = NB;
+    g.lda = NB; g.a_kmajor = false;
+    g.ldb = ld; g.b_kmajor = true;
+    g.alpha = 1.0; g.beta = 0.0; g.lower = false; g.prof_cls = prof_cls;
+    g.batch_a = NB * NB;
+    g.batch_b = NB + NB * ld;
+    g.batch_c = g.batch_d = NB * NB;
+    g.ldcin = g.ldd = NB;
+    double* Mc = c->mchain[dir];
+    if (fwd) {  // blocks 1 .. nblk - 1: W_b x L[b, b - 1]
+        g.A = c->dinv + NB * NB;
+        g.B = c->A + NB;
+        g.D = Mc + NB * NB;
+        g.Cin = g.D;
+        g.batch = nfull - 1;
+        if (g.batch >= 1) FR_TRY(launch_gemm(ctx, g));
+        if (rem > 0 && nfull >= 1) {
+            g.batch = 1;
+            g.K = rem;
+            g.A = c->dinv + nfull * (NB * NB);
+            g.B = c->A + nfull * NB + (nfull - 1) * NB * ld;
+            g.D = Mc + nfull * (NB * NB);
+            g.Cin = g.D;
+            FR_TRY(launch_gemm(ctx, g));
+        }
+    } else {  // blocks 0 .. nblk - 2: W_b^T x (block (b, b + 1) of the upper copy)
+        g.A = c->dinvt;
+        g.B = c->A + NB * ld;
+        g.D = Mc;
+        g.Cin = g.D;
+        g.batch = nfull - 1;
+        if (g.batch >= 1) FR_TRY(launch_gemm(ctx, g));
+        if (rem > 0 && nfull >= 1) {
+            const int64_t b = nfull - 1;
+            FR_HIP(ctx, hipMemsetAsync(Mc + b * (NB * NB), 0, sizeof(double) * NB * NB, ctx->ls));
+            g.batch = 1;
+            g.N = rem;
+            g.A = c->dinvt + b * (NB * NB);
+            g.B = c->A + b * NB + (b + 1) * NB * ld;
+            g.D = Mc + b * (NB * NB);
+            g.Cin = g.D;
+            FR_TRY(launch_gemm(ctx, g));
+        }
+    }
+    c->mchain_gen[dir] = c->gen;
+    return FR_OK;
+}
+
 // B (n x m, device, m >= 2: column groups of 16) <- L^-1 B (fwd) or L^-T B.  One launch (+ a memset of the flags; the backward sweep also
 // builds the transposed copy when the factor changed since it was last built).
 int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int64_t ldb, bool fwd, int prof_cls)
@@ -519,6 +661,11 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     a.ld = c->ld_a;
     a.n = n;
     a.inv = fwd ? c->dinv : c->dinvt;
+    a.mchain = nullptr;
+    if (nq == 1 && ngroups == 1) {
+        FR_TRY(ensure_chain_products(ctx, c, fwd, prof_cls));
+        a.mchain = c->mchain[fwd ? 0 : 1];
+    }
     a.B = B;
     a.ldb = ldb;
     a.m = (int)m;
@@ -540,7 +687,13 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     else if (ngroups >= 2)
         hipLaunchKernelGGL(trsm_narrow_half_kernel<1>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     else
-        hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
+    {
+        if (!ctx->trsmn_lds_set) {  // per context (= per device): > 64 KiB of dynamic LDS needs the attribute
+            FR_HIP(ctx, hipFuncSetAttribute((const void*)trsm_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSMN_LDS));
+            ctx->trsmn_lds_set = true;
+        }
+        hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), TRSMN_LDS, ctx->ls, a);
+    }
     FR_HIP(ctx, hipGetLastError());
     ctx->persistent_pending = true;
     if (ctx->test_force_timeout) {  // test hook: behave as if a hand-off of this launch had timed out
