@@ -72,38 +72,47 @@ __device__ __forceinline__ void gran_store(u64* p, unsigned epoch, unsigned v)
     __hip_atomic_store((gu64*)p, ((u64)epoch << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Block `blk` of the solution (TB doubles = 2 TB granules, one per thread of the first four waves) -> xs[0 .. TB).  Returns false after a
-// timeout (the caller abandons the solve; the host reports it).
-__device__ __forceinline__ bool wait_block(const TrsvArgs& a, int blk, double* xs, int t)
+// Block `blk` of the solution: TB doubles = 2 TB granules, one per thread of the first four waves.  The granule of the NEXT
+// dependency is requested while the current one is multiplied (gran_request; nothing to see first: the data is the flag), so
+// a block that is behind the chain pays no round trip per dependency; a granule that has not arrived is polled with two
+// samples in flight (half a round trip between samples: scripts/handoff_probe.hip).  A wait that times out raises the
+// host-visible status word and goes on with whatever it has -- every later wait then gives up within a few polls, the
+// launch drains and the entry point repeats the solve on the recursive path (solve_retry): no vote, no early exit.
+__device__ __forceinline__ u64 gran_request(const TrsvArgs& a, int blk, int t)
 {
-    bool ok = true;
+    return t < 2 * TB ? gran_load(a.gran + (int64_t)blk * (2 * TB) + t) : 0;
+}
+__device__ __forceinline__ void wait_block(const TrsvArgs& a, int blk, double* xs, int t, u64 g)
+{
     if (t < 2 * TB) {
-    const u64* p = a.gran + (int64_t)blk * (2 * TB) + t;
-    u64 g = gran_load(p);
-    if ((unsigned)(g >> 32) != a.epoch) {
-        const u64 t0 = wall_clock64();  // 100 MHz
-        unsigned spins = 0;
-        for (;;) {
-            __builtin_amdgcn_s_sleep(1);
-            g = gran_load(p);
-            if ((unsigned)(g >> 32) == a.epoch) break;
-            if ((++spins & 255u) == 0) {
-                const bool dead = __hip_atomic_load((gu32*)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-                if (dead || wall_clock64() - t0 > 300000000ull) {  // 3 s
-                    __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    g = 0;
+        if ((unsigned)(g >> 32) != a.epoch) {
+            const u64* p = a.gran + (int64_t)blk * (2 * TB) + t;
+            const u64 t0 = wall_clock64();  // 100 MHz
+            unsigned spins = 0;
+            u64 g1 = gran_load(p);
+            for (;;) {
+                g = gran_load(p);
+                if ((unsigned)(g1 >> 32) == a.epoch) {
+                    g = g1;
                     break;
+                }
+                g1 = gran_load(p);
+                if ((unsigned)(g >> 32) == a.epoch) break;
+                if ((++spins & 127u) == 0) {
+                    const bool dead = __hip_atomic_load((gu32*)a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                    if (dead || wall_clock64() - t0 > 300000000ull) {  // 3 s
+                        __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                 }
             }
         }
+        // lanes 2 i / 2 i + 1 hold the low / high word of double i
+        const unsigned mine = (unsigned)g;
+        const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
+        if ((t & 1) == 0) xs[t >> 1] = __hiloint2double((int)other, (int)mine);
     }
-    ok = (unsigned)(g >> 32) == a.epoch;
-    // lanes 2 i / 2 i + 1 hold the low / high word of double i
-    const unsigned mine = (unsigned)g;
-    const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
-    if ((t & 1) == 0) xs[t >> 1] = __hiloint2double((int)other, (int)mine);
-    }
-    return __syncthreads_and(ok ? 1 : 0) != 0;
+    __syncthreads();
 }
 
 __device__ __forceinline__ void publish_entry(const TrsvArgs& a, int64_t i, double v)
@@ -223,15 +232,21 @@ __global__ __launch_bounds__(NT, 2) void trsv_fwd_kernel(const TrsvArgs a)
         stage_inverse(a, r, wl, rp, cg, A);
         // tiles L[r, q], q = 0 .. r - 1, through two register buffers: while tile q is consumed, tile q + 1 is in flight --
         // the loads do not depend on the hand-offs, only the FMAs do
-        if (r > 0) load_operand(tile_operand(a, r, 0), rp, cg, A);
+        u64 g = 0;
+        if (r > 0) {
+            g = gran_request(a, 0, t);
+            load_operand(tile_operand(a, r, 0), rp, cg, A);
+        }
 #pragma nounroll
         for (int q = 0; q < r; q += 2) {
             if (q + 1 < r) load_operand(tile_operand(a, r, q + 1), rp, cg, B);
-            if (!wait_block(a, q, s.xs[0], t)) return;
+            wait_block(a, q, s.xs[0], t, g);
+            if (q + 1 < r) g = gran_request(a, q + 1, t);
             fwd_fma(A, s.xs[0], cg, acc0, acc1);
             if (q + 1 >= r) break;
             if (q + 2 < r) load_operand(tile_operand(a, r, q + 2), rp, cg, A);
-            if (!wait_block(a, q + 1, s.xs[1], t)) return;
+            wait_block(a, q + 1, s.xs[1], t, g);
+            if (q + 2 < r) g = gran_request(a, q + 2, t);
             fwd_fma(B, s.xs[1], cg, acc0, acc1);
         }
         // x_r = W_r (b_r - acc)
@@ -342,18 +357,24 @@ __global__ __launch_bounds__(NT, 2) void trsv_bwd_kernel(const TrsvArgs a)
             if (c < 16 * ((r0 >> 4) + 1)) wt[wt_off(r0 >> 4) + (r0 & 15) * 16 * ((r0 >> 4) + 1) + c] = A[k].x;
             if (c < 16 * ((r1 >> 4) + 1)) wt[wt_off(r1 >> 4) + (r1 & 15) * 16 * ((r1 >> 4) + 1) + c] = A[k].y;
         }
-        if (cnt > 0) load_operand(tile_operand(a, last, j), rp, cg, A);
+        u64 g = 0;
+        if (cnt > 0) {
+            g = gran_request(a, last, t);
+            load_operand(tile_operand(a, last, j), rp, cg, A);
+        }
 #pragma nounroll
         for (int q = 0; q < cnt; q += 2) {
             if (q + 1 < cnt) load_operand(tile_operand(a, last - q - 1, j), rp, cg, B);
-            if (!wait_block(a, last - q, s.xs[0], t)) return;
+            wait_block(a, last - q, s.xs[0], t, g);
+            if (q + 1 < cnt) g = gran_request(a, last - q - 1, t);
             {
                 const double2 x = *reinterpret_cast<const double2*>(&s.xs[0][2 * rp]);
                 bwd_fma(A, x.x, x.y, p);
             }
             if (q + 1 >= cnt) break;
             if (q + 2 < cnt) load_operand(tile_operand(a, last - q - 2, j), rp, cg, A);
-            if (!wait_block(a, last - q - 1, s.xs[1], t)) return;
+            wait_block(a, last - q - 1, s.xs[1], t, g);
+            if (q + 2 < cnt) g = gran_request(a, last - q - 2, t);
             {
                 const double2 x = *reinterpret_cast<const double2*>(&s.xs[1][2 * rp]);
                 bwd_fma(B, x.x, x.y, p);
