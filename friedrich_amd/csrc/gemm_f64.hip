@@ -45,11 +45,21 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
         const int64_t sidx = ((b >> 3) >> 6) * 8 + xcd;
         const int within = (int)((b >> 3) & 63);
         if (sidx >= g.nsuper) return;
-        // (full products only: the lower-mode SYRK next to the panel stream was measured ~4 % faster in plain order)
         const int sh = 64 >> g.sw_log2;
-        tm = (sidx % g.super_m) * sh + (within & (sh - 1));
-        tn = (sidx / g.super_m) * (1 << g.sw_log2) + (within >> (6 - g.sw_log2));
-        if (tm >= g.tiles_m || tn >= g.tiles_n) return;
+        if (g.lower) {
+            // lower mode: the super-tiles of the lower triangle, row by row (8 x 8 tiles each; the ones on the diagonal hold 36)
+            int64_t R = (int64_t)((sqrt(8.0 * (double)sidx + 1.0) - 1.0) * 0.5);
+            while (R * (R + 1) / 2 > sidx) --R;
+            while ((R + 1) * (R + 2) / 2 <= sidx) ++R;
+            const int64_t C = sidx - R * (R + 1) / 2;
+            tm = R * 8 + (within & 7);
+            tn = C * 8 + (within >> 3);
+            if (tm >= g.tiles_m || tn > tm) return;
+        } else {
+            tm = (sidx % g.super_m) * sh + (within & (sh - 1));
+            tn = (sidx / g.super_m) * (1 << g.sw_log2) + (within >> (6 - g.sw_log2));
+            if (tm >= g.tiles_m || tn >= g.tiles_n) return;
+        }
     } else {
         // plain order: each XCD gets a contiguous run of the tile list
         int64_t tlin;
@@ -336,6 +346,9 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         if (d.M != d.N) return set_err(ctx, FR_INVALID_ARGUMENT, "lower-mode GEMM needs a square result");
         ntiles = g.tiles_m * (g.tiles_m + 1) / 2;
         flops = (double)d.M * (double)(d.M + 1) * (double)g.K;  // 2 * M(M+1)/2 * K
+        g.sw_log2 = 3;
+        g.super_m = (g.tiles_m + 7) / 8;
+        g.nsuper = g.super_m * (g.super_m + 1) / 2;
     } else {
         int swl = 0;
         while ((1 << swl) < g.tiles_n && swl < 3) ++swl;
@@ -347,9 +360,13 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         flops = 2.0 * (double)d.M * (double)d.N * (double)g.K;
     }
     g.per_xcd = (g.nsuper + 7) / 8;
-    // measured inside the factorisation (round 1, in-process A/B): super-tiles pay for large shallow full products only; the
-    // lower-mode SYRK next to the panel stream is ~4 % faster in plain order
-    bool use_super = !d.lower && !small && g.K <= 2048 && g.nsuper >= 128;
+    // measured inside the factorisation (round 1, in-process A/B): super-tiles pay for large shallow products only
+    // lower mode (the trailing update): 8 x 8 super-tiles of the lower triangle while nothing is reserved -- same time as the plain
+    // order inside the factorisation (N = 32768: 194.5 vs 194.6 ms, in-process A/B with FRIEDRICH_AMD_SYRK_SUPER=0 / 1), 22 % less
+    // L2-side fetch traffic per launch (8.15 -> 6.36 GB: rocprofv3 FETCH_SIZE; the workgroups of a super-tile drift apart over
+    // a 1024-deep contraction, so the hit rate stays well below the 8 x 8 ideal)
+    static const int syrk_super = getenv("FRIEDRICH_AMD_SYRK_SUPER") ? atoi(getenv("FRIEDRICH_AMD_SYRK_SUPER")) : 1;
+    bool use_super = (d.lower ? (syrk_super != 0 && d.own_world <= 1) : !small) && g.K <= 2048 && g.nsuper >= 128;
     g.place = 0;
     g.ntiles = ntiles;
     g.xcc_word = nullptr;
