@@ -476,6 +476,7 @@ __global__ __launch_bounds__(NTH, 2) void trsm_narrow_kernel(const TrsmnArgs a0)
         // publish: this wave's 16 rows through LDS (the closing operand's buffer: every wave read it before the neighbour's
         // barrier; a wave reads back only what it wrote itself, and a wave's LDS operations complete in order) -> two 16-byte
         // write-through stores per lane, full cache lines.  No flag: every consumer of this kernel awaits the payload.
+        if (cnt == 0) __syncthreads();  // (no neighbour, no barrier behind the closing product: the other waves may still read its operand)
         {
             double* xo = ((ndep & 1) ? xs1 : xs0) + 256 * w;
 #pragma unroll
