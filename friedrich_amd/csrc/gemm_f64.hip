@@ -170,27 +170,31 @@ __global__ __launch_bounds__(256, 2) void rows_solve_kernel(const RowsSolveArgs 
     g.lower = 0; g.tri = 0; g.place = 0; g.nres = 0; g.epoch = 0; g.ntiles = 0; g.xcc_word = nullptr; g.claim = nullptr; g.max_exit = 0;
     g.tiles_m = 1; g.tiles_n = 1; g.sw_log2 = 0; g.super_m = 1; g.nsuper = 0; g.per_xcd = 0;
     g.batch_a = g.batch_b = g.batch_c = g.batch_d = 0;
-    for (int64_t s = 0; s < nblk; ++s) {
+    // items: for every 128-column sub-panel s its update by the sub-panels in front of it (s > 0), then its solve -- ONE call site
+    // of the tile function (a second inlined copy doubles the kernel and its register pressure)
+#pragma nounroll
+    for (int64_t it = 1; it < 2 * nblk; ++it) {
+        const int64_t s = it >> 1;
+        const bool update = (it & 1) == 0;  // it = 2 s: update of sub-panel s;  it = 2 s + 1: its solve
         const int64_t c0 = s * 128, cs = (a.kb - c0) < 128 ? (a.kb - c0) : 128;
         double* Ss = a.S + c0 * a.lds_;
-        if (s > 0) {
+        g.N = cs;
+        g.Cin = Ss; g.ldcin = a.lds_; g.D = Ss; g.ldd = a.lds_;
+        if (update) {
             // S_s -= S_{<s} L[s, <s]^T
-            g.N = cs; g.K = c0;
+            g.K = c0;
             g.A = a.S; g.lda = a.lds_;
             g.B = a.L + c0; g.ldb = a.ldl;
-            g.Cin = Ss; g.ldcin = a.lds_; g.D = Ss; g.ldd = a.lds_;
             g.alpha = -1.0; g.beta = 1.0;
-            gemm_f64_tile_m32<false, false>(g, lds, m0, 0);
-            __syncthreads();  // (this workgroup's stores, drained, before its own loads of the same rows)
+        } else {
+            // S_s <- S_s W_s^T  (in place: the tile's contraction has read its 32 rows before the epilogue writes them)
+            g.K = cs;
+            g.A = Ss; g.lda = a.lds_;
+            g.B = a.dinv + s * (128 * 128); g.ldb = 128;
+            g.alpha = 1.0; g.beta = 0.0;
         }
-        // S_s <- S_s W_s^T  (in place: the tile's contraction has read its 32 rows before the epilogue writes them)
-        g.N = cs; g.K = cs;
-        g.A = Ss; g.lda = a.lds_;
-        g.B = a.dinv + s * (128 * 128); g.ldb = 128;
-        g.Cin = Ss; g.ldcin = a.lds_; g.D = Ss; g.ldd = a.lds_;
-        g.alpha = 1.0; g.beta = 0.0;
         gemm_f64_tile_m32<false, false>(g, lds, m0, 0);
-        __syncthreads();
+        __syncthreads();  // (this workgroup's stores, drained, before its own loads of the same rows)
     }
 }
 

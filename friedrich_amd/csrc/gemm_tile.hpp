@@ -430,6 +430,98 @@ __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds
     const double* pb = tile_thread_base<B_KMAJ>(g.B, g.ldb, n0, t);
     const int64_t step_b = B_KMAJ ? BK : BK * g.ldb;
     constexpr int STAGE = TILE_A_S + TILE_ELEMS;
+    if ((m0 + BMS) <= g.M && b_fast && nk_full == nk && nk >= 4) {
+        // Interior tile, K a multiple of 16.  These launches have one workgroup per CU (or per slot of a reserved XCD) and 16
+        // MFMAs per wave and K-step (0.4 us) against a memory round trip of 1 - 2 us: what a tile costs is how many round
+        // trips it exposes.  So (round 3) the loads run FOUR K-steps ahead of the MFMAs (four register sets in rotation: slice
+        // kt + 1 waits to be stored to LDS, kt + 2 .. kt + 4 are in flight) -- a K = 128 product, eight K-steps, has half its
+        // operands requested before the first MFMA -- and the C tile is requested BEFORE the K-loop instead of behind it (it is
+        // never an operand of the same product: callers guarantee D != B, and where D aliases A -- the in-place solves -- beta is
+        // 0 and nothing is read).  Unpredicated loads off one pointer per operand.
+        const double* pa = A_KMAJ ? g.A + (t & 15) + (m0 + (t >> 4)) * g.lda : g.A + (m0 + (t & 31)) + (int64_t)(t >> 5) * g.lda;
+        const int64_t step_a = A_KMAJ ? BK : BK * g.lda;
+        const int64_t ea = (A_KMAJ ? 16 : 8) * g.lda;  // second element of the thread's pair
+        const double* pbn = pb;
+        auto load4 = [&](double (&ra)[2], double (&rb)[8]) {
+            ra[0] = pa[0];
+            ra[1] = pa[ea];
+            load_tile_fast<B_KMAJ>(pbn, g.ldb, rb);
+            pa += step_a;
+            pbn += step_b;
+        };
+        double ra0[2], rb0[8], ra1[2], rb1[8], ra2[2], rb2[8], ra3[2], rb3[8];
+        load4(ra0, rb0);
+        load4(ra1, rb1);
+        load4(ra2, rb2);
+        load4(ra3, rb3);
+        // register r of tile (nt, mt) holds D[m0 + 16 mt + (lane & 15)][n0 + 32 wn + 16 nt + (lane >> 4) + 4 r]
+        const bool use_c = g.beta != 0.0;
+        const double* cbase = g.Cin + (m0 + l15) + (n0 + wn * 32 + lq) * g.ldcin;
+        double cv[16];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) cv[(nt * 4 + r) * 2 + mt] = use_c ? cbase[mt * 16 + (int64_t)(nt * 16 + 4 * r) * g.ldcin] : 0.0;
+        store_tile_s<A_KMAJ>(lds, t, ra0);
+        store_tile<B_KMAJ>(lds + TILE_A_S, t, rb0);
+        lds_only_barrier();  // (the slices and the C tile stay in flight across the barrier)
+        int cur = 0;
+        int64_t left = nk - 4;  // slices not requested yet
+        // one K-step: request the next slice into the set slice kt came from, multiply slice kt (in LDS), store slice kt + 1
+        auto kstep = [&](bool last, double (&la)[2], double (&lb)[8], const double (&sa)[2], const double (&sb)[8]) {
+            if (left > 0) {
+                load4(la, lb);
+                --left;
+            }
+            const double* As = lds + cur * STAGE;
+            const double* Bs = As + TILE_A_S;
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                const int kq = ks * 4 + lq;
+                double af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = As[lds_idx_s<A_KMAJ>(i * 16 + l15, kq)];
+                    bf[i] = Bs[lds_idx<B_KMAJ>(wn * 32 + i * 16 + l15, kq)];
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            }
+            if (!last) {
+                double* An = lds + (cur ^ 1) * STAGE;
+                store_tile_s<A_KMAJ>(An, t, sa);
+                store_tile<B_KMAJ>(An + TILE_A_S, t, sb);
+            }
+            lds_only_barrier();  // (the slices in flight stay in flight)
+            cur ^= 1;
+        };
+        for (int64_t kt = 0; kt < nk; kt += 4) {
+            kstep(kt + 1 >= nk, ra0, rb0, ra1, rb1);
+            if (kt + 1 >= nk) break;
+            kstep(kt + 2 >= nk, ra1, rb1, ra2, rb2);
+            if (kt + 2 >= nk) break;
+            kstep(kt + 3 >= nk, ra2, rb2, ra3, rb3);
+            if (kt + 3 >= nk) break;
+            kstep(kt + 4 >= nk, ra3, rb3, ra0, rb0);
+        }
+        double* dbase = g.D + (m0 + l15) + (n0 + wn * 32 + lq) * g.ldd;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    double v = g.alpha * acc[nt][mt][r];
+                    if (use_c) v += g.beta * cv[(nt * 4 + r) * 2 + mt];
+                    dbase[mt * 16 + (int64_t)(nt * 16 + 4 * r) * g.ldd] = v;
+                }
+        return;
+    }
     // The loads run TWO K-steps ahead of the MFMAs (registers: the slice for step kt + 1 waits to be stored, the one for
     // kt + 2 is in flight): these launches have one workgroup per CU and 16 MFMAs per wave and K-step, so a K-step costs a
     // memory round trip unless two are outstanding.
