@@ -412,6 +412,11 @@ __device__ __forceinline__ void lds_only_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// K-steps the 32-row tile's loads run ahead of its MFMAs (register sets in rotation); 4, 6 and 8 measure the same on the fits
+// (N = 2048 / 4096 / 8192: 1.39 / 2.84 / 7.71, 1.40 / 2.86 / 7.79, 1.41 / 2.87 / 7.74 ms), 2 was 7 / 7 / 3 % slower
+#ifndef M32_PF
+#define M32_PF 4
+#endif
 template <bool A_KMAJ, bool B_KMAJ>
 __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds, const int64_t m0, const int64_t n0)
 {
@@ -430,11 +435,11 @@ __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds
     const double* pb = tile_thread_base<B_KMAJ>(g.B, g.ldb, n0, t);
     const int64_t step_b = B_KMAJ ? BK : BK * g.ldb;
     constexpr int STAGE = TILE_A_S + TILE_ELEMS;
-    if ((m0 + BMS) <= g.M && b_fast && nk_full == nk && nk >= 4) {
+    if ((m0 + BMS) <= g.M && b_fast && nk_full == nk && nk >= M32_PF) {
         // Interior tile, K a multiple of 16.  These launches have one workgroup per CU (or per slot of a reserved XCD) and 16
         // MFMAs per wave and K-step (0.4 us) against a memory round trip of 1 - 2 us: what a tile costs is how many round
-        // trips it exposes.  So (round 3) the loads run FOUR K-steps ahead of the MFMAs (four register sets in rotation: slice
-        // kt + 1 waits to be stored to LDS, kt + 2 .. kt + 4 are in flight) -- a K = 128 product, eight K-steps, has half its
+        // trips it exposes.  So (round 3) the loads run FOUR K-steps ahead of the MFMAs (PF register sets in rotation: slice
+        // kt + 1 waits to be stored to LDS, kt + 2 .. kt + PF are in flight) -- a K = 128 product, eight K-steps, has half its
         // operands requested before the first MFMA -- and the C tile is requested BEFORE the K-loop instead of behind it (it is
         // never an operand of the same product: callers guarantee D != B, and where D aliases A -- the in-place solves -- beta is
         // 0 and nothing is read).  Unpredicated loads off one pointer per operand.
@@ -449,11 +454,10 @@ __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds
             pa += step_a;
             pbn += step_b;
         };
-        double ra0[2], rb0[8], ra1[2], rb1[8], ra2[2], rb2[8], ra3[2], rb3[8];
-        load4(ra0, rb0);
-        load4(ra1, rb1);
-        load4(ra2, rb2);
-        load4(ra3, rb3);
+        constexpr int PF = M32_PF;  // register sets = K-steps the loads run ahead
+        double ra[PF][2], rb[PF][8];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) load4(ra[j], rb[j]);
         // register r of tile (nt, mt) holds D[m0 + 16 mt + (lane & 15)][n0 + 32 wn + 16 nt + (lane >> 4) + 4 r]
         const bool use_c = g.beta != 0.0;
         const double* cbase = g.Cin + (m0 + l15) + (n0 + wn * 32 + lq) * g.ldcin;
@@ -464,11 +468,11 @@ __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) cv[(nt * 4 + r) * 2 + mt] = use_c ? cbase[mt * 16 + (int64_t)(nt * 16 + 4 * r) * g.ldcin] : 0.0;
-        store_tile_s<A_KMAJ>(lds, t, ra0);
-        store_tile<B_KMAJ>(lds + TILE_A_S, t, rb0);
+        store_tile_s<A_KMAJ>(lds, t, ra[0]);
+        store_tile<B_KMAJ>(lds + TILE_A_S, t, rb[0]);
         lds_only_barrier();  // (the slices and the C tile stay in flight across the barrier)
         int cur = 0;
-        int64_t left = nk - 4;  // slices not requested yet
+        int64_t left = nk - PF;  // slices not requested yet
         // one K-step: request the next slice into the set slice kt came from, multiply slice kt (in LDS), store slice kt + 1
         auto kstep = [&](bool last, double (&la)[2], double (&lb)[8], const double (&sa)[2], const double (&sb)[8]) {
             if (left > 0) {
@@ -500,14 +504,11 @@ __device__ __forceinline__ void gemm_f64_tile_m32(const GemmArgs& g, double* lds
             lds_only_barrier();  // (the slices in flight stay in flight)
             cur ^= 1;
         };
-        for (int64_t kt = 0; kt < nk; kt += 4) {
-            kstep(kt + 1 >= nk, ra0, rb0, ra1, rb1);
-            if (kt + 1 >= nk) break;
-            kstep(kt + 2 >= nk, ra1, rb1, ra2, rb2);
-            if (kt + 2 >= nk) break;
-            kstep(kt + 3 >= nk, ra2, rb2, ra3, rb3);
-            if (kt + 3 >= nk) break;
-            kstep(kt + 4 >= nk, ra3, rb3, ra0, rb0);
+        for (int64_t kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {  // (unrolled: the set indices are compile-time constants)
+                if (kt0 + j < nk) kstep(kt0 + j + 1 >= nk, ra[j], rb[j], ra[(j + 1) % PF], rb[(j + 1) % PF]);
+            }
         }
         double* dbase = g.D + (m0 + l15) + (n0 + wn * 32 + lq) * g.ldd;
 #pragma unroll
