@@ -16,7 +16,10 @@ TOL_GRAM = 1e-13  # per-pair kernel values: only libm differences (exp/pow/tanh/
 
 # ---- K5/K6 GEMM ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 150, 77), (129, 1, 300), (1, 257, 5), (300, 260, 16), (17, 19, 0)])
+# (the last three shapes run interior 32-row tiles with K a multiple of 16 and at least four K-steps: the deep-prefetch path of
+# gemm_f64_tile_m32, in all four storage combinations; the row tile 96..99 of the last one takes the predicated path)
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 150, 77), (129, 1, 300), (1, 257, 5), (300, 260, 16), (17, 19, 0),
+                                   (96, 256, 128), (160, 128, 64), (100, 128, 80)])
 def test_gemm_matches_numpy(ctx, ta, tb, M, N, K):
     rng = np.random.default_rng(M * 1000 + N * 10 + K + ta * 2 + tb)
     A = np.asfortranarray(rng.standard_normal((K, M) if ta else (M, K)))
