@@ -789,6 +789,29 @@ def test_narrow_persistent_solves_2_to_16_columns(ctx, n, m):
     chol.free()
 
 
+def test_narrow_solves_follow_a_refactored_factor(ctx):
+    """The single-group kernel keeps per-factor caches (chain products W_b L[b, b-1], the transposed copy): a refactor with
+    other hyper-parameters, an upload and add_rows must each invalidate them -- 16 right-hand sides vs the oracle after every change."""
+    n, m = 1000, 16
+    X = rand_inputs(n + 24, 4, 77)
+    B = np.asfortranarray(np.random.default_rng(78).standard_normal((n + 24, m)))
+    k1, k2 = PD_KERNELS[1], PD_KERNELS[0]
+    chol = ctx.cholesky_from_inputs(k1, X[:n], 0.2)
+    st, L1, _ = O.make_cholesky_cov_matrix(k1, X[:n], 0.2)
+    assert rel_err(chol.solve(B[:n]), O.chol_solve(L1, B[:n])) < TOL
+    chol.refactor(k2, 0.35)
+    st, L2, _ = O.make_cholesky_cov_matrix(k2, X[:n], 0.35)
+    assert rel_err(chol.solve(B[:n]), O.chol_solve(L2, B[:n])) < TOL
+    assert rel_err(chol.solve_lower(B[:n]), O.solve_lower(L2, B[:n])[1]) < TOL
+    up = ctx.cholesky_upload(np.tril(L1), X[:n])
+    assert rel_err(up.solve(B[:n]), O.chol_solve(L1, B[:n])) < TOL
+    up.free()
+    chol.add_rows(k2, np.asfortranarray(X), 24, 0.35)
+    st, L3, _ = O.make_cholesky_cov_matrix(k2, X, 0.35)
+    assert rel_err(chol.solve(B), O.chol_solve(L3, B)) < TOL
+    chol.free()
+
+
 # ---- `Input` staging (SURVEY.md section 8 row f3; conversion/mod.rs:58-201) ---------------------------------------------
 @pytest.mark.parametrize("n,d", [(1, 1), (1, 5), (333, 1), (1000, 7), (4100, 16)])
 def test_inputs_to_device_layouts(ctx, n, d):
