@@ -146,6 +146,44 @@ def test_full_size_factor_vs_oracle(ctx, name, n, d, kernel_name, with_eps, ncol
     chol.free()
 
 
+@pytest.mark.skipif(os.environ.get("FRIEDRICH_FULL_PARITY") != "1", reason="two more minutes (threaded oracle of the whole N = 32768 factor): set FRIEDRICH_FULL_PARITY=1")
+def test_config3_whole_n32768_factor_vs_oracle(ctx):
+    """configs[3], one GPU: ALL 32768 columns of the factor against the oracle (every panel of 1024, the switch to 512-column
+    panels for the last 16384 rows, every XCD-reservation tier, the super-tiled trailing updates).  Opt-in, so that the default suite
+    stays near two minutes: the oracle's part takes 105 s on the GPU box's 256 host threads; the result of the round's run is kept
+    in profiles/r03/parity_full_32768.json."""
+    import time
+
+    n, d = 32768, 16
+    X, y, _, hp, k = _problem(ctx, n, d, 3, 0, "squared_exp")
+    noise = hp["noise"]
+    t0 = time.time()
+    with O.threads():
+        st, L_o, idx = O.make_cholesky_cov_matrix_cols(k, X, noise, None, n)
+    t_oracle = time.time() - t0
+    assert st == 0 and len(idx) == 0
+    chol = ctx.cholesky_from_inputs(k, X, noise, capacity_hint=n)
+    info = chol.info()
+    assert info["fail_col"] == -1 and info["n_subst"] == 0
+    worst = 0.0
+    per_block = []
+    for c0 in range(0, n, 4096):  # (column blocks: no second n x n host copy)
+        Lc = _leading_columns(chol, n, c0 + 4096)[:, c0:]
+        ref = L_o[:, c0:c0 + 4096]
+        ref = np.where(np.arange(n)[:, None] >= (c0 + np.arange(4096))[None, :], ref, 0.0)
+        e = rel_err(Lc, ref)
+        per_block.append(float(e))
+        worst = max(worst, e)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_full_32768.json"), "w") as f:
+        json.dump({"config": "configs[3] one GPU: N=32768 d=16 RBF, friedrich default hyper-parameters, whole factor vs the threaded oracle",
+                   "relative_error_per_4096_column_block": per_block, "worst": float(worst), "tolerance": TOL,
+                   "oracle_seconds": round(t_oracle, 1)}, f, indent=1)
+    assert worst < TOL
+    chol.free()
+
+
 def test_large_n_schedule_on_n8192_vs_oracle(ctx):
     """The schedule of a fit at N >= 24576 -- 1024-column panels while the trailing update dominates, 512-column panels with
     XCDs set aside for the panel chain over the last rows -- forced onto a matrix the oracle factors in full (N = 8192:
