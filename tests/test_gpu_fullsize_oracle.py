@@ -130,7 +130,7 @@ def test_full_size_factor_vs_oracle(ctx, name, n, d, kernel_name, with_eps, ncol
     """configs[2]: the WHOLE N = 16384 factor against the oracle (32 panels of 512 columns, both XCD-reservation tiers);
     configs[3]: the leading 8192 columns of the N = 32768 factor (eight look-ahead panels of 1024 columns, i.e. every column
     compared has seen up to seven trailing updates; columns of a left-looking factorisation depend only on the columns in
-    front of them, so the oracle stops there -- the remaining 24576 columns would take it ~10 minutes).  The automatic
+    front of them, so the oracle stops there; all 32768 columns: the opt-in test below).  The automatic
     1024 -> 512 panel switch of the last 16384 rows is covered against the oracle by the configs[2]-sized tail test below."""
     X, y, _, hp, k = _problem(ctx, n, d, 3, 0, kernel_name)
     noise = hp["noise"]
