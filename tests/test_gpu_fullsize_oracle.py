@@ -154,8 +154,8 @@ def test_config3_whole_n32768_factor_vs_oracle(ctx):
     in profiles/r03/parity_full_32768.json."""
     import time
 
-    n, d = 32768, 16
-    X, y, _, hp, k = _problem(ctx, n, d, 3, 0, "squared_exp")
+    n, d, m = 32768, 16, 64
+    X, y, Xq, hp, k = _problem(ctx, n, d, 3, m, "squared_exp")
     noise = hp["noise"]
     t0 = time.time()
     with O.threads():
@@ -174,13 +174,28 @@ def test_config3_whole_n32768_factor_vs_oracle(ctx):
         e = rel_err(Lc, ref)
         per_block.append(float(e))
         worst = max(worst, e)
+    # ... and the predict family on that factor, each solve path of the library: 1 point (K8), 16 points (K9), 64 points (column groups)
+    yres = y - hp["prior"]
+    with O.threads():
+        gp = O.OracleGP.__new__(O.OracleGP)  # the oracle model around the factor computed above (no second O(n^3))
+        gp.prior, gp.prog, gp.noise, gp.cholesky_epsilon = O.ConstantPrior(hp["prior"]), O.kprog(k), noise, None
+        gp.X, gp.y, gp.L, gp.subst = np.asfortranarray(X), yres, np.asfortranarray(L_o), np.zeros(0, dtype=np.int64)
+        mo, vo = gp.predict(Xq), gp.predict_variance(Xq)
+    pred = {}
+    for mm in (1, 16, 64):
+        mean = chol.predict_mean(k, yres, Xq[:mm], np.full(mm, hp["prior"]))
+        var = chol.predict_variance(k, Xq[:mm])
+        pred[str(mm)] = {"mean": float(rel_err(mean, mo[:mm])), "variance": float(rel_err(var, vo[:mm]))}
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_full_32768.json"), "w") as f:
         json.dump({"config": "configs[3] one GPU: N=32768 d=16 RBF, friedrich default hyper-parameters, whole factor vs the threaded oracle",
                    "relative_error_per_4096_column_block": per_block, "worst": float(worst), "tolerance": TOL,
+                   "predict_relative_error_by_number_of_points": pred, "predict_tolerance": 1e-8,
                    "oracle_seconds": round(t_oracle, 1)}, f, indent=1)
     assert worst < TOL
+    for mm, e in pred.items():
+        assert e["mean"] < 1e-8 and e["variance"] < 1e-8, (mm, e)
     chol.free()
 
 
