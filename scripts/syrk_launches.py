@@ -1,0 +1,27 @@
+"""Developer probe: the trailing-update launches of the last fit in a rocprofv3 kernel trace of `fit_only.py 32768`: size, duration and
+rate of each (the bench line's roofline fraction is their flop-weighted average)."""
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kind"] == "KERNEL_DISPATCH" and "syrk_lower" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[-46:]
+n = 32768
+# panel widths: 1024 while more than 16384 rows remain after the panel, then 512
+k = 0; out = []
+widths = []
+rem = n
+while rem > 0:
+    w = 512 if rem <= 16384 else 1024  # the library's rule: 512-column panels once at most 16384 rows remain
+    w = min(w, rem); widths.append(w); rem -= w
+# SYRK j uses K = widths[j], result = rows after panel j+1
+pos = 0
+tot_f = tot_t = 0
+for j, r in enumerate(rows):
+    kb = widths[j]; kb2 = widths[j + 1]
+    rest2 = n - (pos + kb + kb2)
+    fl = rest2 * (rest2 + 1) * kb
+    dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    out.append((j, rest2, kb, dur, fl / dur / 1e6))
+    tot_f += fl; tot_t += dur
+    pos += kb
+for o in out: print("launch %2d rest %5d K %4d  %8.1f us  %5.1f TF/s" % o)
+print("total %.1f ms, %.1f TF/s" % (tot_t / 1e3, tot_f / tot_t / 1e6))
