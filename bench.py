@@ -15,6 +15,11 @@ N > 1: one process per GPU.  The factorisation is sharded (block-cyclic column p
 blocks travels by point-to-point fan-out, the rows below by scatter / per-rank solves / all-gather over xGMI,
 every rank ends with the full factor: DESIGN.md section 6); the m query rows are split across ranks.  Total work
 is fixed => "scaling": "strong".  Inputs (X, y, X*) are resident in HBM before the timed region starts.
+Before the timed region every candidate schedule (2 -> 1 -> 0) has to get a sharded fit of 4096 rows right -- compared
+with a single-rank fit on the same GPU -- under the library's collective time-out; a schedule that fails or times out is
+dropped, the communicators are rebuilt, the next one is tried, and if none works the ranks run as replicas.  The line
+says which (`schedule_used`, `fallback_reason`) and carries one untimed step's per-class times of every rank
+(`per_rank`: comm / potf2 / panel / syrk) next to the critical-path model of DESIGN.md section 6.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the FP64-MFMA trailing SYRK update) with
 HIP events recorded inside the library on the stream the kernel runs on; `cpu_baseline` times the CPU oracle
@@ -123,58 +128,48 @@ def cpu_baseline(n, d, m, cfg):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=32768)
-    ap.add_argument("--d", type=int, default=16)
-    ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block; 0 = the library's choice (1024 on one GPU at this size, 512 sharded)")
-    ap.add_argument("--dist-schedule", type=int, default=-1, help="N > 1, how a panel step travels: 0 = one broadcast per panel; 1 = diagonal block broadcast + rows scattered / solved per rank / all-gathered; 2 = as 1 with the diagonal chain running ahead; -1 = the library's default (2)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=5120)
-    args = ap.parse_args()
+# the critical-path model of the chain-first schedule at N = 32768, nb = 512, W = 8 (microseconds per
+# panel; compute terms measured on one idle GPU, transfers priced at 45 GB/s per xGMI link + 20 us per RCCL call) -- printed
+# next to the measured per-class times of an N > 1 run so that the first scaling curve says where its time went
+MODEL_TERMS_US = {"diag_block_D_p": 290, "R1_solve": 105, "M_p_fanout": 65, "u1": 34, "chain_step": 510,
+                  "bulk_latency_first": 1050, "bulk_latency_last": 450, "rank_share_of_update_k0": 1070,
+                  "predicted_fit_ms_8gpus": "43-47 (schedule 2), ~70 (schedule 1), 100-130 (schedule 0)"}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
 
+def run_rank(args, link, device_index, emit, mode):
+    """One rank of the bench: mode "process" (one process per GPU, RCCL), "threads" (thread-ranks sharing ONE GPU over the
+    library's in-process transport: exercises every line of the N > 1 path on a 1-GPU box, not a measurement) or "solo"."""
     import torch
-    import torch.distributed as dist
 
-    from friedrich_amd import synth
-    from friedrich_amd.device import Context
+    from friedrich_amd import sharding, synth
+    from friedrich_amd.device import Context, FriedrichError
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # FRIEDRICH_BENCH_FORCE_DIST=1 takes the multi-process set-up (process group, ncclUniqueId hand-over, communicator
-    # self-test) with a single rank too: the only way to exercise it on a 1-GPU box
-    use_dist = world > 1 or os.environ.get("FRIEDRICH_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    ctx = Context(local_rank)
+    rank, world = link.rank, link.world
+    dev = torch.device("cuda", device_index)
+    log = (lambda msg: print(f"bench.py: {msg}", file=sys.stderr, flush=True)) if rank == 0 else (lambda msg: None)
+    ctx = Context(device_index)
     ctx.set_option("nb", args.nb)
-    if args.dist_schedule >= 0:
-        ctx.set_option("dist_schedule", args.dist_schedule)
-    dist_sched = args.dist_schedule if args.dist_schedule >= 0 else int(os.environ.get("FRIEDRICH_AMD_DIST_SCHEDULE", "2"))
     nb_eff = args.nb if args.nb > 0 else (1024 if (world == 1 and args.n >= 24576) else 512)
-    if use_dist:
-        ids = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(rank, world, ids[0])
-        ctx.comm_selftest()
+    sharded = world > 1 or mode == "process_forced"
+
+    # ---- N > 1: pick the schedule behind a preflight, under the library's watchdog -------------------------------------
+    schedule, fallback, preflight_ms = None, [], {}
+    if sharded:
+        link.attach(ctx)  # communicator + collective self-test
+        first = args.dist_schedule if args.dist_schedule >= 0 else int(os.environ.get("FRIEDRICH_BENCH_FIRST_SCHEDULE", "2"))
+        candidates = [s for s in (2, 1, 0) if s <= first]
+        if world > 1:
+            ref_ctx = Context(device_index)
+            try:
+                schedule, fallback, preflight_ms = sharding.guarded_schedule(
+                    ctx, link, lambda s: sharding.preflight_fit(ctx, ref_ctx, n=args.preflight_n), schedules=candidates,
+                    timeout_ms=args.preflight_timeout_ms, log=log)
+            finally:
+                ref_ctx.close()
+        else:
+            schedule = candidates[0]
+            ctx.set_option("dist_schedule", schedule)
+        ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
 
     n, d, m = args.n, args.d, args.m
     cfg = 4
@@ -186,47 +181,96 @@ def main():
     noise = hp["noise"]
 
     # query rows are sharded across ranks; everything the timed region touches is resident in HBM
-    lo, hi = (m * rank) // world, (m * (rank + 1)) // world
+    lo, hi = sharding.query_slice(m, rank, world)
     m_loc = hi - lo
     Xq_d = torch.from_numpy(np.ascontiguousarray(Xq[lo:hi].T)).to(dev).t() if m_loc > 0 else torch.empty((0, d), dtype=torch.float64, device=dev)
     y_d = torch.from_numpy(y - hp["prior"]).to(dev)
     prior_d = torch.full((m_loc,), hp["prior"], dtype=torch.float64, device=dev)
     mean_d = torch.empty((m_loc,), dtype=torch.float64, device=dev)
     X_d = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev).t()
-    chol = ctx.cholesky_from_inputs(kernel, X_d, noise, capacity_hint=n)  # allocates + first (untimed) factorisation
 
     def sync():
         ctx.synchronize()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+        torch.cuda.synchronize(dev)
+        link.barrier()
+        if mode.startswith("process") and sharded:
+            import torch.distributed as dist
+            dist.barrier()  # (the contract's barrier over RCCL; link.barrier is the control plane's)
 
-    fit_ms, pred_ms = [], []
+    def measure():
+        """first (untimed) factorisation, warm-up, the timed steps, one profiled step -> dict; raises FriedrichError"""
+        chol = ctx.cholesky_from_inputs(kernel, X_d, noise, capacity_hint=n)  # allocates + first (untimed) factorisation
+        try:
+            fit_ms, pred_ms = [], []
 
-    def step(record):
-        t0 = time.perf_counter()
-        chol.refactor(kernel, noise)  # Gram + Cholesky (host returns after the status read-back)
-        t1 = time.perf_counter()
-        if m_loc > 0:
-            chol.predict_mean(kernel, y_d, Xq_d, prior_d, out=mean_d)
-        ctx.synchronize()
-        t2 = time.perf_counter()
-        if record:
-            fit_ms.append(1e3 * (t1 - t0))
-            pred_ms.append(1e3 * (t2 - t1))
+            def step(record):
+                t0 = time.perf_counter()
+                chol.refactor(kernel, noise)  # Gram + Cholesky (host returns after the status read-back)
+                t1 = time.perf_counter()
+                if m_loc > 0:
+                    chol.predict_mean(kernel, y_d, Xq_d, prior_d, out=mean_d)
+                ctx.synchronize()
+                t2 = time.perf_counter()
+                if record:
+                    fit_ms.append(1e3 * (t1 - t0))
+                    pred_ms.append(1e3 * (t2 - t1))
 
-    for _ in range(args.warmup):
-        step(False)
-    ctx.profile_reset()
-    ctx.profile_enable(True, classes=["syrk"])
-    sync()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    sync()
-    elapsed = time.perf_counter() - t_start
-    prof = ctx.profile()
-    ctx.profile_enable(False)
+            for _ in range(args.warmup):
+                step(False)
+            ctx.profile_reset()
+            ctx.profile_enable(True, classes=["syrk"])
+            sync()
+            t_start = time.perf_counter()
+            for _ in range(args.steps):
+                step(True)
+            sync()
+            elapsed = time.perf_counter() - t_start
+            prof = ctx.profile()
+            # one more, untimed step with every class timed (HIP events around every launch: they perturb the step, hence
+            # outside the clock): where the time of a step goes -- collectives (incl. the wait for the peers), diagonal-block
+            # kernels, panel products, trailing updates
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            t0 = time.perf_counter()
+            step(False)
+            prof_step_ms = 1e3 * (time.perf_counter() - t0)
+            classes = ctx.profile()
+            ctx.profile_enable(False)
+            return {"chol": chol, "elapsed": elapsed, "fit_ms": fit_ms, "pred_ms": pred_ms, "prof": prof, "classes": classes,
+                    "prof_step_ms": prof_step_ms}
+        except BaseException:
+            chol.free()
+            raise
+
+    res = None
+    while res is None:
+        try:
+            res = measure()
+            ok, why = True, None
+        except FriedrichError as e:
+            if not sharded or world == 1 or schedule is None or schedule < 0:
+                raise
+            ok, why = False, str(e)
+        if sharded and world > 1 and schedule is not None and schedule >= 0:
+            ok, why = sharding.agree(link, ok, why)
+            if not ok:
+                if res is not None:
+                    res["chol"].free()
+                    res = None
+                fallback.append(f"schedule {schedule} at N={n}: {why}")
+                log(f"sharded schedule {schedule} failed on the bench workload ({why}); falling back")
+                lower = [s for s in (1, 0) if s < schedule]
+                err = sharding.reattach(ctx, link) if lower else "no schedule left"
+                if err is None:
+                    ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
+                    schedule = lower[0]
+                    ctx.set_option("dist_schedule", schedule)
+                else:
+                    if lower:
+                        fallback.append(err)
+                    ctx.comm_finalize(abort=True)
+                    schedule = -1
+    chol, elapsed, fit_ms, pred_ms, prof = res["chol"], res["elapsed"], res["fit_ms"], res["pred_ms"], res["prof"]
 
     # outside the timed region: the same predict associated as K*^T (K^-1 y) (option predict_assoc = 1; two n x 1 solves
     # instead of two n x m ones) -- reported next to the reference's association, not part of `value`
@@ -245,7 +289,7 @@ def main():
     # readme.md:7), a handful of points, likelihood, the cached-alpha predict, and the fit with the host -> device staging of
     # the training inputs inside the clock
     extras = {}
-    if m_loc > 0 and rank == 0:
+    if m_loc > 0 and rank == 0 and not args.no_extras:
         def best_ms(fn, reps=3):
             fn()
             ctx.synchronize()
@@ -257,7 +301,7 @@ def main():
                 b = min(b, time.perf_counter() - t0)
             return 1e3 * b
 
-        for mm in (1, 16, 32, 64):
+        for mm in (1, 16, 32, 64, 128, 256):
             if mm > m_loc:
                 continue
             q = Xq_d[:mm]
@@ -268,7 +312,7 @@ def main():
         extras["likelihood_ms"] = best_ms(lambda: chol.likelihood(kernel, y_d, noise))
         chol.set_targets(y_d)
         extras["predict_ms_cached_alpha"] = best_ms(lambda: chol.predict_mean(kernel, None, Xq_d, prior_d, out=mean_d))
-        if world == 1:
+        if world == 1 and mode == "solo":
             # one optimizer iteration's gradient terms (optimizer.rs:159-203: K^-1 = W^T W and the fused reductions); the
             # refactor that precedes it in fit_parameters is `fit_ms` without the Gram heuristics
             npar = 2
@@ -283,10 +327,26 @@ def main():
 
             extras["fit_ms_h2d_inclusive"] = best_ms(fit_from_host, reps=2)
 
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # --verify: this rank's share of the predictions against a single-rank fit of the same rows on the same GPU (tests)
+    verify_err = None
+    if args.verify and m_loc > 0:
+        ref_ctx = Context(device_index)
+        ref = ref_ctx.cholesky_from_inputs(kernel, X_d, noise)
+        want = torch.empty((m_loc,), dtype=torch.float64, device=dev)
+        ref.predict_mean(kernel, y_d, Xq_d, prior_d, out=want)
+        chol.predict_mean(kernel, y_d, Xq_d, prior_d, out=mean_d)
+        ref_ctx.synchronize()
+        ctx.synchronize()
+        verify_err = float((mean_d - want).abs().max() / want.abs().max())
+        ref.free()
+        ref_ctx.close()
+
+    # MAX over ranks of the timed region; every rank's per-class times of the profiled step
+    per_rank = link.gather({"elapsed": elapsed, "fit_ms": float(np.mean(fit_ms)), "pred_ms": float(np.mean(pred_ms)),
+                            "classes": {k: round(v["ms"], 3) for k, v in res["classes"].items()},
+                            "launches": {k: v["launches"] for k, v in res["classes"].items()},
+                            "prof_step_ms": res["prof_step_ms"], "comm_timeouts": ctx.counter("comm_timeouts"), "verify": verify_err})
+    elapsed = max(r["elapsed"] for r in per_rank)
 
     info = chol.info()
     if rank == 0:
@@ -300,13 +360,20 @@ def main():
         pmc_path = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc_path) and (n, d, nb_eff, world) == (32768, 16, PMC_NB, 1):
             with open(pmc_path) as f:
-                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: regenerate (scripts/profile_r03.sh) whenever gemm_f64.hip / gemm_tile.hpp change
+                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: regenerate (scripts/profile_r04.sh) whenever gemm_f64.hip / gemm_tile.hpp change
             traffic_src = PMC_FILE
+        if not sharded:
+            parallelism = "1 GPU"
+        else:
+            what = f"{world} thread-ranks on ONE GPU over the in-process transport (TEST MODE: exercises the N > 1 path, not a measurement)" \
+                if mode == "threads" else f"{world} GPUs (RCCL)"
+            parallelism = (f"block-cyclic column panels over {what}, {sharding.SCHEDULE_NAMES[schedule]}, queries sharded" if schedule >= 0
+                           else f"{what}: {sharding.SCHEDULE_NAMES[-1]}")
         out = {
             "metric": "gp_fit_predict_gflops",
             "value": total_flops / (ms_per_step * 1e-3) / 1e9,
             "unit": "GFLOP/s",
-            "n_gpus": world,
+            "n_gpus": 1 if mode == "threads" else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -318,7 +385,7 @@ def main():
             "config": {
                 "workload": f"GP fit (Gram + Cholesky) + predict, N={n} d={d} RBF, m={m} queries, friedrich default hyper-parameters",
                 "n": n, "d": d, "m": m, "kernel": "squared_exp", "nb": nb_eff,
-                "parallelism": "1 GPU" if world == 1 else f"block-cyclic column panels over {world} GPUs (RCCL, " + ["one broadcast per panel", "diagonal block broadcast + scatter / all-gather of the rows below", "diagonal chain first: block to the next owner, then scatter / all-gather of the rows below"][dist_sched] + "), queries sharded",
+                "parallelism": parallelism,
             },
             "fit_ms": float(np.mean(fit_ms)),
             "predict_ms": float(np.mean(pred_ms)),
@@ -326,6 +393,8 @@ def main():
             **extras,
             "cholesky_tflops": (n ** 3 / 3.0) / (np.mean(fit_ms) * 1e-3) / 1e12,
             "n_substitutions": info["n_subst"],
+            # one untimed step with HIP events around every launch of every class (rank 0; per_rank below has all of them)
+            "step_breakdown_ms": {"step_with_events": res["prof_step_ms"], **per_rank[0]["classes"]},
             "roofline": {
                 "kernel": "syrk_lower_f64_kernel (trailing SYRK update of the blocked Cholesky, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",
@@ -341,14 +410,112 @@ def main():
                 "flops_per_launch": syrk["flops"] / max(syrk["launches"], 1),
             },
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only (rank 0's host cores)
+        if sharded:
+            out["schedule_used"] = schedule
+            out["fallback_reason"] = "; ".join(fallback) if fallback else None
+            out["preflight"] = {"n": args.preflight_n, "timeout_ms": args.preflight_timeout_ms,
+                                "ms_by_schedule": {str(k): round(v, 1) for k, v in preflight_ms.items()}}
+            out["per_rank"] = {
+                "fit_ms": [round(r["fit_ms"], 3) for r in per_rank], "predict_ms": [round(r["pred_ms"], 3) for r in per_rank],
+                "comm_ms": [r["classes"]["comm"] for r in per_rank], "potf2_ms": [r["classes"]["potf2"] for r in per_rank],
+                "panel_ms": [r["classes"]["gemm_panel"] for r in per_rank], "syrk_ms": [r["classes"]["syrk"] for r in per_rank],
+                "gram_ms": [r["classes"]["gram"] for r in per_rank], "solve_ms": [r["classes"]["gemm_solve"] for r in per_rank],
+                "comm_calls": [r["launches"]["comm"] for r in per_rank], "step_with_events_ms": [round(r["prof_step_ms"], 3) for r in per_rank],
+                "comm_timeouts": [r["comm_timeouts"] for r in per_rank],
+                "note": "one untimed step with HIP events around every launch; comm_ms includes the wait for the peers; classes on "
+                        "different streams overlap, so they do not add up to the step",
+            }
+            out["model_terms_us_n32768_w8"] = MODEL_TERMS_US
+        if args.verify:
+            out["verify_rel_err"] = [r["verify"] for r in per_rank]
+        if not args.no_cpu_baseline and world == 1 and mode == "solo":  # the CPU leg is timed at N = 1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, d, 256, cfg)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
     chol.free()
     ctx.close()
-    if use_dist:
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--d", type=int, default=16)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--nb", type=int, default=0, help="outer Cholesky block; 0 = the library's choice (1024 on one GPU at this size, 512 sharded)")
+    ap.add_argument("--dist-schedule", type=int, default=-1, help="N > 1, the FIRST schedule tried (the preflight falls back to the lower ones): 0 = one broadcast per panel; 1 = diagonal block broadcast + rows scattered / solved per rank / all-gathered; 2 = as 1 with the diagonal chain running ahead; -1 = 2")
+    ap.add_argument("--preflight-n", type=int, default=4096, help="N > 1: rows of the sharded fit every candidate schedule has to get right first")
+    ap.add_argument("--preflight-timeout-ms", type=int, default=20000, help="N > 1: the library's collective time-out during the preflight")
+    ap.add_argument("--comm-timeout-ms", type=int, default=60000, help="N > 1: the library's collective time-out during the measurement")
+    ap.add_argument("--local-ranks", type=int, default=0, help="TEST MODE: that many thread-ranks on ONE GPU over the library's in-process transport instead of one process per GPU")
+    ap.add_argument("--verify", action="store_true", help="after the measurement, compare every rank's predictions with a single-rank fit on the same GPU (verify_rel_err)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (latencies of small predicts, gradient terms)")
+    ap.add_argument("--cpu-sample-n", type=int, default=5120)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    import torch
+
+    from friedrich_amd import sharding
+
+    emit = lambda line: print(line, flush=True)
+    if args.local_ranks > 1:
+        # thread-ranks: the whole N > 1 path of this file (preflight, fall-back, per-rank breakdown) on the one GPU of a test box
+        import threading
+
+        torch.cuda.set_device(local_rank)
+        shared = sharding.ThreadShared(args.local_ranks)
+        errors = []
+
+        def worker(r):
+            try:
+                run_rank(args, sharding.ThreadLink(shared, r), local_rank, emit, "threads")
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                shared.barrier.abort()
+
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(args.local_ranks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return
+
+    torch.cuda.set_device(local_rank)
+    # FRIEDRICH_BENCH_FORCE_DIST=1 takes the multi-process set-up (process group, ncclUniqueId hand-over, communicator
+    # self-test) with a single rank too: the only way to exercise it on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("FRIEDRICH_BENCH_FORCE_DIST") == "1"
+    if not use_dist:
+        run_rank(args, sharding.SoloLink(), local_rank, emit, "solo")
+        return
+    import datetime
+
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # control plane: a gloo group (CPU side) -- agreement between the ranks must not depend on the communicator under test
+    ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+    try:
+        run_rank(args, sharding.TorchLink(dist, rank, world, ctl), local_rank, emit, "process" if world > 1 else "process_forced")
         dist.barrier()
+    finally:
         dist.destroy_process_group()
 
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "fr_ctx_comm_init_local": (_int, [_vp, _int, _int, _int]),
     "fr_ctx_comm_info": (_int, [_vp, _pint, _pint]),
     "fr_ctx_comm_selftest": (_int, [_vp]),
+    "fr_ctx_comm_finalize": (_int, [_vp, _int]),
     "fr_inputs_to_device": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _pp, _pi64]),
     "fr_device_free": (None, [_vp, _vp]),
     "fr_linear_prior_fit": (_int, [_vp, _dp, _i64, _i64, _i64, _dp, _pdbl, _pdbl]),

@@ -225,6 +225,7 @@ static int potrf_dist_chain(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64
     const int W = ctx->world, me = ctx->rank;
     if (nb % IB != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "multi-GPU factorisation needs nb %% 128 == 0");
     hipStream_t S0 = ctx->stream, S1 = ctx->stream2, S3 = ctx->stream3;
+    FR_TRY(ensure_comm2(ctx));  // (collective; created on the first factorisation that takes this schedule)
     for (int kind = 0; kind < 5; ++kind)
         for (int i = 0; i < 4; ++i)
             if (!ctx->ev_ring[kind][i]) FR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ring[kind][i], hipEventDisableTiming));
@@ -254,8 +255,7 @@ static int potrf_dist_chain(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64
         comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
         ctx->ls = S0;
         ctx->reserve_now = 0;
-        (void)hipStreamSynchronize(S1);
-        (void)hipStreamSynchronize(S3);
+        comm_drain(ctx);
         return code;
     };
 #define CH_HIP(call)                              \
@@ -463,11 +463,15 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         ctx->claim_next = 0;
     }
     auto fail = [&](int code) {
-        if (world > 1) comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
         ctx->ls = S0;
         ctx->reserve_now = 0;
         ctx->cols_final_at = -1;
-        (void)hipStreamSynchronize(S1);
+        if (world > 1) {
+            comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
+            comm_drain(ctx);
+        } else {
+            (void)hipStreamSynchronize(S1);
+        }
         return code;
     };
     // the panel stream starts after everything already queued on the main stream (Gram assembly)
@@ -1023,7 +1027,7 @@ int chol_fetch_info(fr_chol* c)
     fr_ctx* ctx = c->ctx;
     int64_t head[3] = {0, 0, 0};
     FR_HIP(ctx, hipMemcpyAsync(head, c->info, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
-    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FR_TRY(comm_stream_sync(ctx, ctx->stream, "the sharded factorisation"));  // (single rank: a plain hipStreamSynchronize)
     FR_TRY(check_status_word(ctx));  // a bounded device-side wait of the factorisation (hand-offs, counted tiles) gave up
     c->fail_col = head[0] - 1;
     c->n_subst = head[1];
@@ -1054,7 +1058,7 @@ static int merge_info(fr_chol* c)
     FR_TRY(comm_allgather_i64(ctx, c->info, all, (size_t)len));
     std::vector<int64_t> host((size_t)(len * W));
     FR_HIP(ctx, hipMemcpyAsync(host.data(), all, sizeof(int64_t) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
-    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FR_TRY(comm_stream_sync(ctx, ctx->stream, "the merge of the substitution logs"));
     FR_TRY(check_status_word(ctx));  // a bounded device-side wait of the factorisation (hand-offs, counted tiles) gave up
     int64_t fail = -1;
     std::vector<int64_t> subst;

@@ -10,11 +10,13 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "fr_internal.hpp"
 #include <vector>
@@ -34,6 +36,7 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional
 };
 
 static RcclApi g_rccl;
@@ -63,6 +66,7 @@ static int rccl_load(fr_ctx* ctx)
     LOAD(GroupEnd);
     LOAD(GetErrorString);
 #undef LOAD
+    g_rccl.CommGetAsyncError = (decltype(g_rccl.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
     g_rccl.handle = h;
     return FR_OK;
 }
@@ -74,7 +78,144 @@ static int rccl_load(fr_ctx* ctx)
             return set_err((ctx), FR_RCCL_ERROR, "%s failed: %s", #call, g_rccl.GetErrorString(r__)); \
     } while (0)
 
+static inline int64_t now_ms()
+{
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- watchdog ------------------------------------------------------------------------------------------
+// RCCL collectives have no timeout.  Two ways a sharded factorisation can wait forever, two guards:
+//   * on the DEVICE: a collective kernel spins for a peer that never arrives -> the stream never drains.  The host thread
+//     never waits for such a stream with hipStreamSynchronize; it polls (comm_stream_sync) and, past the deadline
+//     (option "comm_timeout_ms"), aborts both communicators itself -- ncclCommAbort makes the pending kernels exit -- and
+//     returns FR_RCCL_ERROR.
+//   * on the HOST: a call into RCCL blocks (connection set-up with a peer that never calls).  The thread that is stuck
+//     cannot help itself, so every context with a communicator has a watchdog thread.  The host thread brackets each RCCL
+//     call with a sequence number (CallGuard); a call in progress for longer than the deadline is aborted from the
+//     watchdog -- the documented use of ncclCommAbort from a second thread.  Ownership of the communicators passes by a
+//     compare-and-swap on that sequence number: either the host thread leaves the call first (the watchdog's swap fails, it
+//     does nothing), or the watchdog wins and the host thread, when its call returns, waits for the abort to finish and never
+//     touches the handles again.
+// After either, the context is "lost" (every collective fails at once) until the host calls fr_ctx_comm_finalize and attaches
+// a new communicator; bench.py then falls back to a more conservative schedule (friedrich_amd/sharding.py: guarded_schedule).
+constexpr uint64_t kWatchAborting = ~uint64_t(0);
+
+struct CommWatch {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    std::atomic<uint64_t> call{0};  // sequence number of the RCCL host call in progress; 0: none; kWatchAborting: the watchdog took over
+    std::atomic<int64_t> call_t0{0};
+    std::atomic<int> aborted{0};    // the watchdog has torn the communicators down
+    uint64_t seq = 0;
+};
+
+static void abort_handles(fr_ctx* ctx)
+{
+    if (ctx->comm2 && g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)ctx->comm2);
+    if (ctx->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)ctx->comm);
+    ctx->comm2 = nullptr;
+    ctx->comm = nullptr;
+}
+
+static void watch_main(fr_ctx* ctx, CommWatch* w)
+{
+    std::unique_lock<std::mutex> lk(w->m);
+    while (!w->stop) {
+        w->cv.wait_for(lk, std::chrono::milliseconds(25));
+        if (w->stop) break;
+        const uint64_t c = w->call.load();
+        const int64_t T = ctx->comm_timeout_ms;
+        if (c == 0 || c == kWatchAborting || T <= 0) continue;
+        if (now_ms() - w->call_t0.load() < T) continue;
+        uint64_t expect = c;
+        if (!w->call.compare_exchange_strong(expect, kWatchAborting)) continue;  // the call returned in the meantime
+        abort_handles(ctx);  // (the host thread is inside RCCL and touches the handles no more: see CallGuard)
+        ++ctx->comm_timeouts;
+        w->aborted.store(1);
+    }
+}
+
+static void watch_start(fr_ctx* ctx)
+{
+    if (ctx->watch) return;
+    CommWatch* w = new CommWatch();
+    ctx->watch = w;
+    w->th = std::thread(watch_main, ctx, w);
+}
+
+static void watch_stop(fr_ctx* ctx)
+{
+    CommWatch* w = (CommWatch*)ctx->watch;
+    if (!w) return;
+    {
+        std::lock_guard<std::mutex> lk(w->m);
+        w->stop = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+    delete w;
+    ctx->watch = nullptr;
+}
+
+// Brackets the RCCL host calls of one collective.
+struct CallGuard {
+    fr_ctx* ctx;
+    CommWatch* w;
+    uint64_t mine = 0;
+    explicit CallGuard(fr_ctx* c) : ctx(c), w((CommWatch*)c->watch)
+    {
+        if (!w) return;
+        mine = ++w->seq;
+        w->call_t0.store(now_ms());
+        w->call.store(mine);
+    }
+    ~CallGuard()
+    {
+        if (!w) return;
+        uint64_t expect = mine;
+        if (w->call.compare_exchange_strong(expect, 0)) return;
+        // the watchdog decided this call was stuck and is tearing the communicators down (or has): wait for it, then mark
+        // the context; the handles are gone
+        while (!w->aborted.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        ctx->comm_lost = true;
+        set_err(ctx, FR_RCCL_ERROR, "an RCCL call did not return within %lld ms (dist_schedule %lld): communicators aborted by the watchdog",
+                (long long)ctx->comm_timeout_ms, (long long)ctx->dist_schedule);
+    }
+};
+
+// ---- test hook: one rank goes missing ------------------------------------------------------------------------
+// FRIEDRICH_AMD_TEST_COMM_HANG = "schedule,rank,nth": while the context runs dist_schedule `schedule`, rank `rank` does not take
+// part in its nth collective (counted from 1 over the context's life) -- it stalls instead, the way a crashed or wedged peer
+// would -- so that the tests can watch the time-outs and the schedule fall-back work.  Returns true when the call is the one.
+static bool test_hang_hit(fr_ctx* ctx)
+{
+    if (ctx->test_hang_nth <= 0 || ctx->dist_schedule != ctx->test_hang_schedule || ctx->rank != ctx->test_hang_rank) return false;
+    return ++ctx->test_comm_calls == ctx->test_hang_nth;
+}
+
+static int test_hang_stall(fr_ctx* ctx)
+{
+    const int64_t T = ctx->comm_timeout_ms > 0 ? ctx->comm_timeout_ms : 2000;
+    std::this_thread::sleep_for(std::chrono::milliseconds(T + T / 2 + 200));
+    comm_abort(ctx);
+    return set_err(ctx, FR_RCCL_ERROR, "injected hang (FRIEDRICH_AMD_TEST_COMM_HANG): this rank skipped a collective");
+}
+
 // ---- local transport ---------------------------------------------------------------------------------
+// Default: ASYNCHRONOUS -- like RCCL, a collective is work enqueued on the calling rank's stream and ordered against the
+// peers' streams by events, never by waiting for a stream on the host: a rank records "my buffer is ready" on its stream,
+// the ranks exchange {pointer, events} through a host rendezvous (host threads stay in step per collective; the DEVICE
+// work does not), every receiver makes its stream wait for the sender's event, copies device-to-device on its own stream
+// and records "I have read it", and after a second rendezvous the sender's stream waits for those.  A missing event
+// dependency BETWEEN THE STREAMS OF ONE RANK (chain / bulk / main) therefore shows up here as a wrong factor, exactly as it
+// would over RCCL -- round 3's transport synchronised the stream around every collective and could not expose one.
+// FRIEDRICH_AMD_LOCAL_SYNC=1 restores that behaviour (debugging aid).
+struct LocalPub {
+    const void* ptr = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+};
 struct LocalGroup {
     int world = 0;
     int attached = 0;
@@ -82,29 +223,36 @@ struct LocalGroup {
     std::condition_variable cv;
     int arrived = 0;
     uint64_t gen = 0;
-    const void* ptrs[2][64] = {{nullptr}};  // double-buffered by barrier generation parity
+    LocalPub pubs[2][64];  // double-buffered by barrier generation parity
     bool broken = false;
+    bool async = true;
 };
 struct LocalComm {
     LocalGroup* g;
     int group_id;
+    hipEvent_t ready = nullptr, done = nullptr;
 };
 
 static std::mutex g_local_mutex;
 static std::map<int, LocalGroup*> g_local_groups;
 
-// host barrier; every rank publishes one pointer first and gets a snapshot of all of them (taken from the slot of
-// THIS barrier generation: a fast rank entering the next barrier writes the other slot).  false on timeout.
-static bool local_barrier(LocalGroup* g, int rank, const void* publish, const void** snapshot = nullptr)
+// host rendezvous; every rank publishes {pointer, events} first and gets a snapshot of all of them (taken from the slot of
+// THIS generation: a fast rank entering the next rendezvous writes the other slot).  false on timeout / broken group.
+static bool local_barrier(fr_ctx* ctx, const void* publish, LocalPub* snapshot = nullptr)
 {
+    LocalComm* lc = (LocalComm*)ctx->local;
+    LocalGroup* g = lc->g;
+    const int rank = ctx->rank;
     std::unique_lock<std::mutex> lk(g->m);
     if (g->broken) return false;
     const uint64_t my_gen = g->gen;
-    const void** slot = g->ptrs[my_gen & 1];
-    slot[rank] = publish;
+    LocalPub* slot = g->pubs[my_gen & 1];
+    slot[rank].ptr = publish;
+    slot[rank].ready = lc->ready;
+    slot[rank].done = lc->done;
     struct Snap {
-        const void** dst;
-        const void** src;
+        LocalPub* dst;
+        LocalPub* src;
         int n;
         ~Snap()
         {
@@ -118,8 +266,10 @@ static bool local_barrier(LocalGroup* g, int rank, const void* publish, const vo
         g->cv.notify_all();
         return true;
     }
-    const bool ok = g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->gen != my_gen || g->broken; });
+    const int64_t T = ctx->comm_timeout_ms > 0 ? ctx->comm_timeout_ms : 120000;
+    const bool ok = g->cv.wait_for(lk, std::chrono::milliseconds(T), [&] { return g->gen != my_gen || g->broken; });
     if (!ok || g->broken) {
+        if (!ok) ++ctx->comm_timeouts;
         g->broken = true;
         g->cv.notify_all();
         return false;
@@ -127,49 +277,69 @@ static bool local_barrier(LocalGroup* g, int rank, const void* publish, const vo
     return true;
 }
 
-static int local_bcast(fr_ctx* ctx, void* buf, size_t bytes, int root)
+static int local_fail(fr_ctx* ctx, const char* what)
 {
-    LocalGroup* g = ((LocalComm*)ctx->local)->g;
-    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
-    const void* all[64];
-    if (!local_barrier(g, ctx->rank, buf, all)) return set_err(ctx, FR_RCCL_ERROR, "local broadcast: barrier timed out");
-    const void* src = all[root];
-    if (ctx->rank != root && bytes > 0) {
-        FR_HIP(ctx, hipMemcpyAsync(buf, src, bytes, hipMemcpyDeviceToDevice, ctx->ls));
-        FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    ctx->comm_lost = true;
+    return set_err(ctx, FR_RCCL_ERROR, "local %s: a peer did not arrive within %lld ms (dist_schedule %lld)", what,
+                   (long long)(ctx->comm_timeout_ms > 0 ? ctx->comm_timeout_ms : 120000), (long long)ctx->dist_schedule);
+}
+
+// one transfer pattern for broadcast / fan-out (slices = 0: the whole buffer from the root), scatter (slice `rank` of the
+// root's buffer to the same place of rank's) and all-gather (root < 0: slice r of rank r's `send` to recv + r * bytes)
+static int local_exchange(fr_ctx* ctx, const char* what, const void* send, void* recv, size_t bytes, int root, bool sliced)
+{
+    LocalComm* lc = (LocalComm*)ctx->local;
+    LocalGroup* g = lc->g;
+    const int W = g->world, me = ctx->rank;
+    const bool async = g->async;
+    hipStream_t s = ctx->ls;
+    if (async)
+        FR_HIP(ctx, hipEventRecord(lc->ready, s));  // everything this rank contributes is ahead of this point on its stream
+    else
+        FR_HIP(ctx, hipStreamSynchronize(s));
+    LocalPub all[64];
+    if (!local_barrier(ctx, send, all)) return local_fail(ctx, what);
+    auto pull = [&](int from, const char* src, char* dst, size_t nbytes) -> int {
+        if (nbytes == 0 || src == dst) return FR_OK;  // (in place: the own slice is already there)
+        if (async && from != me) FR_HIP(ctx, hipStreamWaitEvent(s, all[from].ready, 0));
+        FR_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, s));
+        return FR_OK;
+    };
+    if (root >= 0) {
+        if (me != root) {
+            const size_t off = sliced ? (size_t)me * bytes : 0;
+            FR_TRY(pull(root, (const char*)all[root].ptr + off, (char*)recv + off, bytes));
+        }
+    } else {
+        for (int r = 0; r < W; ++r) FR_TRY(pull(r, (const char*)all[r].ptr, (char*)recv + (size_t)r * bytes, bytes));
     }
-    if (!local_barrier(g, ctx->rank, nullptr)) return set_err(ctx, FR_RCCL_ERROR, "local broadcast: barrier timed out");
+    if (async)
+        FR_HIP(ctx, hipEventRecord(lc->done, s));  // this rank has read what it wanted from its peers
+    else
+        FR_HIP(ctx, hipStreamSynchronize(s));
+    if (!local_barrier(ctx, nullptr, nullptr)) return local_fail(ctx, what);
+    if (async) {
+        // a sender's buffer may be overwritten by its later stream work only after every reader is done with it
+        if (root >= 0) {
+            if (me == root)
+                for (int r = 0; r < W; ++r)
+                    if (r != me) FR_HIP(ctx, hipStreamWaitEvent(s, all[r].done, 0));
+        } else {
+            for (int r = 0; r < W; ++r)
+                if (r != me) FR_HIP(ctx, hipStreamWaitEvent(s, all[r].done, 0));
+        }
+    }
     return FR_OK;
 }
 
+static int local_bcast(fr_ctx* ctx, void* buf, size_t bytes, int root) { return local_exchange(ctx, "broadcast", buf, buf, bytes, root, false); }
 static int local_allgather(fr_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank)
 {
-    LocalGroup* g = ((LocalComm*)ctx->local)->g;
-    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
-    const void* srcs[64];
-    if (!local_barrier(g, ctx->rank, send, srcs)) return set_err(ctx, FR_RCCL_ERROR, "local allgather: barrier timed out");
-    for (int r = 0; r < g->world; ++r)
-        if (bytes_per_rank > 0 && (const char*)srcs[r] != (const char*)recv + (size_t)r * bytes_per_rank)  // (in place: own slice already there)
-            FR_HIP(ctx, hipMemcpyAsync((char*)recv + (size_t)r * bytes_per_rank, srcs[r], bytes_per_rank,
-                                       hipMemcpyDeviceToDevice, ctx->ls));
-    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
-    if (!local_barrier(g, ctx->rank, nullptr)) return set_err(ctx, FR_RCCL_ERROR, "local allgather: barrier timed out");
-    return FR_OK;
+    return local_exchange(ctx, "all-gather", send, recv, bytes_per_rank, -1, true);
 }
-
 static int local_scatter(fr_ctx* ctx, char* buf, size_t bytes_per_rank, int root)
 {
-    LocalGroup* g = ((LocalComm*)ctx->local)->g;
-    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
-    const void* all[64];
-    if (!local_barrier(g, ctx->rank, buf, all)) return set_err(ctx, FR_RCCL_ERROR, "local scatter: barrier timed out");
-    if (ctx->rank != root && bytes_per_rank > 0) {
-        const size_t off = (size_t)ctx->rank * bytes_per_rank;
-        FR_HIP(ctx, hipMemcpyAsync(buf + off, (const char*)all[root] + off, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->ls));
-        FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
-    }
-    if (!local_barrier(g, ctx->rank, nullptr)) return set_err(ctx, FR_RCCL_ERROR, "local scatter: barrier timed out");
-    return FR_OK;
+    return local_exchange(ctx, "scatter", buf, buf, bytes_per_rank, root, true);
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------
@@ -182,14 +352,25 @@ static int local_scatter(fr_ctx* ctx, char* buf, size_t bytes_per_rank, int root
 // the head of its queue on every rank.
 static inline ncclComm_t pick_comm(fr_ctx* ctx, int which) { return (ncclComm_t)((which == 1 && ctx->comm2) ? ctx->comm2 : ctx->comm); }
 
+// common prologue of every collective: a lost communicator fails at once (never a silent single-rank no-op), the test hook
+#define COMM_ENTER(ctx)                                                                                                   \
+    do {                                                                                                                  \
+        if ((ctx)->comm_lost || (!(ctx)->comm && !(ctx)->local))                                                          \
+            return set_err((ctx), FR_RCCL_ERROR, "the communicator of this context was aborted (time-out or failed peer): " \
+                                                 "call fr_ctx_comm_finalize and attach a new one");                      \
+        if (test_hang_hit(ctx)) return test_hang_stall(ctx);                                                              \
+    } while (0)
+
 // Scatter: slice r (count doubles at buf + r * count) of the ROOT's buffer lands in the same place of rank r's buffer.
 // RCCL: one grouped set of point-to-point sends from the root, each over its own xGMI link.
 int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root, int which)
 {
     if (ctx->world <= 1 || count_per_rank == 0) return FR_OK;
+    COMM_ENTER(ctx);
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count_per_rank * (ctx->world - 1));
     if (ctx->local) return local_scatter(ctx, (char*)buf, 8 * count_per_rank, root);
     ncclComm_t comm = pick_comm(ctx, which);
+    CallGuard guard(ctx);
     FR_NCCL(ctx, g_rccl.GroupStart());
     if (ctx->rank == root) {
         for (int r = 0; r < ctx->world; ++r)
@@ -208,9 +389,11 @@ int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root, int 
 int comm_fanout(fr_ctx* ctx, double* buf, size_t count, int root, int which)
 {
     if (ctx->world <= 1 || count == 0) return FR_OK;
+    COMM_ENTER(ctx);
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count * (ctx->world - 1));
     if (ctx->local) return local_bcast(ctx, buf, 8 * count, root);
     ncclComm_t comm = pick_comm(ctx, which);
+    CallGuard guard(ctx);
     FR_NCCL(ctx, g_rccl.GroupStart());
     if (ctx->rank == root) {
         for (int r = 0; r < ctx->world; ++r)
@@ -225,8 +408,10 @@ int comm_fanout(fr_ctx* ctx, double* buf, size_t count, int root, int which)
 int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root)
 {
     if (ctx->world <= 1) return FR_OK;
+    COMM_ENTER(ctx);
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count);
     if (ctx->local) return local_bcast(ctx, buf, 8 * count, root);
+    CallGuard guard(ctx);
     FR_NCCL(ctx, g_rccl.Broadcast(buf, buf, count, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
@@ -238,7 +423,9 @@ int comm_allgather_i64(fr_ctx* ctx, const int64_t* send, int64_t* recv, size_t c
             FR_HIP(ctx, hipMemcpyAsync(recv, send, 8 * count_per_rank, hipMemcpyDeviceToDevice, ctx->ls));
         return FR_OK;
     }
+    COMM_ENTER(ctx);
     if (ctx->local) return local_allgather(ctx, send, recv, 8 * count_per_rank);
+    CallGuard guard(ctx);
     FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclInt64, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
@@ -250,15 +437,68 @@ int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_p
             FR_HIP(ctx, hipMemcpyAsync(recv, send, 8 * count_per_rank, hipMemcpyDeviceToDevice, ctx->ls));
         return FR_OK;
     }
+    COMM_ENTER(ctx);
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count_per_rank * ctx->world);
     if (ctx->local) return local_allgather(ctx, send, recv, 8 * count_per_rank);
+    CallGuard guard(ctx);
     FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, pick_comm(ctx, which), ctx->ls));
     return FR_OK;
 }
 
+// After an abort the collectives in flight end (RCCL: their kernels see the abort flag) and the library's own device-side
+// waits are bounded, so the streams empty; should they not (a wedged device), the host does not wait for ever either.
+void comm_drain(fr_ctx* ctx)
+{
+    const int64_t t0 = now_ms();
+    for (hipStream_t q : {ctx->stream2, ctx->stream3, ctx->stream}) {
+        while (q && hipStreamQuery(q) == hipErrorNotReady && now_ms() - t0 < 20000) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        (void)hipGetLastError();
+    }
+}
+
+// Wait for a stream that may hold collectives -- never with hipStreamSynchronize alone: a collective whose peer never arrives
+// would keep the host there for ever.  Polls; past the deadline (option "comm_timeout_ms", 0 = wait for ever) or on an
+// asynchronous RCCL error the communicators are aborted (the pending collective kernels then exit), the streams are given a
+// bounded time to drain, and the caller gets FR_RCCL_ERROR.
+int comm_stream_sync(fr_ctx* ctx, hipStream_t s, const char* what)
+{
+    if (ctx->world <= 1 || ctx->comm_timeout_ms <= 0 || ctx->local || !ctx->comm) {
+        FR_HIP(ctx, hipStreamSynchronize(s));
+        return FR_OK;
+    }
+    const int64_t t0 = now_ms();
+    int spins = 0;
+    const char* why = "timed out";
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return FR_OK;
+        if (e != hipErrorNotReady) return set_err(ctx, FR_HIP_ERROR, "hipStreamQuery failed while waiting for %s: %s", what, hipGetErrorString(e));
+        (void)hipGetLastError();
+        if (++spins > 2000) {  // (the first ~ms by yielding: the common case is a wait of a few hundred microseconds)
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if ((spins & 1023) == 0 && g_rccl.CommGetAsyncError && ctx->comm) {
+                ncclResult_t ar = ncclSuccess;
+                if (g_rccl.CommGetAsyncError((ncclComm_t)ctx->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                    why = "reported an asynchronous RCCL error";
+                    break;
+                }
+            }
+        } else {
+            std::this_thread::yield();
+        }
+        if (now_ms() - t0 > ctx->comm_timeout_ms) break;
+    }
+    ++ctx->comm_timeouts;
+    const int64_t waited = now_ms() - t0;
+    comm_abort(ctx);
+    comm_drain(ctx);
+    return set_err(ctx, FR_RCCL_ERROR, "%s %s after %lld ms (dist_schedule %lld, rank %d of %d): communicators aborted", what, why,
+                   (long long)waited, (long long)ctx->dist_schedule, ctx->rank, ctx->world);
+}
+
 // Every rank contributes ok (1) / failed (0); all learn whether EVERY rank is ok.  Used before the first panel exchange of a
-// sharded factorisation: a rank that could not allocate its buffers must not leave its peers waiting inside a broadcast
-// (RCCL collectives have no timeout).  Synchronises the launch stream.
+// sharded factorisation: a rank that could not allocate its buffers must not leave its peers waiting inside a broadcast.
+// Synchronises the launch stream (with the deadline).
 int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok)
 {
     *all_ok = ok;
@@ -269,26 +509,25 @@ int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok)
     FR_TRY(comm_allgather_i64(ctx, ctx->agree_buf, ctx->agree_buf + 1, 1));
     std::vector<int64_t> h((size_t)ctx->world);
     FR_HIP(ctx, hipMemcpyAsync(h.data(), ctx->agree_buf + 1, sizeof(int64_t) * h.size(), hipMemcpyDeviceToHost, ctx->ls));
-    FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+    FR_TRY(comm_stream_sync(ctx, ctx->ls, "status agreement of the ranks"));
     for (int64_t v : h)
         if (v != 1) *all_ok = false;
     return FR_OK;
 }
 
-// A rank that fails on the host side in the middle of a sharded factorisation tears its communicator down instead of
-// leaving through a normal return: its peers' pending collectives then end in an error (RCCL) / a broken barrier (local
-// transport) rather than waiting forever.  The context cannot take part in collectives afterwards.
+// A rank that fails on the host side in the middle of a sharded factorisation -- or whose wait ran out -- tears its
+// communicators down instead of leaving through a normal return: its peers' pending collectives then end in an error (RCCL)
+// / a broken rendezvous (local transport) rather than waiting forever.  The context keeps its rank and world size but is
+// "lost": every collective fails until fr_ctx_comm_finalize.
 void comm_abort(fr_ctx* ctx)
 {
-    if (ctx->comm2 && g_rccl.CommAbort) {
-        (void)g_rccl.CommAbort((ncclComm_t)ctx->comm2);
-        ctx->comm2 = nullptr;
-    }
-    if (ctx->comm && g_rccl.CommAbort) {
-        (void)g_rccl.CommAbort((ncclComm_t)ctx->comm);
-        ctx->comm = nullptr;
-        ctx->world = 1;
-        ctx->rank = 0;
+    CommWatch* w = (CommWatch*)ctx->watch;
+    if (ctx->comm || ctx->comm2) {
+        if (w && w->aborted.load()) {
+            ctx->comm = ctx->comm2 = nullptr;  // (the watchdog has done it)
+        } else {
+            abort_handles(ctx);
+        }
     }
     if (ctx->local) {
         LocalGroup* g = ((LocalComm*)ctx->local)->g;
@@ -296,6 +535,53 @@ void comm_abort(fr_ctx* ctx)
         g->broken = true;
         g->cv.notify_all();
     }
+    ctx->comm_lost = true;
+}
+
+// Second communicator over the same ranks (bulk stream of the chain-first schedule), created on first use: its id is drawn
+// by rank 0 and travels over the first communicator.  Collective: every rank of the first communicator calls it at the same
+// point of its host program (the start of a schedule-2 factorisation / the self-test), and every rank takes part in the
+// broadcast and the CommInitRank whatever happened locally before -- a zeroed id tells the peers that rank 0 could not draw
+// one -- so that no rank is left waiting; the ranks then agree on the outcome.
+int ensure_comm2(fr_ctx* ctx)
+{
+    if (ctx->world <= 1 || ctx->local || ctx->comm2) return FR_OK;
+    COMM_ENTER(ctx);
+    if (!ctx->agree_buf) FR_HIP(ctx, hipMalloc((void**)&ctx->agree_buf, sizeof(int64_t) * 65));
+    static_assert(sizeof(ncclUniqueId) <= sizeof(int64_t) * 64, "id fits the agreement buffer");
+    ncclUniqueId id2;
+    memset(&id2, 0, sizeof(id2));
+    if (ctx->rank == 0 && g_rccl.GetUniqueId(&id2) != ncclSuccess) memset(&id2, 0, sizeof(id2));
+    void* d = ctx->agree_buf + 1;
+    hipStream_t s = ctx->stream;
+    FR_HIP(ctx, hipMemcpyAsync(d, &id2, sizeof(id2), hipMemcpyHostToDevice, s));
+    {
+        CallGuard guard(ctx);
+        FR_NCCL(ctx, g_rccl.Broadcast(d, d, sizeof(id2), ncclChar, 0, (ncclComm_t)ctx->comm, s));
+    }
+    FR_HIP(ctx, hipMemcpyAsync(&id2, d, sizeof(id2), hipMemcpyDeviceToHost, s));
+    FR_TRY(comm_stream_sync(ctx, s, "hand-over of the second communicator's id"));
+    bool id_ok = false;
+    for (size_t i = 0; i < sizeof(id2); ++i) id_ok = id_ok || ((const char*)&id2)[i] != 0;
+    ncclComm_t comm2 = nullptr;
+    bool ok = id_ok;
+    if (id_ok) {
+        CallGuard guard(ctx);
+        ok = g_rccl.CommInitRank(&comm2, ctx->world, id2, ctx->rank) == ncclSuccess;
+    }
+    if (ctx->comm_lost) return FR_RCCL_ERROR;
+    bool all_ok = false;
+    hipStream_t saved = ctx->ls;
+    ctx->ls = s;
+    const int st = comm_agree(ctx, ok, &all_ok);
+    ctx->ls = saved;
+    if (st != FR_OK || !all_ok) {
+        if (comm2) (void)g_rccl.CommAbort(comm2);
+        if (st != FR_OK) return st;
+        return set_err(ctx, FR_RCCL_ERROR, id_ok ? "a rank could not create the second communicator" : "rank 0 could not draw an id for the second communicator");
+    }
+    ctx->comm2 = comm2;
+    return FR_OK;
 }
 
 }  // namespace fr
@@ -304,24 +590,30 @@ using namespace fr;
 
 extern "C" {
 
-void fr_comm_destroy_internal(fr_ctx* ctx)
+static void comm_release(fr_ctx* ctx, bool abort)
 {
-    if (ctx->comm2 && g_rccl.CommDestroy) {
-        g_rccl.CommDestroy((ncclComm_t)ctx->comm2);
+    watch_stop(ctx);  // first: nobody else touches the handles from here on
+    if (ctx->comm2) {
+        if (abort && g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)ctx->comm2);
+        else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)ctx->comm2);
         ctx->comm2 = nullptr;
     }
-    if (ctx->comm && g_rccl.CommDestroy) {
-        g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    if (ctx->comm) {
+        if (abort && g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)ctx->comm);
+        else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
-    }
-    if (ctx->agree_buf) {
-        (void)hipFree(ctx->agree_buf);
-        ctx->agree_buf = nullptr;
     }
     if (ctx->local) {
         LocalComm* lc = (LocalComm*)ctx->local;
+        if (lc->ready) (void)hipEventDestroy(lc->ready);
+        if (lc->done) (void)hipEventDestroy(lc->done);
         {
             std::lock_guard<std::mutex> lk(g_local_mutex);
+            if (abort) {
+                std::lock_guard<std::mutex> lk2(lc->g->m);
+                lc->g->broken = true;
+                lc->g->cv.notify_all();
+            }
             if (--lc->g->attached == 0) {
                 g_local_groups.erase(lc->group_id);
                 delete lc->g;
@@ -330,6 +622,30 @@ void fr_comm_destroy_internal(fr_ctx* ctx)
         delete lc;
         ctx->local = nullptr;
     }
+    ctx->comm_lost = false;
+    ctx->rank = 0;
+    ctx->world = 1;
+}
+
+void fr_comm_destroy_internal(fr_ctx* ctx)
+{
+    comm_release(ctx, ctx->comm_lost);
+    if (ctx->agree_buf) {
+        (void)hipFree(ctx->agree_buf);
+        ctx->agree_buf = nullptr;
+    }
+}
+
+int fr_ctx_comm_finalize(fr_ctx* ctx, int abort)
+{
+    if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
+    (void)hipSetDevice(ctx->device);
+    // whatever the communicator still had in flight is either complete or, with `abort`, about to be cut short
+    if (abort || ctx->comm_lost) comm_abort(ctx);
+    comm_drain(ctx);
+    comm_release(ctx, abort != 0 || ctx->comm_lost);
+    return FR_OK;
 }
 
 int fr_comm_unique_id(void* out_id)
@@ -348,7 +664,7 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
     if (!ctx || world_size < 1 || rank < 0 || rank >= world_size) return FR_INVALID_ARGUMENT;
     FR_LOCK(ctx);
     FR_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->comm || ctx->local) return set_err(ctx, FR_INVALID_ARGUMENT, "communicator already initialised");
+    if (ctx->comm || ctx->local || ctx->comm_lost) return set_err(ctx, FR_INVALID_ARGUMENT, "communicator already initialised (fr_ctx_comm_finalize first)");
     if (world_size == 1 && !unique_id) {
         ctx->rank = 0;
         ctx->world = 1;
@@ -356,6 +672,8 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
     }
     if (!unique_id) return FR_INVALID_ARGUMENT;
     FR_TRY(rccl_load(ctx));
+    // (the one device buffer the communicator's own hand-shakes need, BEFORE any rank can be left waiting for this one)
+    if (!ctx->agree_buf) FR_HIP(ctx, hipMalloc((void**)&ctx->agree_buf, sizeof(int64_t) * 65));
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclComm_t comm = nullptr;
@@ -363,26 +681,8 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->world = world_size;
-    if (world_size > 1) {
-        // the second communicator (bulk stream of the chain-first schedule): rank 0 draws its id, the first communicator
-        // carries it to the others
-        ncclUniqueId id2;
-        memset(&id2, 0, sizeof(id2));
-        if (rank == 0) FR_NCCL(ctx, g_rccl.GetUniqueId(&id2));
-        void* d = nullptr;
-        FR_HIP(ctx, hipMalloc(&d, sizeof(id2)));
-        hipError_t e = hipMemcpyAsync(d, &id2, sizeof(id2), hipMemcpyHostToDevice, ctx->stream);
-        ncclResult_t r = ncclSuccess;
-        if (e == hipSuccess) r = g_rccl.Broadcast(d, d, sizeof(id2), ncclChar, 0, comm, ctx->stream);
-        if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(&id2, d, sizeof(id2), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d);
-        if (e != hipSuccess) return set_err(ctx, FR_HIP_ERROR, "handing over the second communicator's id failed: %s", hipGetErrorString(e));
-        if (r != ncclSuccess) return set_err(ctx, FR_RCCL_ERROR, "broadcast of the second communicator's id failed: %s", g_rccl.GetErrorString(r));
-        ncclComm_t comm2 = nullptr;
-        FR_NCCL(ctx, g_rccl.CommInitRank(&comm2, world_size, id2, rank));
-        ctx->comm2 = comm2;
-    }
+    if (world_size > 1) watch_start(ctx);
+    // the second communicator (chain-first schedule only) is created on first use: ensure_comm2
     return FR_OK;
 }
 
@@ -390,18 +690,33 @@ int fr_ctx_comm_init_local(fr_ctx* ctx, int group_id, int rank, int world_size)
 {
     if (!ctx || world_size < 1 || world_size > 64 || rank < 0 || rank >= world_size) return FR_INVALID_ARGUMENT;
     FR_LOCK(ctx);
-    if (ctx->comm || ctx->local) return set_err(ctx, FR_INVALID_ARGUMENT, "communicator already initialised");
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm || ctx->local || ctx->comm_lost) return set_err(ctx, FR_INVALID_ARGUMENT, "communicator already initialised (fr_ctx_comm_finalize first)");
+    hipEvent_t ready = nullptr, done = nullptr;
+    FR_HIP(ctx, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipEventDestroy(ready);
+        return set_err(ctx, FR_HIP_ERROR, "hipEventCreate failed");
+    }
     std::lock_guard<std::mutex> lk(g_local_mutex);
     LocalGroup*& g = g_local_groups[group_id];
     if (!g) {
         g = new LocalGroup();
         g->world = world_size;
+        const char* e = getenv("FRIEDRICH_AMD_LOCAL_SYNC");
+        g->async = !(e && e[0] == '1');
     }
-    if (g->world != world_size) return set_err(ctx, FR_INVALID_ARGUMENT, "local group %d has world size %d", group_id, g->world);
+    if (g->world != world_size) {
+        (void)hipEventDestroy(ready);
+        (void)hipEventDestroy(done);
+        return set_err(ctx, FR_INVALID_ARGUMENT, "local group %d has world size %d", group_id, g->world);
+    }
     g->attached += 1;
     LocalComm* lc = new LocalComm();
     lc->g = g;
     lc->group_id = group_id;
+    lc->ready = ready;
+    lc->done = done;
     ctx->local = lc;
     ctx->rank = rank;
     ctx->world = world_size;
@@ -414,6 +729,7 @@ int fr_ctx_comm_selftest(fr_ctx* ctx)
     FR_LOCK(ctx);
     if (!ctx->comm && !ctx->local) return FR_OK;
     FR_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->dist_schedule == 2) FR_TRY(ensure_comm2(ctx));  // (the chain-first schedule's second communicator: collective)
     const int W = ctx->world, R = ctx->rank;
     const size_t cnt = 256;
     std::vector<double> h(cnt * (size_t)(2 + W));
@@ -438,14 +754,14 @@ int fr_ctx_comm_selftest(fr_ctx* ctx)
         // the chain-first schedule's calls: a fan-out on the first communicator, an (in-place) all-gather on the second
         if (st == FR_OK && W > 1) st = comm_fanout(ctx, d, cnt, 0, 0);  // (point-to-point: needs a real peer)
         if (st == FR_OK && ctx->stream3) {
-            if (hipStreamSynchronize(ctx->ls) != hipSuccess) st = FR_HIP_ERROR;
+            st = comm_stream_sync(ctx, ctx->ls, "communicator self-test");
             ctx->ls = ctx->stream3;
             if (st == FR_OK) st = comm_allgather(ctx, d + (2 + (size_t)ctx->rank) * cnt, d + 2 * cnt, cnt, 1);
-            if (st == FR_OK && hipStreamSynchronize(ctx->ls) != hipSuccess) st = FR_HIP_ERROR;
+            if (st == FR_OK) st = comm_stream_sync(ctx, ctx->ls, "communicator self-test");
         }
         ctx->world = world_saved;
         if (st != FR_OK) break;
-        if (hipStreamSynchronize(ctx->ls) != hipSuccess ||
+        if (comm_stream_sync(ctx, ctx->ls, "communicator self-test") != FR_OK ||
             hipMemcpy(h.data(), d, sizeof(double) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) {
             st = set_err(ctx, FR_HIP_ERROR, "selftest: download failed");
             break;

@@ -390,6 +390,18 @@ int fr_ctx_create(fr_ctx** out, int device)
     if (const char* e = getenv("FRIEDRICH_AMD_TEST_FORCE_SOLVE_TIMEOUT")) ctx->test_force_timeout = e[0] == '1';
     if (const char* e = getenv("FRIEDRICH_AMD_TEST_MAX_WORKGROUPS")) ctx->test_max_wgs = atoi(e);
     if (const char* e = getenv("FRIEDRICH_AMD_SMALL_TILES")) ctx->small_tiles = atoi(e);
+    if (const char* e = getenv("FRIEDRICH_AMD_TEST_COMM_HANG")) {  // "schedule,rank,nth": see comm.hip (test hook)
+        long long a = -1, b = -1, c = 0;
+        if (sscanf(e, "%lld,%lld,%lld", &a, &b, &c) == 3) {
+            ctx->test_hang_schedule = a;
+            ctx->test_hang_rank = b;
+            ctx->test_hang_nth = c;
+        }
+    }
+    if (const char* e = getenv("FRIEDRICH_AMD_COMM_TIMEOUT_MS")) {
+        const long long v = atoll(e);
+        if (v >= 0) ctx->comm_timeout_ms = v;
+    }
     if (const char* e = getenv("FRIEDRICH_AMD_DIST_SCHEDULE")) {  // operator override of the sharded schedule (0, 1, 2) without touching the host program
         const int v = atoi(e);
         if (v >= 0 && v <= 2) ctx->dist_schedule = v;
@@ -402,8 +414,12 @@ int fr_ctx_create(fr_ctx** out, int device)
     ctx->ls = ctx->stream;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+    // Only the panel / chain stream is high-priority.  The bulk stream of the chain-first schedule carries what is explicitly
+    // NOT on the critical path (slice solves, copies, the large collectives): default priority, so that it neither competes
+    // with the chain nor pre-empts the main stream's updates (round 1 measured a busy high-priority queue throttling the
+    // dispatch of the others: +16 % on trailing updates).
     if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_bulk, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_cols, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess ||
@@ -512,6 +528,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->dist_schedule = value;
         return FR_OK;
     }
+    if (!strcmp(name, "comm_timeout_ms")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "comm_timeout_ms must be >= 0 (0: wait for ever)");
+        ctx->comm_timeout_ms = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "splitk")) {
         ctx->splitk = value != 0;
         return FR_OK;
@@ -567,6 +588,10 @@ int fr_ctx_get_counter(fr_ctx* ctx, const char* name, int64_t* out)
     FR_LOCK(ctx);
     if (!strcmp(name, "solve_retries")) {
         *out = ctx->solve_retries;
+        return FR_OK;
+    }
+    if (!strcmp(name, "comm_timeouts")) {
+        *out = ctx->comm_timeouts;
         return FR_OK;
     }
     if (!strcmp(name, "pool_bytes")) {

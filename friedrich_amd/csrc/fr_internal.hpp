@@ -72,9 +72,12 @@ struct fr_ctx {
     // XCD reservation (gemm_f64.hip): the main stream's GEMM launches of a factorisation leave the first `reserve_now` XCDs
     // (counted from the one the diagonal-block kernels run on) to the panel stream -- their workgroups there exit at once
     int64_t xcd_reserve = -1;   // -1: chosen by the factorisation (single GPU, nb <= 512: 1 XCD below 16384 rows, 2 below 8192); 0: never; 1 .. 4: always
-    int64_t dist_schedule = 2;  // sharded factorisation, panel step: 0 owner solves the whole panel + one broadcast; 1 diagonal block
-                                // broadcast, rows scattered / solved per rank / all-gathered; 2 as 1 with the diagonal chain running ahead
-                                // (diagonal block sent to the next owner first, bulk rows on their own stream: chol.hip)
+    int64_t dist_schedule = 1;  // sharded factorisation, panel step: 0 owner solves the whole panel + one broadcast; 1 (default) diagonal
+                                // block broadcast, rows scattered / solved per rank / all-gathered; 2 as 1 with the diagonal chain running
+                                // ahead (diagonal block sent to the next owner first, bulk rows on their own stream: chol.hip) -- opt-in
+                                // until it has run over real RCCL on more than one GPU (bench.py preflights it and falls back)
+    int64_t comm_timeout_ms = 120000;  // sharded operations: how long a wait for a stream holding collectives / a blocked RCCL call may
+                                       // last before the communicators are aborted (comm.hip: comm_stream_sync, watchdog); 0: for ever
     int64_t splitk = 1;         // GEMMs with few result tiles and a deep contraction are cut along K (gemm_f64.hip)
     int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
     int64_t narrow_batched_max = -1;  // right-hand sides up to which the persistent solve runs in column groups of 16 (trsm_narrow.hip); -1: chosen from n and m (chol.hip)
@@ -137,6 +140,11 @@ struct fr_ctx {
     hipEvent_t ev_ring[5][4] = {};  // chain-first schedule: head / message / bulk / first look-ahead tile / nearest column, by panel % 4 (created on first use)
     int64_t* agree_buf = nullptr;  // 1 + world slots of the status agreement (comm_agree)
     void* local = nullptr;  // in-process ("local") communicator: ranks are host threads sharing one device
+    void* watch = nullptr;  // watchdog thread of the RCCL communicators (comm.hip: CommWatch)
+    bool comm_lost = false; // the communicators were aborted (time-out, failed peer): every collective fails until fr_ctx_comm_finalize
+    int64_t comm_timeouts = 0;  // how often a wait ran out (fr_ctx_get_counter)
+    // FRIEDRICH_AMD_TEST_COMM_HANG = "schedule,rank,nth" at context creation: that rank skips its nth collective under that schedule
+    int64_t test_hang_schedule = -1, test_hang_rank = -1, test_hang_nth = 0, test_comm_calls = 0;
     int rank = 0;
     int world = 1;
 };
@@ -405,6 +413,9 @@ int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root, int 
 int comm_fanout(fr_ctx* ctx, double* buf, size_t count, int root, int which = 0);            // root's buffer -> every rank, grouped point-to-point
 int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok);  // collective: does EVERY rank report ok?  (synchronises)
 void comm_abort(fr_ctx* ctx);                        // failing rank: tear the communicator down so that peers do not wait forever
+int comm_stream_sync(fr_ctx* ctx, hipStream_t s, const char* what);  // wait for a stream that may hold collectives, with the deadline
+void comm_drain(fr_ctx* ctx);                        // after comm_abort: give the context's three streams a bounded time to empty
+int ensure_comm2(fr_ctx* ctx);                       // collective: the second communicator exists on every rank (created on first use)
 
 // ---- blocked algorithms (chol.hip) ------------------------------------------------------------------
 // in-place Cholesky of the lower triangle of the n x n block at A (rows/cols offset col0 for bookkeeping)

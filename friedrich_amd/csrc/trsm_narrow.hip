@@ -23,6 +23,8 @@ namespace fr {
 
 typedef double d4n_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) double gdbl;
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) volatile d2_t gvd2;
 
 constexpr int NB = 128;   // block
 constexpr int MR = 16;    // right-hand sides per launch (padded)
@@ -224,6 +226,142 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArg
     }
 }
 
+// ---- wide column groups (m >= 128): 64 right-hand sides per workgroup ---------------------------------------------------------
+// With 16 (32) right-hand sides per group a solve of m columns streams the factor m / 16 (m / 32) times, and its
+// n / 128 x m / 16 blocks need several rounds of the chip (two workgroups per CU): add_samples(512) onto 7680 rows ran 3.75
+// rounds of a 60-step chain (1.6 ms for 3e10 flop: an MFMA-sized job on a memory-shaped kernel).  Here a wave owns 16 rows and
+// NQ = 4 accumulator tiles -- every factor fragment feeds four MFMAs -- so the factor is read m / 64 times and a solve of 512
+// columns onto 8192 rows is ONE round.  What bounds it then is the chain of hand-offs, so the chain carries one product, as in
+// the single-group kernel:  x_r = y' - M_r x_(r-1)  with  y' = W_r (b_r - sum_(q < r-1) L[r, q] x_q)  formed while the neighbour
+// is still being computed and  M_r = W_r L[r, r-1]  cached per factor (ensure_chain_products).  Items of a block, in order:
+// the tiles of all dependencies but the neighbour; the inverse block (operand t'); M (operand -x_neighbour).
+// LDS: one operand block [128 k][64 columns] = 64 KiB, so two workgroups share a CU (two groups' chains side by side); a
+// row is 512 B = all 64 banks, so the four k-rows one fragment read touches would collide four ways: the 16-column segment
+// index is XORed with k & 3.
+template <int NQ>
+__device__ __forceinline__ int wide_idx(int k, int c)
+{
+    return k * (16 * NQ) + (c ^ ((k & 3) << 4));
+}
+
+template <int NQ>
+__global__ __launch_bounds__(NTH, 4) void trsm_narrow_wide_kernel(const TrsmnArgs a0)
+{
+    constexpr int MRT = 16 * NQ;
+    extern __shared__ __attribute__((aligned(16))) double wide_lds[];
+    double* const xs = wide_lds;                                           // the operand block of the current item
+    int* const claim_slot = reinterpret_cast<int*>(wide_lds + NB * MRT);  // (behind it)
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int last = a0.nblk - 1;
+    TrsmnArgs a = a0;
+    {
+        const int grp = blockIdx.y;
+        a.B += (int64_t)grp * MRT * a.ldb;
+        a.m = a.m - grp * MRT < MRT ? a.m - grp * MRT : MRT;
+        a.xg += (int64_t)grp * a.nblk * (NB * MRT);
+        a.flags += (int64_t)grp * a.nblk;
+        a.tickets += grp;
+    }
+#pragma nounroll
+    for (;;) {
+        const int bi = claim_block(a.tickets, a.nblk, claim_slot);
+        if (bi < 0) return;
+        const int blk = a.bwd ? last - bi : bi;
+        const int cnt = a.bwd ? last - blk : blk;      // dependencies; the neighbour is the last of them
+        const int nitems = cnt == 0 ? 1 : cnt + 1;     // tiles of dep(0 .. cnt - 2), the inverse block, M
+        const int64_t b0 = (int64_t)blk * NB;
+        const int64_t row = b0 + 16 * w + l15;
+        auto frag_of = [&](int q) -> Frag {
+            if (q + 1 < cnt) return item_frag(a, blk, a.bwd ? last - q : q, false);
+            if (q + 1 == cnt || cnt == 0) return item_frag(a, blk, 0, true);
+            Frag f;  // the chain product (rows / columns outside a last, partial block: see ensure_chain_products)
+            f.base = a.mchain + (int64_t)blk * (NB * NB);
+            f.stride = NB;
+            f.mrows = f.kcols = NB;
+            return f;
+        };
+        // the accumulators start at -b: after the tiles they hold -(b - sum L x) = -t'
+        d4n_t acc[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 16 * j + lq + 4 * i;
+                acc[j][i] = (row < a.n && q < a.m) ? -a.B[row + (int64_t)q * a.ldb] : 0.0;
+            }
+        double H0[16], H1[16];  // first / second half of the current item; the next half is always in flight
+        load_half(frag_of(0), 0, w, l15, lq, H0);
+#pragma nounroll
+        for (int q = 0; q < nitems; ++q) {
+            load_half(frag_of(q), 1, w, l15, lq, H1);
+            const bool is_w = (q + 1 == cnt) || cnt == 0;
+            if (!is_w) {
+                // a solution block -> LDS (the chain product takes the neighbour's block NEGATED: x = y' + M (-x_neighbour));
+                // the barrier inside the wait also tells that every wave is done with the operand before
+                const bool is_m = q == cnt;
+                const int dep = is_m ? (a.bwd ? blk + 1 : blk - 1) : (a.bwd ? last - q : q);
+                if (!handoff_wait_ge<false>(a.flags + dep, 1, a.status)) return;  // no acquire fence: write-through stores, sc1 loads
+                const gvd2* src = (const gvd2*)(a.xg + (int64_t)dep * (NB * MRT));
+                d2_t v[(NB * MRT) / (2 * NTH)];
+#pragma unroll
+                for (int i = 0; i < (NB * MRT) / (2 * NTH); ++i) v[i] = src[t + NTH * i];
+#pragma unroll
+                for (int i = 0; i < (NB * MRT) / (2 * NTH); ++i) {
+                    const int e = 2 * (t + NTH * i);
+                    const d2_t u = is_m ? -v[i] : v[i];
+                    *reinterpret_cast<d2_t*>(xs + wide_idx<NQ>(e / MRT, e % MRT)) = u;
+                }
+                __syncthreads();
+            } else {
+                // t' = -acc, the operand of the closing product with the inverse block (every wave is done with the last
+                // solution block first); the accumulators restart at zero and end as y'
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xs[wide_idx<NQ>(16 * w + l15, 16 * j + lq + 4 * i)] = -acc[j][i];
+                        acc[j][i] = 0.0;
+                    }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int H = 0; H < 2; ++H) {
+                if (H == 1 && q + 1 < nitems) load_half(frag_of(q + 1), 0, w, l15, lq, H0);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const double xf = xs[wide_idx<NQ>(64 * H + 4 * u + lq, 16 * j + l15)];  // element (k = 64 H + 4 u + lq, column 16 j + l15)
+                        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, H == 0 ? H0[u] : H1[u], acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // publish (write-through), flag, then the caller's copy
+        double* dst = a.xg + (int64_t)blk * (NB * MRT);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __hip_atomic_store((gdbl*)(dst + (16 * w + l15) * MRT + 16 * j + lq + 4 * i), acc[j][i], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store((hgi32*)(a.flags + blk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 16 * j + lq + 4 * i;
+                if (row < a.n && q < a.m) a.B[row + (int64_t)q * a.ldb] = acc[j][i];
+            }
+        __syncthreads();  // xs and the claim slot are reused by the next block of this workgroup
+    }
+}
+
 // ---- one column group (m <= 16) ------------------------------------------------------------------------------------------
 // The solve is a chain of n / 128 hand-offs; what one step costs is what the whole solve costs.  Round 2's step was: flag poll,
 // payload fetch, the product with the neighbouring tile (1.7 us: 64 MFMAs per SIMD), a transposition through LDS, the closing
@@ -251,8 +389,6 @@ __device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long lo
 // quarter-lines per workgroup, and the consumer's barrier waits for the LAST of them); a consumer lane owns two 16-byte pieces
 // (doubles 2 t, 2 t + 1 and 1024 + 2 t, 1024 + 2 t + 1).  Volatile accesses: system-scope (sc0 sc1) loads and write-through
 // stores, which need no fence (Guideline 16, R1); every double is written once and none can be the sentinel.
-typedef double d2_t __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) volatile d2_t gvd2;
 struct Piece {
     d2_t lo, hi;
 };

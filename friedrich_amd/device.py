@@ -180,6 +180,10 @@ class Context:
         """one broadcast + one all-gather through the attached communicator, verified (collective)"""
         self.check(self.lib.fr_ctx_comm_selftest(self.h))
 
+    def comm_finalize(self, abort=False):
+        """detach the communicator (after a time-out: tear it down without waiting for the peers); a new one can be attached"""
+        self.check(self.lib.fr_ctx_comm_finalize(self.h, 1 if abort else 0))
+
     def comm_init_local(self, group_id, rank, world_size):
         """in-process transport (ranks = threads sharing one GPU); see fr_ctx_comm_init_local"""
         self.check(self.lib.fr_ctx_comm_init_local(self.h, int(group_id), int(rank), int(world_size)))

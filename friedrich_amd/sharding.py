@@ -77,3 +77,178 @@ def chain_rounds(n, nb, world):
             "bulk": (sr, [(k2 + r * sr, max(0, min(sr, below - r * sr))) for r in range(world)]),
             "near": {r: nearest_owned(p, r, world) for r in range(world)},
         }
+
+
+# ---- guarded start of a sharded run: preflight, watchdog, schedule fall-back (bench.py, tests/test_gpu_dist_guard.py) ---------
+# The library bounds every wait for a collective (option "comm_timeout_ms": comm.hip) and reports FR_RCCL_ERROR instead of
+# hanging; what to do then is the host's decision.  These helpers are that decision for bench.py and the tests: try the
+# schedules from the most aggressive to the most conservative, each behind a small sharded fit that is compared with a
+# single-rank fit of the same rows; after a failure EVERY rank drops its communicator (aborted where the wait ran out),
+# attaches a fresh one and tries the next schedule; when none works the ranks continue as independent replicas (world 1).
+# Agreement between the ranks travels OUT OF BAND -- a `link` object (gloo group of torch.distributed in bench.py, a
+# threading.Barrier for thread-ranks) -- never over the communicator under test.
+import itertools
+import threading
+import time
+
+SCHEDULE_NAMES = {
+    2: "diagonal chain first: block to the next owner, then scatter / all-gather of the rows below",
+    1: "diagonal block broadcast + scatter / all-gather of the rows below",
+    0: "one broadcast per panel",
+    -1: "replicated: every rank factors the whole matrix (no working sharded schedule), queries sharded",
+}
+
+_thread_group_ids = itertools.count(500000)
+
+
+class ThreadShared:
+    """state shared by the thread-ranks of one process (in-process transport of the library)"""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.base = next(_thread_group_ids) * 64
+
+
+class ThreadLink:
+    """out-of-band link of one thread-rank: rendezvous through a threading.Barrier"""
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.world = shared, rank, shared.world
+        self.generation = 0
+
+    def gather(self, obj):
+        self.shared.slots[self.rank] = obj
+        self.shared.barrier.wait(timeout=900)
+        out = list(self.shared.slots)
+        self.shared.barrier.wait(timeout=900)
+        return out
+
+    def barrier(self):
+        self.shared.barrier.wait(timeout=900)
+
+    def attach(self, ctx):
+        """collective: a fresh communicator on every rank's context"""
+        self.generation += 1
+        ctx.comm_init_local(self.shared.base + self.generation, self.rank, self.world)
+        ctx.comm_selftest()
+
+
+class TorchLink:
+    """out-of-band link of one process-rank: a gloo group of torch.distributed (CPU side: independent of RCCL and of the GPU)"""
+
+    def __init__(self, dist, rank, world, control_group):
+        self.dist, self.rank, self.world, self.ctl = dist, rank, world, control_group
+
+    def gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj, group=self.ctl)
+        return out
+
+    def barrier(self):
+        self.dist.barrier(group=self.ctl)
+
+    def attach(self, ctx):
+        ids = [ctx.comm_unique_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(ids, src=0, group=self.ctl)
+        ctx.comm_init(self.rank, self.world, ids[0])
+        ctx.comm_selftest()
+
+
+class SoloLink:
+    """a single rank without any peer"""
+    rank, world = 0, 1
+
+    def gather(self, obj):
+        return [obj]
+
+    def barrier(self):
+        pass
+
+    def attach(self, ctx):
+        pass
+
+
+def preflight_fit(ctx, ref_ctx, n=4096, d=8, tol=1e-11):
+    """collective: a sharded fit of n synthetic rows on `ctx` (its communicator, its dist_schedule) compared with the
+    single-rank fit of the same rows on `ref_ctx` (a context without communicator on the same GPU).
+    -> None, or a string saying what is wrong"""
+    import numpy as np
+
+    from . import synth
+
+    X, _, _ = synth.make_problem(n, d, cfg=1, m=1)
+    k = ("squared_exp", 1.1, 1.0)
+    ref = ref_ctx.cholesky_from_inputs(k, X, 0.1)
+    Lref = ref.l()
+    ref.free()
+    chol = ctx.cholesky_from_inputs(k, X, 0.1)
+    L = chol.l()
+    info = chol.info()
+    chol.free()
+    err = float(np.max(np.abs(L - Lref)) / np.max(np.abs(Lref)))
+    if not np.isfinite(err) or err > tol:
+        return f"preflight factor (N={n}) deviates from the single-rank factor by {err:.2e} (tolerance {tol:.0e})"
+    if info["n_subst"] != 0 or info["fail_col"] != -1:
+        return f"preflight factor (N={n}) reports substitutions / a failing column: {info}"
+    return None
+
+
+def agree(link, ok, why=None):
+    """-> (every rank ok?, the first failing rank's reason)"""
+    flags = link.gather((bool(ok), why))
+    bad = [(r, w) for r, (o, w) in enumerate(flags) if not o]
+    if not bad:
+        return True, None
+    return False, f"rank {bad[0][0]}: {bad[0][1]}"
+
+
+def reattach(ctx, link):
+    """every rank drops its communicator -- without waiting for peers: it may be the one that timed out -- and attaches a
+    fresh one.  -> None or the reason it failed (then the ranks are left without communicator: replicas)"""
+    from .device import FriedrichError
+
+    ctx.comm_finalize(abort=True)
+    try:
+        link.attach(ctx)
+        ok, why = True, None
+    except FriedrichError as e:
+        ok, why = False, f"attaching a fresh communicator failed: {e}"
+    ok, why = agree(link, ok, why)
+    if not ok:
+        ctx.comm_finalize(abort=True)
+    return why
+
+
+def guarded_schedule(ctx, link, preflight, schedules=(2, 1, 0), timeout_ms=20000, log=None):
+    """Pick the first schedule of `schedules` whose preflight passes on EVERY rank.  preflight(schedule) is collective and
+    returns None / a reason, or raises FriedrichError (a time-out inside the library).  The context must have a communicator
+    attached; on return it has a working one and the option dist_schedule set -- or none at all (-1: replicas).
+    -> (schedule, [reasons of the schedules that failed], {schedule: preflight milliseconds})"""
+    from .device import FriedrichError
+
+    reasons, took = [], {}
+    ctx.set_option("comm_timeout_ms", timeout_ms)
+    for i, s in enumerate(schedules):
+        ctx.set_option("dist_schedule", s)
+        t0 = time.perf_counter()
+        try:
+            why = preflight(s)
+            ok = why is None
+        except FriedrichError as e:
+            ok, why = False, str(e)
+        took[s] = 1e3 * (time.perf_counter() - t0)
+        ok, why = agree(link, ok, why)
+        if ok:
+            return s, reasons, took
+        reasons.append(f"schedule {s}: {why}")
+        if log:
+            log(f"sharded schedule {s} failed its preflight ({why}); falling back")
+        if i + 1 < len(schedules):
+            why = reattach(ctx, link)
+            if why is not None:
+                reasons.append(why)
+                return -1, reasons, took
+    ctx.comm_finalize(abort=True)
+    return -1, reasons, took

@@ -96,7 +96,7 @@ void fr_ctx_destroy(fr_ctx* ctx);
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
-/* Tunables (15 names; everything else the library decides from the problem size):
+/* Tunables (16 names; everything else the library decides from the problem size):
  *   "nb"             outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
  *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
@@ -104,8 +104,13 @@ const char* fr_last_error(const fr_ctx* ctx);
  *                    the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, 4 below 4096, nb <= 512 only: DESIGN.md
  *                    section 5); 0: never; 1..4: that many XCDs for the whole factorisation
  *   "dist_schedule"  sharded (multi-GPU) factorisation, how a panel step travels: 0 = the owner solves the whole panel, one
- *                    broadcast; 1 = diagonal block broadcast, rows below scattered / solved per rank / all-gathered;
- *                    2 (default) = as 1 with the chain of diagonal blocks running ahead of the bulk rows
+ *                    broadcast; 1 (default) = diagonal block broadcast, rows below scattered / solved per rank / all-gathered;
+ *                    2 = as 1 with the chain of diagonal blocks running ahead of the bulk rows on a second communicator
+ *                     -- opt-in until it has run over RCCL on a multi-GPU node: bench.py preflights it
+ *                    under the watchdog and falls back 2 -> 1 -> 0.  Every rank must use the same value.
+ *   "comm_timeout_ms" 120000 (default): how long a sharded operation may wait for its collectives (a stream that does not
+ *                    drain, an RCCL call that does not return) before the communicators are aborted and the call returns
+ *                    FR_RCCL_ERROR; 0 = for ever.  See fr_ctx_comm_finalize.
  *   "splitk"         1 (default): products with few result tiles and a deep contraction are cut along K; 0: never
  *   "narrow_max"     16 (default): solves with at most this many right-hand sides use memory-bound kernels instead of the
  *                    128-wide GEMM tiles;  "narrow_batched_max" (-1: by size): up to this many right-hand sides the persistent
@@ -121,7 +126,17 @@ const char* fr_last_error(const fr_ctx* ctx);
  *                    n x 1 solves instead */
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
 /* Observability: "solve_retries" = how often an entry point of this context repeated its work on the recursive path because a
- * persistent solve gave up on a hand-off (0 in normal operation); "pool_bytes" = bytes held by the workspace pool. */
+ * persistent solve gave up on a hand-off (0 in normal operation); "comm_timeouts" = how often a wait for a collective ran out;
+ * "pool_bytes" = bytes held by the workspace pool.
+ * Environment read when a context is created (operators / tests; none is needed in normal use):
+ *   FRIEDRICH_AMD_DIST_SCHEDULE = 0 | 1 | 2, FRIEDRICH_AMD_COMM_TIMEOUT_MS   the options of the same name without touching the host program
+ *   FRIEDRICH_AMD_RCCL_PATH         the librccl to dlopen (it has to match the process's HIP runtime)
+ *   FRIEDRICH_AMD_ROCTX = 1         roctx ranges around the entry points (rocprofv3 --marker-trace)
+ *   FRIEDRICH_AMD_SMALL_TILES       A/B override of the 32-row-tile rule (gemm_f64.hip)
+ *   FRIEDRICH_AMD_LOCAL_SYNC = 1    in-process transport: synchronise around every collective instead of ordering by events
+ *   test hooks: FRIEDRICH_AMD_TEST_MAX_WORKGROUPS (cap on the grid of the persistent solves: many blocks per workgroup),
+ *   FRIEDRICH_AMD_TEST_FORCE_SOLVE_TIMEOUT = 1 (every persistent solve reports a time-out: the retry path),
+ *   FRIEDRICH_AMD_TEST_COMM_HANG = "schedule,rank,nth" (that rank skips its nth collective under that schedule: the watchdog). */
 int fr_ctx_get_counter(fr_ctx* ctx, const char* name, int64_t* out);
 
 /* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline leg). */
@@ -149,6 +164,12 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
  * group_id form one communicator).  Lets the sharded path run on a 1-GPU box; not a performance path. */
 int fr_ctx_comm_init_local(fr_ctx* ctx, int group_id, int rank, int world_size);
 int fr_ctx_comm_info(const fr_ctx* ctx, int* rank, int* world_size);
+/* Detach the communicator (RCCL: both communicators of the context; local: leave the group): the context is single-rank
+ * again and a new communicator can be attached.  abort != 0 (and always after a time-out / failed peer, when the context's
+ * communicator is "lost") tears it down without waiting for the peers (ncclCommAbort) -- the recovery step of a host that
+ * falls back to another schedule after FR_RCCL_ERROR: every rank finalizes, the host distributes a fresh id, every rank
+ * calls fr_ctx_comm_init again.  No reference counterpart. */
+int fr_ctx_comm_finalize(fr_ctx* ctx, int abort);
 /* Collective self-test of the communicator the way the factorisation uses it (one broadcast from rank 0 and one
  * all-gather of small device buffers on the panel stream, results verified on the host).  Every rank calls it.
  * No reference counterpart (friedrich is single-process); FR_OK when no communicator is attached. */

@@ -188,8 +188,8 @@ def test_rccl_single_rank_communicator():
 
 
 def test_config3_full_size_sharded_over_eight_ranks():
-    """BASELINE configs[3] as it is sharded: N = 32768, d = 16, RBF, block columns of 512 dealt to EIGHT ranks, the default
-    (chain-first) schedule -- eight thread-ranks on the one GPU a test box has (8 x 8 GiB factors + the reference's), the
+    """BASELINE configs[3] as it is sharded: N = 32768, d = 16, RBF, block columns of 512 dealt to EIGHT ranks, the
+    chain-first schedule (dist_schedule = 2) -- eight thread-ranks on the one GPU a test box has (8 x 8 GiB factors + the reference's), the
     in-process transport instead of RCCL, everything else the code path of an 8-GPU node: ownership filters in the Gram and
     trailing-update kernels, 64 rounds of the chain / bulk / update streams with their events, the merged substitution log.
     Every rank's factor is compared ON THE DEVICE with the single-rank factor of the same build, which
@@ -225,6 +225,7 @@ def test_config3_full_size_sharded_over_eight_ranks():
     lock = th.Lock()
 
     def fn(ctx, rank):
+        ctx.set_option("dist_schedule", 2)  # (opt-in since round 4: the library's default is the split schedule, 1)
         chol = ctx.cholesky_from_inputs(k, X, hp["noise"])
         info = chol.info()
         with lock:  # one 8 GiB comparison buffer at a time
