@@ -656,33 +656,101 @@ static int ensure_inv512(fr_ctx* ctx, const fr_chol* cc, int cls)
     const int64_t nq = c->n / LB;
     if (nq <= 0 || c->inv512_rows >= nq * LB) return FR_OK;
     if (c->inv512_cap < nq) {
-        if (c->inv512) (void)hipFree(c->inv512);
-        c->inv512 = nullptr;
-        c->inv512_cap = 0;
+        // (grown: the blocks already built are copied over -- add_rows extends the cache by one block per 512 rows)
         const int64_t cap = imax(nq, c->capacity / LB);
-        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->inv512, sizeof(double) * (size_t)cap * LB * LB));
+        double* fresh = nullptr;
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&fresh, sizeof(double) * (size_t)cap * LB * LB));
+        if (c->inv512 && c->inv512_rows > 0)
+            FR_HIP(ctx, hipMemcpyAsync(fresh, c->inv512, sizeof(double) * (size_t)(c->inv512_rows / LB) * LB * LB, hipMemcpyDeviceToDevice, ctx->ls));
+        if (c->inv512) {
+            FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+            (void)hipFree(c->inv512);
+        }
+        c->inv512 = fresh;
         c->inv512_cap = cap;
     }
+    // only the blocks that are not valid yet (after add_rows: the new ones)
+    const int64_t q0 = c->inv512_rows / LB, nn = nq - q0;
     const int64_t ld = c->ld_a;
     WsGuard w(ctx);
-    double* T = w.get(sizeof(double) * (size_t)nq * 256 * 256);
+    double* T = w.get(sizeof(double) * (size_t)nn * 256 * 256);
     if (!T) return FR_OUT_OF_MEMORY;
-    double* W = c->inv512;
-    FR_TRY(launch_blockdiag512(ctx, c->dinv, W, nq));
+    double* W = c->inv512 + q0 * LB * LB;
+    const double* A0 = c->A + q0 * LB + q0 * LB * ld;
+    const double* D0 = c->dinv + 4 * q0 * INV_ELEMS;
+    FR_TRY(launch_blockdiag512(ctx, D0, W, nn));
     // level 256: for both 256-halves (par) of every block q, 128-blocks a (upper) and b = a + 1:  W_ba = -X_b (L_ba X_a)
     for (int par = 0; par < 2; ++par) {
         const int64_t off = 256 * par;  // first row of the half inside its 512-block
-        FR_TRY(batched_gemm(ctx, cls, IB, IB, IB, c->A + (off + IB) + off * ld, ld, false, LB + LB * ld,
-                            c->dinv + (2 * par) * INV_ELEMS, IB, true, 4 * INV_ELEMS, 1.0, T, IB, INV_ELEMS, nq));
-        FR_TRY(batched_gemm(ctx, cls, IB, IB, IB, c->dinv + (2 * par + 1) * INV_ELEMS, IB, false, 4 * INV_ELEMS, T, IB, true,
-                            INV_ELEMS, -1.0, W + (off + IB) + off * LB, LB, LB * LB, nq));
+        FR_TRY(batched_gemm(ctx, cls, IB, IB, IB, A0 + (off + IB) + off * ld, ld, false, LB + LB * ld,
+                            D0 + (2 * par) * INV_ELEMS, IB, true, 4 * INV_ELEMS, 1.0, T, IB, INV_ELEMS, nn));
+        FR_TRY(batched_gemm(ctx, cls, IB, IB, IB, D0 + (2 * par + 1) * INV_ELEMS, IB, false, 4 * INV_ELEMS, T, IB, true,
+                            INV_ELEMS, -1.0, W + (off + IB) + off * LB, LB, LB * LB, nn));
     }
     // level 512: halves P (rows 0..255) and Q (256..511) of every block:  W_QP = -W_QQ (L_QP W_PP)
-    FR_TRY(batched_gemm(ctx, cls, 256, 256, 256, c->A + 256, ld, false, LB + LB * ld, W, LB, true, LB * LB, 1.0, T, 256,
-                        256 * 256, nq));
+    FR_TRY(batched_gemm(ctx, cls, 256, 256, 256, A0 + 256, ld, false, LB + LB * ld, W, LB, true, LB * LB, 1.0, T, 256,
+                        256 * 256, nn));
     FR_TRY(batched_gemm(ctx, cls, 256, 256, 256, W + 256 + 256 * LB, LB, false, LB * LB, T, 256, true, 256 * 256, -1.0,
-                        W + 256, LB, LB * LB, nq));
+                        W + 256, LB, LB * LB, nn));
     c->inv512_rows = nq * LB;
+    return FR_OK;
+}
+
+// ---- explicit inverses of the 2048 x 2048 diagonal blocks ----------------------------------------------------------------
+// A solve with a few hundred right-hand sides is neither a bandwidth problem (the persistent column-group kernel streams the
+// factor once per 16 columns and lives on a chain of n / 128 hand-offs) nor yet a throughput problem: the recursion over
+// 512-row leaves is ~6 n / 1024 dependent launches of 25 - 45 us that use a quarter of the chip each (n = 8192, 512 columns:
+// 47 launches, 1.1 ms for 3.4e10 flop; configs[4]'s L21 solves, sample_at(256), predict_variance(1024)).  Fewer, fatter links:
+// 2048-row diagonal blocks with an explicit inverse (two more block levels on top of the 512 ones, the same 2 x 2 formula),
+// applied as ONE triangular-operand product per block on 32-row tiles claimed in dispatch order, and a LEFT-looking sweep
+// between them -- one deep update (contraction = all rows solved so far: split along K) per block: 2 n / 2048 - 1 launches.
+constexpr int64_t GB = 2048;
+
+static int ensure_invbig(fr_ctx* ctx, const fr_chol* cc, int cls)
+{
+    fr_chol* c = const_cast<fr_chol*>(cc);
+    const int64_t ng = c->n / GB;
+    if (ng <= 0 || c->invbig_rows >= ng * GB) return FR_OK;
+    FR_TRY(ensure_inv512(ctx, c, cls));
+    if (c->invbig_cap < ng) {
+        const int64_t cap = imax(ng, c->capacity / GB);
+        double* fresh = nullptr;
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&fresh, sizeof(double) * (size_t)cap * GB * GB));
+        if (c->invbig && c->invbig_rows > 0)
+            FR_HIP(ctx, hipMemcpyAsync(fresh, c->invbig, sizeof(double) * (size_t)(c->invbig_rows / GB) * GB * GB, hipMemcpyDeviceToDevice, ctx->ls));
+        if (c->invbig) {
+            FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+            (void)hipFree(c->invbig);
+        }
+        c->invbig = fresh;
+        c->invbig_cap = cap;
+    }
+    const int64_t g0 = c->invbig_rows / GB, nn = ng - g0;
+    const int64_t ld = c->ld_a;
+    WsGuard w(ctx);
+    double* T = w.get(sizeof(double) * (size_t)nn * 1024 * 1024);
+    if (!T) return FR_OUT_OF_MEMORY;
+    double* W = c->invbig + g0 * GB * GB;
+    const double* A0 = c->A + g0 * GB + g0 * GB * ld;
+    // zero (the products below read whole sub-blocks), then the four 512-block inverses of every block on its diagonal
+    FR_HIP(ctx, hipMemsetAsync(W, 0, sizeof(double) * (size_t)nn * GB * GB, ctx->ls));
+    for (int64_t b = 0; b < nn; ++b)
+        for (int j = 0; j < 4; ++j)
+            FR_TRY(launch_copy(ctx, c->inv512 + (4 * (g0 + b) + j) * LB * LB, LB, W + b * GB * GB + j * LB + j * LB * GB, GB, LB, LB));
+    // level 1024: both 1024-halves (par) of every block, 512-blocks P (upper) and Q:  W_QP = -W_QQ (L_QP W_PP)
+    for (int par = 0; par < 2; ++par) {
+        const int64_t off = 1024 * par;
+        FR_TRY(batched_gemm(ctx, cls, LB, LB, LB, A0 + (off + LB) + off * ld, ld, false, GB + GB * ld, W + off + off * GB, GB, true,
+                            GB * GB, 1.0, T, LB, LB * LB, nn));
+        FR_TRY(batched_gemm(ctx, cls, LB, LB, LB, W + (off + LB) + (off + LB) * GB, GB, false, GB * GB, T, LB, true, LB * LB, -1.0,
+                            W + (off + LB) + off * GB, GB, GB * GB, nn));
+    }
+    // level 2048: halves P (rows 0 .. 1023) and Q (1024 .. 2047)
+    FR_TRY(batched_gemm(ctx, cls, 1024, 1024, 1024, A0 + 1024, ld, false, GB + GB * ld, W, GB, true, GB * GB, 1.0, T, 1024,
+                        1024 * 1024, nn));
+    FR_TRY(batched_gemm(ctx, cls, 1024, 1024, 1024, W + 1024 + 1024 * GB, GB, false, GB * GB, T, 1024, true, 1024 * 1024, -1.0,
+                        W + 1024, GB, GB * GB, nn));
+    c->invbig_rows = ng * GB;
     return FR_OK;
 }
 
@@ -763,6 +831,93 @@ static int trsm_right_rec(fr_ctx* ctx, const double* L, int64_t ld, const double
     // X2 -= X1 * L21^T
     FR_TRY(gemm(ctx, cls, k, n - n1, n1, X, ldx, false, L + n1, ld, false, -1.0, 1.0, X + n1 * ldx, ldx));
     return trsm_right_rec(ctx, L + n1 + n1 * ld, ld, dinv + (n1 / IB) * INV_ELEMS, n - n1, X + n1 * ldx, k, ldx, cls);
+}
+
+// one 2048-row leaf: B (2048 x m) <- W B (forward) / W^T B (backward) through a copy; the product skips the structural zeros
+// of the triangular inverse tile by tile
+static int leaf_big(fr_ctx* ctx, const fr_chol* c, int64_t row0, double* B, int64_t m, int64_t ldb, int cls, bool fwd, double* tmp,
+                    bool tmp_holds_operand)
+{
+    const double* W = c->invbig + (row0 / GB) * GB * GB;
+    if (!tmp_holds_operand) FR_TRY(launch_copy(ctx, B, ldb, tmp, GB, GB, m));
+    GemmDesc g;
+    g.M = GB; g.N = m; g.K = GB;
+    g.A = W; g.lda = GB; g.a_kmajor = !fwd;
+    g.B = tmp; g.ldb = GB; g.b_kmajor = true;
+    g.Cin = B; g.ldcin = ldb; g.D = B; g.ldd = ldb;
+    g.alpha = 1.0; g.beta = 0.0; g.lower = false; g.prof_cls = cls;
+    g.tri = fwd ? 4 : 1;  // W (r, k) = 0 for k > r  /  W^T (r, k) = 0 for k < r
+    // Two variants, by measurement (scripts/solve_mid.py, forward solves at N = 4096 / 8192 in one process):
+    //  * up to 640 columns: cut along K like the other products with few result tiles (slices that only meet structural zeros
+    //    write zeros and retire) -- 256 columns 0.37 / 0.92 -> 0.28 / 0.75 ms, 512 columns equal;
+    //  * above: 32-row tiles in mirrored pairs -- a workgroup takes row tile i and then row tile 63 - i, a contraction of 2080
+    //    for every workgroup -- 1024 columns 0.59 / 1.76 -> 0.50 / 1.61 ms (148 against 166 + 13 us per leaf; claimed one by
+    //    one in dispatch order the 32-row tiles took 180 us: the launch is as long as its deepest tiles).  Both run at half
+    //    the rate of the dense updates: the paired tiles are bound by the L2 (a 32 x 128 tile moves 20 KiB per 131 kflop), the
+    //    slices by the workgroups that hold two deep ones on one CU.  FRIEDRICH_AMD_LEAF_MIRROR = 0 / 1 forces a variant.
+    static const int leaf_force = getenv("FRIEDRICH_AMD_LEAF_MIRROR") ? atoi(getenv("FRIEDRICH_AMD_LEAF_MIRROR")) : -1;
+    const bool leaf_mirror = leaf_force >= 0 ? leaf_force == 1 : m > 640;
+    if (leaf_mirror) {
+        g.force_small = true;
+        g.mirror = true;
+    } else {
+        g.tri_splitk = true;
+    }
+    return launch_gemm(ctx, g);
+}
+
+// T (rows x m, ld GB) = Bblk - op(A) X: the left-looking update of a block lands in the leaf's scratch directly (no copy)
+static int update_into(fr_ctx* ctx, int cls, int64_t rows, int64_t m, int64_t K, const double* A, int64_t lda, bool a_kmajor, const double* X,
+                       int64_t ldx, const double* Bblk, int64_t ldb, double* T)
+{
+    GemmDesc g;
+    g.M = rows; g.N = m; g.K = K;
+    g.A = A; g.lda = lda; g.a_kmajor = a_kmajor;
+    g.B = X; g.ldb = ldx; g.b_kmajor = true;
+    g.Cin = Bblk; g.ldcin = ldb; g.D = T; g.ldd = GB;
+    g.alpha = -1.0; g.beta = 1.0; g.lower = false; g.prof_cls = cls;
+    return launch_gemm(ctx, g);
+}
+
+// B (n x m) <- L^-1 B (fwd) / L^-T B, left-looking over 2048-row blocks; the rows behind the last whole block go through the
+// 512-leaf recursion (tmp: 2048 x m scratch)
+static int trsm_big(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int cls, bool fwd, double* tmp)
+{
+    const int64_t ld = c->ld_a;
+    const int64_t ng = c->invbig_rows / GB < n / GB ? c->invbig_rows / GB : n / GB;
+    const int64_t n0 = ng * GB, tail = n - n0;
+    if (fwd) {
+        for (int64_t b = 0; b < ng; ++b) {
+            const int64_t r0 = b * GB;
+            if (b > 0) FR_TRY(update_into(ctx, cls, GB, m, r0, c->A + r0, ld, false, B, ldb, B + r0, ldb, tmp));
+            FR_TRY(leaf_big(ctx, c, r0, B + r0, m, ldb, cls, true, tmp, b > 0));
+        }
+        if (tail > 0) {
+            if (n0 > 0) FR_TRY(gemm(ctx, cls, tail, m, n0, c->A + n0, ld, false, B, ldb, true, -1.0, 1.0, B + n0, ldb));
+            FR_TRY(trsm_fwd_rec(ctx, c, n0, tail, B + n0, m, ldb, cls, tail >= LB ? tmp : nullptr));
+        }
+        return FR_OK;
+    }
+    if (tail > 0) FR_TRY(trsm_bwd_rec(ctx, c, n0, tail, B + n0, m, ldb, cls, tail >= LB ? tmp : nullptr));
+    for (int64_t b = ng - 1; b >= 0; --b) {
+        const int64_t r0 = b * GB, below = n - (r0 + GB);
+        // B_b - L[rows below, block b]^T X[rows below]     (op(A)[m][k] = L[k][m]: k-major)
+        if (below > 0) FR_TRY(update_into(ctx, cls, GB, m, below, c->A + (r0 + GB) + r0 * ld, ld, true, B + r0 + GB, ldb, B + r0, ldb, tmp));
+        FR_TRY(leaf_big(ctx, c, r0, B + r0, m, ldb, cls, false, tmp, below > 0));
+    }
+    return FR_OK;
+}
+
+// measured (scripts/narrow_wide_ab.py): see use_big_leaves
+static bool use_big_leaves(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m)
+{
+    // measured against the column groups and the 512-leaf recursion (scripts/narrow_wide_ab.py, predict_variance at
+    // N = 4096 / 8192 / 16384): 64 columns 0.43 / 0.98 / 2.30 ms against 0.32 / 0.67 / 1.44 in groups of 16; 128 columns
+    // 0.36 / 0.85 / 1.93 against 0.33 / 0.73 / 2.39; 256 columns 0.39 / 0.94 / 2.42 against 0.38 / 1.14 / 4.1 (recursion: 0.47 /
+    // 1.08 / 2.68); 1024 columns 0.54 / 1.63 / 5.11 against the recursion's 1.06 / 2.65 / 7.38; 2048 columns 0.96 / 2.73 / 9.24
+    // against 1.39 / 3.73 / 11.6
+    const int64_t mmax = ctx->bigleaf_max >= 0 ? ctx->bigleaf_max : 2048;
+    return ctx->leaf512 != 0 && !c->refine && n == c->n && n >= 2 * GB && m <= mmax && (m >= 192 || (m >= 96 && n >= 12288));
 }
 
 // ---- a few right-hand sides (likelihood, K^-1 y, predicting a handful of points) -----------------------------------------
@@ -859,6 +1014,14 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         return trsm_fwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, true, cls);
+    if (use_big_leaves(ctx, c, n, m) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
+        FR_TRY(ensure_inv512(ctx, c, cls));  // (the rows behind the last whole 2048-block take the 512-row leaves)
+        FR_TRY(ensure_invbig(ctx, c, cls));
+        WsGuard wb(ctx);
+        double* tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m);
+        if (!tmpb) return FR_OUT_OF_MEMORY;
+        return trsm_big(ctx, c, n, B, m, ldb, cls, true, tmpb);
+    }
     if (use_column_groups(ctx, c, n, m)) return launch_trsm_narrow(ctx, c, B, m, ldb, true, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, true);
     WsGuard w(ctx);
@@ -931,6 +1094,14 @@ int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         return trsm_bwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, false, cls);
+    if (use_big_leaves(ctx, c, n, m) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
+        FR_TRY(ensure_inv512(ctx, c, cls));
+        FR_TRY(ensure_invbig(ctx, c, cls));
+        WsGuard wb(ctx);
+        double* tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m);
+        if (!tmpb) return FR_OUT_OF_MEMORY;
+        return trsm_big(ctx, c, n, B, m, ldb, cls, false, tmpb);
+    }
     if (use_column_groups(ctx, c, n, m)) return launch_trsm_narrow(ctx, c, B, m, ldb, false, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, false);
     WsGuard w(ctx);
@@ -950,13 +1121,16 @@ static void chol_release(fr_chol* c)
     if (c->dinv) (void)hipFree(c->dinv);
     if (c->info) (void)hipFree(c->info);
     if (c->inv512) (void)hipFree(c->inv512);
+    if (c->invbig) (void)hipFree(c->invbig);
+    c->invbig = nullptr;
+    c->invbig_cap = c->invbig_rows = 0;
     if (c->cest) (void)hipFree(c->cest);
     c->cest = nullptr;
     if (c->dinvt) (void)hipFree(c->dinvt);
     c->dinvt = nullptr;
     c->dinvt_cap = 0;
     c->ut_gen = 0;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (c->mchain[i]) (void)hipFree(c->mchain[i]);
         c->mchain[i] = nullptr;
         c->mchain_cap[i] = 0;
@@ -1077,6 +1251,7 @@ static int merge_info(fr_chol* c)
 int potrf_device(fr_ctx* ctx, fr_chol* c, int64_t j0, int64_t n, int mode, double sub)
 {
     c->inv512_rows = 0;
+    c->invbig_rows = 0;
     ++c->gen;
     return potrf_blocked(ctx, c->A + j0 + j0 * c->ld_a, c->ld_a, n, j0, mode, sub, c->dinv + (j0 / IB) * INV_ELEMS, c->info,
                          c->nb);
@@ -1154,7 +1329,9 @@ static int assemble_and_factor_once(fr_chol* c, const fr_kprog* kernel, double n
     ctx->refine_now = c->refine;
     ctx->cur_cest = c->cest;
     c->inv512_rows = 0;
+    c->invbig_rows = 0;
     ++c->gen;
+    drain_stale_status(ctx);  // (a time-out left behind by an earlier call must not be read as this factorisation's)
     FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
     FR_HIP(ctx, hipMemsetAsync(c->cest, 0, sizeof(double) * (size_t)((c->capacity + IB - 1) / IB), ctx->stream));
     FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank, c->nb));
@@ -1299,6 +1476,7 @@ int fr_chol_from_matrix(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, in
         if (st == FR_OK) {
             ctx->refine_now = c->refine;
             ctx->cur_cest = c->cest;
+            drain_stale_status(ctx);
             st = potrf_device(ctx, c, 0, n, has_eps ? 1 : 0, eps);
             ctx->refine_now = false;
             ctx->cur_cest = nullptr;
@@ -1384,19 +1562,28 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
                 FR_TRY(gemm(ctx, FR_PROF_SYRK, nb_new, nb_new, n_old, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
             }
         }
+        const bool aligned = n_old % IB == 0;  // the new rows start on the 128-grid of the inverse blocks
         {
             WsGuard tmp(ctx);
             const int64_t nblk = (nb_new + IB - 1) / IB;
-            double* dinv_tmp = tmp.get(sizeof(double) * (size_t)nblk * INV_ELEMS);
-            if (!dinv_tmp) return FR_OUT_OF_MEMORY;
-            FR_TRY(potrf_blocked(ctx, A22, ld, nb_new, n_old, 2, 0.0, dinv_tmp, c->info, c->nb));
+            // aligned (the usual case: appends in multiples of 128 rows): the factorisation's diagonal-block kernels write the
+            // inverse blocks and their conditioning estimates straight into place -- the four extra launches per 512 rows that
+            // rebuilt them were 0.13 ms of every add_samples(512) (configs[4])
+            double* dinv_new = aligned ? c->dinv + (n_old / IB) * INV_ELEMS : tmp.get(sizeof(double) * (size_t)nblk * INV_ELEMS);
+            if (!dinv_new) return FR_OUT_OF_MEMORY;
+            double* saved_cest = ctx->cur_cest;
+            ctx->cur_cest = aligned ? c->cest : nullptr;  // (K4 indexes it by global column / 128: potrf_blocked gets col0 = n_old)
+            const int st2 = potrf_blocked(ctx, A22, ld, nb_new, n_old, 2, 0.0, dinv_new, c->info, c->nb);
+            ctx->cur_cest = saved_cest;
+            FR_TRY(st2);
         }
         c->n = n_all;
-        // re-align the inverse blocks with the global 128-grid over the rows that changed (and take their conditioning estimates)
-        for (int64_t b = n_old / IB; b * IB < n_all; ++b) {
-            const int64_t j = b * IB, sb = imin(IB, n_all - j);
-            FR_TRY(invert_block128(ctx, c->A + j + j * ld, ld, sb, c->dinv + b * INV_ELEMS, c->cest + b));
-        }
+        // otherwise re-align the inverse blocks with the global 128-grid over the rows that changed (and take their estimates)
+        if (!aligned)
+            for (int64_t b = n_old / IB; b * IB < n_all; ++b) {
+                const int64_t j = b * IB, sb = imin(IB, n_all - j);
+                FR_TRY(invert_block128(ctx, c->A + j + j * ld, ld, sb, c->dinv + b * INV_ELEMS, c->cest + b));
+            }
         FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return check_status_word(ctx);
     };

@@ -307,6 +307,19 @@ int check_status_word(fr_ctx* ctx)
     return FR_OK;
 }
 
+void drain_stale_status(fr_ctx* ctx)
+{
+    if (!ctx->persistent_pending) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->persistent_pending = false;
+    if (!ctx->host_status) return;
+    volatile unsigned* s = ctx->host_status;
+    if (s[0] != 0) {
+        s[0] = 0;
+        ++ctx->stale_status_drops;
+    }
+}
+
 // ---- profiling ------------------------------------------------------------------------------------
 static hipEvent_t get_event(fr_ctx* ctx)
 {
@@ -552,6 +565,16 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->narrow_pair_min = value;
         return FR_OK;
     }
+    if (!strcmp(name, "bigleaf_max")) {
+        if (value < -1) return set_err(ctx, FR_INVALID_ARGUMENT, "bigleaf_max must be >= -1");
+        ctx->bigleaf_max = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "narrow_wide_min")) {
+        if (value < -1) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow_wide_min must be >= -1");
+        ctx->narrow_wide_min = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "leaf512")) {
         ctx->leaf512 = value != 0;
         return FR_OK;
@@ -588,6 +611,10 @@ int fr_ctx_get_counter(fr_ctx* ctx, const char* name, int64_t* out)
     FR_LOCK(ctx);
     if (!strcmp(name, "solve_retries")) {
         *out = ctx->solve_retries;
+        return FR_OK;
+    }
+    if (!strcmp(name, "stale_status_drops")) {
+        *out = ctx->stale_status_drops;
         return FR_OK;
     }
     if (!strcmp(name, "comm_timeouts")) {

@@ -81,8 +81,11 @@ struct fr_ctx {
     int64_t splitk = 1;         // GEMMs with few result tiles and a deep contraction are cut along K (gemm_f64.hip)
     int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
     int64_t narrow_batched_max = -1;  // right-hand sides up to which the persistent solve runs in column groups of 16 (trsm_narrow.hip); -1: chosen from n and m (chol.hip)
-    int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0: never, -1: by size)
+    int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0 / -1: never; A/B only)
+    int64_t narrow_wide_min = -1;  // ... with at least this many: 64 per column group, the wide kernel (0: never, -1: 128)
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
+    int64_t bigleaf_max = -1;   // solves with at most this many right-hand sides (and >= 4096 rows) run left-looking over 2048-row blocks
+                                // with explicit 2048-block inverses (chol.hip: trsm_big); -1: 2048; 0: never
     int64_t trsv = 1;           // solves with few right-hand sides as one persistent launch per direction (trsv.hip, trsm_narrow.hip)
     int64_t tri_inverse = 1;    // gradient terms: L^-1 and W^T W skip the structural zeros (chol_tri_inverse); 0: dense products
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
@@ -97,6 +100,7 @@ struct fr_ctx {
     bool potf2_lds_set = false;  // dynamic-LDS attributes applied on this device (per context = per device)
     bool trsv_lds_set = false;
     bool trsmn_lds_set = false;
+    bool trsmw_lds_set = false;
     bool prior_lds_set = false;
     // profiling
     bool prof = false;
@@ -122,6 +126,7 @@ struct fr_ctx {
     bool solve_timeout_seen = false;  // a persistent solve timed out on this context: the entry point re-runs on the recursive path
     bool persistent_pending = false;  // a persistent solve was launched since the last check_status_word
     int64_t solve_retries = 0;        // how often that happened (fr_ctx_get_counter)
+    int64_t stale_status_drops = 0;   // time-outs left behind by an entry point that returned early, dropped by the next one (drain_stale_status)
     int test_max_wgs = 0;             // FRIEDRICH_AMD_TEST_MAX_WORKGROUPS at context creation: cap on the grid of the persistent solves (tests: many blocks per workgroup)
     bool test_force_timeout = false;  // FRIEDRICH_AMD_TEST_FORCE_SOLVE_TIMEOUT=1 at context creation: every persistent solve reports a timeout (tests of the retry)
     int num_cus = 256;
@@ -168,6 +173,11 @@ struct fr_chol {
     double* inv512 = nullptr;
     int64_t inv512_cap = 0;  // blocks allocated
     int64_t inv512_rows = 0;
+    // explicit inverses of the 2048 x 2048 diagonal blocks (leaves of the solves with a few hundred right-hand sides: chol.hip,
+    // ensure_invbig), built on demand from inv512 by two more block levels; invbig_rows = rows covered by valid blocks
+    double* invbig = nullptr;
+    int64_t invbig_cap = 0;  // blocks allocated
+    int64_t invbig_rows = 0;
     int64_t* info = nullptr;  // device: [0] = 1 + first failing column (0: none), [1] = n_subst,
                               //         [2] = 1 if a zero diagonal was seen, [3..] substituted columns
     int64_t info_cap = 0;
@@ -176,11 +186,14 @@ struct fr_chol {
     double* dinvt = nullptr;
     int64_t dinvt_cap = 0;
     uint64_t ut_gen = 0;
+    int64_t ut_n = -1;  // (rows the copy was built for: a generation can see two row counts, fr_chol_add_rows)
     // K9's chain products M_b = W_b L[b, b - 1] (forward, [0]) and W_b^T L[b + 1, b]^T (backward, [1]), one 128 x 128 block per
     // block row, valid for generation mchain_gen (trsm_narrow.hip: ensure_chain_products)
-    double* mchain[2] = {nullptr, nullptr};
-    int64_t mchain_cap[2] = {0, 0};
-    uint64_t mchain_gen[2] = {0, 0};
+    // ([2], [3]: the same with the tile two blocks from the diagonal -- the wide column-group kernel); valid for (mchain_gen, mchain_n)
+    double* mchain[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t mchain_cap[4] = {0, 0, 0, 0};
+    uint64_t mchain_gen[4] = {0, 0, 0, 0};
+    int64_t mchain_n[4] = {-1, -1, -1, -1};
     // conditioning estimates of the 128 x 128 diagonal blocks (device, one double per block), their maximum after the
     // last factorisation, and whether this handle applies iterative refinement (fr_ctx::refine)
     double* cest = nullptr;
@@ -335,6 +348,10 @@ struct GemmDesc {
     // tiles claimed in dispatch order instead of dealt per XCD: for launches whose tiles differ in length (tri), where equal
     // tile counts per XCD are unequal work
     bool dynamic = false;
+    bool tri_splitk = false;   // a triangular-operand product may be cut along K like any other (slices of structural zeros retire at once)
+    int64_t tri_kslice = 0;    // (set by the split-K path: slice length of a batched triangular-operand launch)
+    bool mirror = false;       // a workgroup takes row tile i and then row tile (last - i): equal work per workgroup with a triangular left operand
+    bool force_small = false;  // 32-row tiles whatever the tile count, triangular operands included (the big solve leaves: chol.hip)
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 // S (rows x kb, ld lds_) <- S L^-T against a factored kb x kb diagonal block and its 128-block inverses: one launch (gemm_f64.hip)
@@ -381,6 +398,11 @@ int ensure_status_word(fr_ctx* ctx);
 int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* c, double* B, int64_t m, int64_t ldb, bool fwd, int prof_cls);
 // FR_HIP_ERROR if a device-side wait timed out since the last check (call after a synchronisation)
 int check_status_word(fr_ctx* ctx);
+// An entry point that launched a persistent solve and then left early (out of memory, bad argument) never read the status
+// word: the flag -- and a possible time-out -- would be reported by the NEXT, unrelated check (a factorisation would return a
+// spurious FR_HIP_ERROR).  Called at the start of solve_retry and of the factorisation entry points: waits for the stream,
+// drops a stale time-out (counter "stale_status_drops").
+void drain_stale_status(fr_ctx* ctx);
 
 // Run the body of an entry point; if a persistent solve inside it gave up on a hand-off (bounded device-side wait -> status
 // word -> check_status_word returns FR_HIP_ERROR and raises ctx->solve_timeout_seen), run the body ONCE more with the
@@ -389,6 +411,7 @@ int check_status_word(fr_ctx* ctx);
 template <class F>
 int solve_retry(fr_ctx* ctx, F&& body)
 {
+    drain_stale_status(ctx);
     ctx->solve_timeout_seen = false;
     int st = body();
     if (st == FR_HIP_ERROR && ctx->solve_timeout_seen && ctx->trsv) {

@@ -90,24 +90,32 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
             tn = tlin / g.tiles_m;
         }
     }
-    const int64_t m0 = tm * BMT, n0 = tn * BN;
+    const int64_t n0 = tn * BN;
     if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) return;
-    GemmArgs gt = g;  // (ONE call site of the tile function: a second inlined copy would double the kernel)
-    if (g.tri) {
-        // triangular operand(s): skip the part of the contraction that only multiplies structural zeros
-        int64_t kbeg = 0, kend = g.K;
-        if ((g.tri & 1) && m0 > kbeg) kbeg = m0;
-        if ((g.tri & 2) && n0 > kbeg) kbeg = n0;
-        if ((g.tri & 4) && m0 + BMT < kend) kend = m0 + BMT;
-        if (kbeg > kend) kbeg = kend;
-        gt.A += kbeg * (A_KMAJ ? 1 : g.lda);
-        gt.B += kbeg * (B_KMAJ ? 1 : g.ldb);
-        gt.K = kend - kbeg;
+    const int reps = g.mirror_tiles > 0 ? 2 : 1;
+#pragma nounroll
+    for (int rep = 0; rep < reps; ++rep) {
+        const int64_t m0 = (rep == 0 ? tm : g.mirror_tiles - 1 - tm) * BMT;
+        GemmArgs gt = g;  // (ONE call site of the tile function: a second inlined copy would double the kernel)
+        if (g.tri) {
+            // triangular operand(s): skip the part of the contraction that only multiplies structural zeros
+            // (k0: where this launch's -- this batch member's -- part of the contraction starts in the whole one)
+            const int64_t k0 = g.tri_kslice * (int64_t)blockIdx.y;
+            int64_t kbeg = k0, kend = k0 + g.K;
+            if ((g.tri & 1) && m0 > kbeg) kbeg = m0;
+            if ((g.tri & 2) && n0 > kbeg) kbeg = n0;
+            if ((g.tri & 4) && m0 + BMT < kend) kend = m0 + BMT;
+            if (kbeg > kend) kbeg = kend;  // (an empty slice: the tile is written as beta * Cin)
+            gt.A += (kbeg - k0) * (A_KMAJ ? 1 : g.lda);
+            gt.B += (kbeg - k0) * (B_KMAJ ? 1 : g.ldb);
+            gt.K = kend - kbeg;
+        }
+        if constexpr (BMT == BM)
+            gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
+        else
+            gemm_f64_tile_m32<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
+        if (rep + 1 < reps) __syncthreads();  // (the LDS stages are reused by the mirrored tile)
     }
-    if constexpr (BMT == BM)
-        gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
-    else
-        gemm_f64_tile_m32<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
 }
 
 // Two kernel symbols over the same body: the lower-mode launch is the trailing SYRK update of the factorisation (the
@@ -167,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void rows_solve_kernel(const RowsSolveArgs 
     GemmArgs g;
     g.M = a.rows;
     g.own_world = 1; g.own_rank = 0; g.own_nb = 1; g.own_col0 = 0;
+    g.mirror_tiles = 0; g.tri_kslice = 0;
     g.lower = 0; g.tri = 0; g.place = 0; g.nres = 0; g.epoch = 0; g.ntiles = 0; g.xcc_word = nullptr; g.claim = nullptr; g.max_exit = 0;
     g.tiles_m = 1; g.tiles_n = 1; g.sw_log2 = 0; g.super_m = 1; g.nsuper = 0; g.per_xcd = 0;
     g.batch_a = g.batch_b = g.batch_c = g.batch_d = 0;
@@ -272,9 +281,11 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
     const int64_t tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     // (the trailing updates of a factorisation -- profile class SYRK -- keep round 1's rule: their launches stay
     // syrk_lower_f64_kernel launches, which is what the profile class and the rocprofv3 summaries count)
-    if (d.batch <= 1 && d.own_world <= 1 && !d.tri && ctx->ls == ctx->stream && ctx->splitk != 0 &&
+    if (d.batch <= 1 && d.own_world <= 1 && (!d.tri || d.tri_splitk) && !d.dynamic && ctx->ls == ctx->stream && ctx->splitk != 0 &&
         tiles <= (d.prof_cls == FR_PROF_SYRK ? 192 : kSplitkTiles) && d.K >= (d.prof_cls == FR_PROF_SYRK ? 2048 : kSplitkMinK) &&
         d.M <= 65535 * 256) {
+        // (triangular operands: about half of the slices only meet structural zeros and retire at once; twice the slices to make up
+        // for them was measured and is slower -- 166 -> 200 us for a 2048 x 1024 x 2048 leaf: more partial sums to write and add)
         int64_t S = (kSplitkTarget + tiles - 1) / tiles;
         if (S > d.K / kSplitkSlice) S = d.K / kSplitkSlice;
         if (S > 32) S = 32;
@@ -293,6 +304,7 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
             p.batch_a = d.a_kmajor ? ks : ks * d.lda;
             p.batch_b = d.b_kmajor ? ks : ks * d.ldb;
             p.batch_c = p.batch_d = d.M * d.N;
+            p.tri_kslice = d.tri ? ks : 0;  // (slices that only meet structural zeros write zeros and retire)
             FR_TRY(launch_gemm_plain(ctx, p));
             const double* cin = d.Cin ? d.Cin : d.D;
             const int64_t ldcin = d.Cin ? d.ldcin : d.ldd;
@@ -338,9 +350,16 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     // ones the fit at N = 8192 went from 9.1 to 10.2 ms)
     int64_t small_max = ctx->small_tiles;
     if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip && ctx->ls == ctx->stream2 && small_max > 32 * ctx->reserve_now) small_max = 32 * ctx->reserve_now;
-    const bool small = small_max > 0 && !d.lower && !d.tri && d.M > BMS && d.D != d.B /* in place over op(B) needs ONE tile row */ &&
-                       g.tiles_m * g.tiles_n * (d.batch > 1 ? d.batch : 1) <= small_max;
+    const bool small = (small_max > 0 && !d.lower && !d.tri && d.M > BMS && d.D != d.B /* in place over op(B) needs ONE tile row */ &&
+                        g.tiles_m * g.tiles_n * (d.batch > 1 ? d.batch : 1) <= small_max) ||
+                       (d.force_small && !d.lower && d.M > BMS && d.D != d.B);
     if (small) g.tiles_m = (d.M + BMS - 1) / BMS;
+    g.tri_kslice = d.tri_kslice;
+    g.mirror_tiles = 0;
+    if (d.mirror && !d.lower && d.batch <= 1 && g.tiles_m >= 2 && g.tiles_m % 2 == 0) {
+        g.mirror_tiles = g.tiles_m;
+        g.tiles_m /= 2;
+    }
     double flops;
     int64_t ntiles;
     g.sw_log2 = 3;

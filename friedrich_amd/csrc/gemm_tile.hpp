@@ -47,6 +47,13 @@ struct GemmArgs {
     //   2: kbeg = n0  (op(B)(k, n) = 0 for k < n: a lower-triangular matrix as the right operand)
     //   4: kend = m0 + 128  (op(A)(m, k) = 0 for k > m: a lower-triangular matrix as the left operand)
     int tri;
+    // mirrored row tiles (> 0: the number of row tiles of the product; tiles_m is then half of it): a workgroup computes row
+    // tile tm and then row tile mirror_tiles - 1 - tm -- with a triangular left operand (tri 1 / 4) the two contractions add
+    // up to the same length for every workgroup (the big solve leaves: chol.hip)
+    int64_t mirror_tiles;
+    // split-K launches with triangular operands: batch member z holds the slice [z * tri_kslice, (z + 1) * tri_kslice) of the
+    // contraction; the restriction above is applied in the coordinates of the whole contraction (0: not sliced)
+    int64_t tri_kslice;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile

@@ -61,7 +61,9 @@ __device__ __forceinline__ double div_uniform(double a, double c)
 // two fused steps (Cody-Waite, |r| <= 0.3466); exp(r) by its Taylor polynomial of degree 13 (remainder 0.3466^14 / 14! = 4e-18
 // relative) in Horner form; scaled by 2^n with v_ldexp_f64 (one rounding: gradual underflow comes out right).  ~21 instructions
 // against ~35 of the library routine, which carries the full special-case handling of an arbitrary argument.  Arguments below
-// -746 give 0; NaN propagates; overflow gives +inf through ldexp.
+// -746 give 0; NaN propagates; overflow gives +inf (through ldexp up to the first arguments whose n no longer fits, and by the
+// explicit select beyond -- x = +inf would otherwise reduce to inf - inf = NaN.  Positive arguments are reachable: the Matern-5/2
+// GRADIENT keeps the reference's signed length scale, kernel.rs:881-900, so a negative ls gives exp(+x)).
 __device__ __forceinline__ double exp_fast(double x)
 {
     const double n = __builtin_rint(x * 1.44269504088896338700e+00);
@@ -82,7 +84,7 @@ __device__ __forceinline__ double exp_fast(double x)
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     const double e = __builtin_ldexp(p, (int)n);
-    return x < -746.0 ? 0.0 : e;
+    return x < -746.0 ? 0.0 : (x > 710.0 ? __builtin_inf() : e);
 }
 
 // KIND >= 0: the leaf kind is a compile-time constant (single-leaf programs get a kernel of their own: no dispatch, the

@@ -34,7 +34,8 @@ struct TrsmnArgs {
     const double* A;    // factor buffer: lower triangle L; strict upper off-diagonal blocks hold L^T (backward)
     int64_t ld, n;
     const double* inv;  // inverse blocks (forward) or transposed inverse blocks (backward)
-    const double* mchain;  // single-group kernel: the chain products M_b = inv_b * (tile next to the diagonal), block b at b * 128 * 128
+    const double* mchain;  // single-group / wide kernels: the chain products M_b = inv_b * (tile next to the diagonal), block b at b * 128 * 128
+    const double* mchain2; // wide kernel: the same with the tile TWO blocks from the diagonal
     double* B;          // n x m right-hand sides in, solutions out
     int64_t ldb;
     int m;
@@ -90,8 +91,9 @@ __device__ __forceinline__ void load_half(const Frag& f, int H, int w, int l15, 
     for (int u = 0; u < 16; ++u) buf[u] = (base + (int64_t)(4 * u) * f.stride)[lane_off];
     if (f.mrows < NB || f.kcols < NB) {  // last block only: zeros outside the valid extent (the addresses exist)
         const bool mok = 16 * w + l15 < f.mrows;
+        const int klim = f.kcols - 64 * H;  // (uniform: one lane value, lq, against sixteen scalars)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) buf[u] = (mok && 64 * H + 4 * u + lq < f.kcols) ? buf[u] : 0.0;
+        for (int u = 0; u < 16; ++u) buf[u] = (mok && lq < klim - 4 * u) ? buf[u] : 0.0;
     }
 }
 
@@ -232,9 +234,12 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArg
 // rounds of a 60-step chain (1.6 ms for 3e10 flop: an MFMA-sized job on a memory-shaped kernel).  Here a wave owns 16 rows and
 // NQ = 4 accumulator tiles -- every factor fragment feeds four MFMAs -- so the factor is read m / 64 times and a solve of 512
 // columns onto 8192 rows is ONE round.  What bounds it then is the chain of hand-offs, so the chain carries one product, as in
-// the single-group kernel:  x_r = y' - M_r x_(r-1)  with  y' = W_r (b_r - sum_(q < r-1) L[r, q] x_q)  formed while the neighbour
-// is still being computed and  M_r = W_r L[r, r-1]  cached per factor (ensure_chain_products).  Items of a block, in order:
-// the tiles of all dependencies but the neighbour; the inverse block (operand t'); M (operand -x_neighbour).
+// the single-group kernel, and here also for the dependency before it (with one product, 6.8 us of a CU's matrix cores at 64
+// columns, the path "x_(r-2) arrives -> its tile -> closing product -> ready for x_(r-1)" was as long as the chain step
+// itself: measured 19 us per step with M alone):
+//     x_r = y'' - M2_r x_(r-2) - M_r x_(r-1),     y'' = W_r (b_r - sum_(q < r-2) L[r, q] x_q),
+//     M_r = W_r L[r, r-1],  M2_r = W_r L[r, r-2]   cached per factor (ensure_chain_products).
+// Items of a block, in order: the tiles of all dependencies but the last two; the inverse block (operand t'); M2; M.
 // LDS: one operand block [128 k][64 columns] = 64 KiB, so two workgroups share a CU (two groups' chains side by side); a
 // row is 512 B = all 64 banks, so the four k-rows one fragment read touches would collide four ways: the 16-column segment
 // index is XORed with k & 3.
@@ -270,14 +275,17 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_wide_kernel(const TrsmnArg
         if (bi < 0) return;
         const int blk = a.bwd ? last - bi : bi;
         const int cnt = a.bwd ? last - blk : blk;      // dependencies; the neighbour is the last of them
-        const int nitems = cnt == 0 ? 1 : cnt + 1;     // tiles of dep(0 .. cnt - 2), the inverse block, M
+        // items: the tiles of dep(0 .. cnt - 3); the inverse block (operand t' -> y''); then ONE product per arriving block of
+        // the two nearest dependencies: M2 (operand -x two blocks away), M (operand -x_neighbour)
+        const int nt = cnt >= 2 ? cnt - 2 : 0;
+        const int nitems = nt + 1 + (cnt >= 2 ? 1 : 0) + (cnt >= 1 ? 1 : 0);
         const int64_t b0 = (int64_t)blk * NB;
         const int64_t row = b0 + 16 * w + l15;
         auto frag_of = [&](int q) -> Frag {
-            if (q + 1 < cnt) return item_frag(a, blk, a.bwd ? last - q : q, false);
-            if (q + 1 == cnt || cnt == 0) return item_frag(a, blk, 0, true);
-            Frag f;  // the chain product (rows / columns outside a last, partial block: see ensure_chain_products)
-            f.base = a.mchain + (int64_t)blk * (NB * NB);
+            if (q < nt) return item_frag(a, blk, a.bwd ? last - q : q, false);
+            if (q == nt) return item_frag(a, blk, 0, true);
+            Frag f;  // a chain product (rows / columns outside a last, partial block: see ensure_chain_products)
+            f.base = ((q == nt + 1 && cnt >= 2) ? a.mchain2 : a.mchain) + (int64_t)blk * (NB * NB);
             f.stride = NB;
             f.mrows = f.kcols = NB;
             return f;
@@ -293,25 +301,33 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_wide_kernel(const TrsmnArg
             }
         double H0[16], H1[16];  // first / second half of the current item; the next half is always in flight
         load_half(frag_of(0), 0, w, l15, lq, H0);
+        const double* xrd[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) xrd[j] = xs + lq * MRT + ((16 * j + l15) ^ (lq << 4));
 #pragma nounroll
         for (int q = 0; q < nitems; ++q) {
             load_half(frag_of(q), 1, w, l15, lq, H1);
-            const bool is_w = (q + 1 == cnt) || cnt == 0;
+            const bool is_w = q == nt;
             if (!is_w) {
-                // a solution block -> LDS (the chain product takes the neighbour's block NEGATED: x = y' + M (-x_neighbour));
+                // a solution block -> LDS (the chain products take their block NEGATED: x = y'' + M2 (-x_2) + M (-x_neighbour));
                 // the barrier inside the wait also tells that every wave is done with the operand before
-                const bool is_m = q == cnt;
-                const int dep = is_m ? (a.bwd ? blk + 1 : blk - 1) : (a.bwd ? last - q : q);
+                const bool is_m = q > nt;
+                const int dist = (q == nt + 1 && cnt >= 2) ? 2 : 1;
+                const int dep = is_m ? (a.bwd ? blk + dist : blk - dist) : (a.bwd ? last - q : q);
                 if (!handoff_wait_ge<false>(a.flags + dep, 1, a.status)) return;  // no acquire fence: write-through stores, sc1 loads
                 const gvd2* src = (const gvd2*)(a.xg + (int64_t)dep * (NB * MRT));
-                d2_t v[(NB * MRT) / (2 * NTH)];
+                constexpr int PIECES = (NB * MRT) / (2 * NTH), BATCH = 4;  // 16-byte pieces per lane, four in flight (registers)
 #pragma unroll
-                for (int i = 0; i < (NB * MRT) / (2 * NTH); ++i) v[i] = src[t + NTH * i];
+                for (int i0 = 0; i0 < PIECES; i0 += BATCH) {
+                    d2_t v[BATCH];
 #pragma unroll
-                for (int i = 0; i < (NB * MRT) / (2 * NTH); ++i) {
-                    const int e = 2 * (t + NTH * i);
-                    const d2_t u = is_m ? -v[i] : v[i];
-                    *reinterpret_cast<d2_t*>(xs + wide_idx<NQ>(e / MRT, e % MRT)) = u;
+                    for (int i = 0; i < BATCH; ++i) v[i] = src[t + NTH * (i0 + i)];
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        const int e = 2 * (t + NTH * (i0 + i));
+                        const d2_t u = is_m ? -v[i] : v[i];
+                        *reinterpret_cast<d2_t*>(xs + wide_idx<NQ>(e / MRT, e % MRT)) = u;
+                    }
                 }
                 __syncthreads();
             } else {
@@ -327,16 +343,27 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_wide_kernel(const TrsmnArg
                     }
                 __syncthreads();
             }
+            // operand fragments one k-step ahead of their MFMAs, and no further (sched_barrier: left to itself the scheduler hoists
+            // the LDS reads of a whole half -- 128 registers -- and spills the factor fragments)
+            // (k = 64 H + 4 u + lq: k & 3 == lq for every read of a lane, so its swizzled column is fixed per accumulator tile and the
+            // reads are one lane base + immediate offsets)
+            double xa[NQ], xn[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) xa[j] = xrd[j][0];
 #pragma unroll
             for (int H = 0; H < 2; ++H) {
                 if (H == 1 && q + 1 < nitems) load_half(frag_of(q + 1), 0, w, l15, lq, H0);
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
+                    if (64 * H + 4 * (u + 1) < NB) {  // element (k = 64 H + 4 (u + 1) + lq, column 16 j + l15) of the operand block
 #pragma unroll
-                    for (int j = 0; j < NQ; ++j) {
-                        const double xf = xs[wide_idx<NQ>(64 * H + 4 * u + lq, 16 * j + l15)];  // element (k = 64 H + 4 u + lq, column 16 j + l15)
-                        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf, H == 0 ? H0[u] : H1[u], acc[j], 0, 0, 0);
+                        for (int j = 0; j < NQ; ++j) xn[j] = xrd[j][(64 * H + 4 * (u + 1)) * MRT];
                     }
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[j], H == 0 ? H0[u] : H1[u], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) xa[j] = xn[j];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -665,7 +692,7 @@ __global__ __launch_bounds__(256) void transpose_inv_kernel(const double* __rest
 
 static int ensure_transposed(fr_ctx* ctx, fr_chol* c)
 {
-    if (c->ut_gen == c->gen && c->dinvt) return FR_OK;
+    if (c->ut_gen == c->gen && c->ut_n == c->n && c->dinvt) return FR_OK;
     const int64_t nblk = (c->n + NB - 1) / NB;
     const int64_t cap_blk = (c->capacity + NB - 1) / NB;
     if (c->dinvt_cap < cap_blk) {
@@ -684,33 +711,36 @@ static int ensure_transposed(fr_ctx* ctx, fr_chol* c)
     hipLaunchKernelGGL(transpose_inv_kernel, dim3(2, 2, (unsigned)nblk), dim3(256), 0, ctx->ls, c->dinv, c->dinvt);
     FR_HIP(ctx, hipGetLastError());
     c->ut_gen = c->gen;
+    c->ut_n = c->n;
     return FR_OK;
 }
 
-// The chain products of the single-group kernel: M_b = W_b L[b, b - 1] (forward) / W_b^T L[b + 1, b]^T (backward; both operands
-// from the transposed copy), b = every block with a neighbour -- ONE batched product of 128^3 per block row (n = 32768: 1 GFLOP,
-// 32 MiB per direction), cached with the factor's generation like the transposed copy.  (Round 3 first formed M inside the solve,
-// 31 us at the start of every block's life and 64 more live registers next to it.)
-static int ensure_chain_products(fr_ctx* ctx, fr_chol* c, bool fwd, int prof_cls)
+// The chain products: M_b = W_b L[b, b - k] (forward) / W_b^T L[b + k, b]^T (backward; both operands from the transposed
+// copy), k = 1 (the neighbour: single-group and wide kernels) and k = 2 (wide kernel), b = every block with such a dependency --
+// ONE batched product of 128^3 per block row (n = 32768: 1 GFLOP, 32 MiB per direction and distance), cached per factor like
+// the transposed copy: valid for the factor's generation AND its row count (add_rows solves against the old rows under the
+// new generation before the factor grows).  (Round 3 first formed M inside the solve, 31 us at the start of every block's
+// life and 64 more live registers next to it.)
+static int ensure_chain_products(fr_ctx* ctx, fr_chol* c, bool fwd, int k, int prof_cls)
 {
-    const int dir = fwd ? 0 : 1;
+    const int slot = (fwd ? 0 : 1) + 2 * (k - 1);
     const int64_t nblk = (c->n + NB - 1) / NB;
-    if (nblk < 2) return FR_OK;
-    if (c->mchain_gen[dir] == c->gen && c->mchain[dir]) return FR_OK;
+    if (nblk < k + 1) return FR_OK;
+    if (c->mchain_gen[slot] == c->gen && c->mchain_n[slot] == c->n && c->mchain[slot]) return FR_OK;
     const int64_t cap_blk = (c->capacity + NB - 1) / NB;
-    if (c->mchain_cap[dir] < cap_blk) {
-        if (c->mchain[dir]) {
+    if (c->mchain_cap[slot] < cap_blk) {
+        if (c->mchain[slot]) {
             (void)hipStreamSynchronize(ctx->stream);
-            (void)hipFree(c->mchain[dir]);
-            c->mchain[dir] = nullptr;
-            c->mchain_cap[dir] = 0;
+            (void)hipFree(c->mchain[slot]);
+            c->mchain[slot] = nullptr;
+            c->mchain_cap[slot] = 0;
         }
-        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->mchain[dir], sizeof(double) * (size_t)cap_blk * NB * NB));
-        c->mchain_cap[dir] = cap_blk;
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&c->mchain[slot], sizeof(double) * (size_t)cap_blk * NB * NB));
+        c->mchain_cap[slot] = cap_blk;
     }
     // full blocks as ONE batched product; a last, partial block (rem rows) separately, restricted to what is valid: forward, its
-    // tile L[last, last - 1] has rem rows (K = rem; rows >= rem of M only reach solution entries nobody reads); backward, the
-    // upper-copy block (last - 1, last) has rem columns (N = rem, the other columns of M zero: they meet the zero entries of
+    // tile L[last, last - k] has rem rows (K = rem; rows >= rem of M only reach solution entries nobody reads); backward, the
+    // upper-copy block (last - k, last) has rem columns (N = rem, the other columns of M zero: they meet the zero entries of
     // the last solution block)
     const int64_t ld = c->ld_a;
     const int64_t nfull = c->n / NB, rem = c->n - nfull * NB;
@@ -723,43 +753,44 @@ static int ensure_chain_products(fr_ctx* ctx, fr_chol* c, bool fwd, int prof_cls
     g.batch_b = NB + NB * ld;
     g.batch_c = g.batch_d = NB * NB;
     g.ldcin = g.ldd = NB;
-    double* Mc = c->mchain[dir];
-    if (fwd) {  // blocks 1 .. nblk - 1: W_b x L[b, b - 1]
-        g.A = c->dinv + NB * NB;
-        g.B = c->A + NB;
-        g.D = Mc + NB * NB;
+    double* Mc = c->mchain[slot];
+    if (fwd) {  // blocks k .. nblk - 1: W_b x L[b, b - k]
+        g.A = c->dinv + (int64_t)k * NB * NB;
+        g.B = c->A + (int64_t)k * NB;
+        g.D = Mc + (int64_t)k * NB * NB;
         g.Cin = g.D;
-        g.batch = nfull - 1;
+        g.batch = nfull - k;
         if (g.batch >= 1) FR_TRY(launch_gemm(ctx, g));
-        if (rem > 0 && nfull >= 1) {
+        if (rem > 0 && nfull >= k) {
             g.batch = 1;
             g.K = rem;
             g.A = c->dinv + nfull * (NB * NB);
-            g.B = c->A + nfull * NB + (nfull - 1) * NB * ld;
+            g.B = c->A + nfull * NB + (nfull - k) * NB * ld;
             g.D = Mc + nfull * (NB * NB);
             g.Cin = g.D;
             FR_TRY(launch_gemm(ctx, g));
         }
-    } else {  // blocks 0 .. nblk - 2: W_b^T x (block (b, b + 1) of the upper copy)
+    } else {  // blocks 0 .. nblk - 1 - k: W_b^T x (block (b, b + k) of the upper copy)
         g.A = c->dinvt;
-        g.B = c->A + NB * ld;
+        g.B = c->A + (int64_t)k * NB * ld;
         g.D = Mc;
         g.Cin = g.D;
-        g.batch = nfull - 1;
+        g.batch = nfull - k;
         if (g.batch >= 1) FR_TRY(launch_gemm(ctx, g));
-        if (rem > 0 && nfull >= 1) {
-            const int64_t b = nfull - 1;
+        if (rem > 0 && nfull >= k) {
+            const int64_t b = nfull - k;
             FR_HIP(ctx, hipMemsetAsync(Mc + b * (NB * NB), 0, sizeof(double) * NB * NB, ctx->ls));
             g.batch = 1;
             g.N = rem;
             g.A = c->dinvt + b * (NB * NB);
-            g.B = c->A + b * NB + (b + 1) * NB * ld;
+            g.B = c->A + b * NB + (b + k) * NB * ld;
             g.D = Mc + b * (NB * NB);
             g.Cin = g.D;
             FR_TRY(launch_gemm(ctx, g));
         }
     }
-    c->mchain_gen[dir] = c->gen;
+    c->mchain_gen[slot] = c->gen;
+    c->mchain_n[slot] = c->n;
     return FR_OK;
 }
 
@@ -770,12 +801,13 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     fr_chol* c = const_cast<fr_chol*>(cc);  // the transposed copy is a cache: logically const
     const int64_t n = c->n;
     if (n <= 0 || m <= 0) return FR_OK;
-    // right-hand sides per column group: 16; 32 (the half-tile kernel with two MFMA tiles per workgroup) from narrow_pair_min
-    // right-hand sides on
-    // (measured, scripts/narrow_pair_ab.py: pairs pay from 128 right-hand sides on against a factor of 16384+ rows -- n = 32768:
-    // m = 128 / 256 / 512 forward solve 8.1 / 14.7 / 27.8 -> 7.7 / 12.7 / 22.9 ms -- and cost up to 60 % on smaller solves)
-    const int64_t pair_min = ctx->narrow_pair_min >= 0 ? ctx->narrow_pair_min : (n >= 12288 ? 128 : 0);
-    const int nq = (pair_min > 0 && m >= pair_min) ? 2 : 1;
+    // right-hand sides per column group: 16 below narrow_wide_min (128) right-hand sides; from there on 64 (the wide kernel:
+    // four MFMA tiles per wave on the same factor fragments, one product on the chain).  The 32-wide pair variant of the
+    // half-tile kernel (option narrow_pair_min, round 3's rule: from 128 right-hand sides against >= 12288 rows) stays
+    // selectable for A/B runs (scripts/narrow_wide_ab.py).
+    const int64_t wide_min = ctx->narrow_wide_min >= 0 ? ctx->narrow_wide_min : 128;
+    const int64_t pair_min = ctx->narrow_pair_min >= 0 ? ctx->narrow_pair_min : 0;
+    const int nq = (wide_min > 0 && m >= wide_min) ? 4 : ((pair_min > 0 && m >= pair_min) ? 2 : 1);
     const int MRT = 16 * nq;
     const int ngroups = (int)((m + MRT - 1) / MRT);
     if (ngroups > 65535) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow solve: too many right-hand sides");
@@ -798,10 +830,14 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     a.ld = c->ld_a;
     a.n = n;
     a.inv = fwd ? c->dinv : c->dinvt;
-    a.mchain = nullptr;
-    if (nq == 1 && ngroups == 1) {
-        FR_TRY(ensure_chain_products(ctx, c, fwd, prof_cls));
+    a.mchain = a.mchain2 = nullptr;
+    if (nq == 4 || (nq == 1 && ngroups == 1)) {
+        FR_TRY(ensure_chain_products(ctx, c, fwd, 1, prof_cls));
         a.mchain = c->mchain[fwd ? 0 : 1];
+    }
+    if (nq == 4) {
+        FR_TRY(ensure_chain_products(ctx, c, fwd, 2, prof_cls));
+        a.mchain2 = c->mchain[2 + (fwd ? 0 : 1)];
     }
     a.B = B;
     a.ldb = ldb;
@@ -819,7 +855,14 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     if (nq == 1 && ngroups == 1)  // the single-group kernel awaits the neighbour's block on the payload itself: fill it with the sentinel
         FR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)a.xg, (int)SENT32, (size_t)nblk * NB * MR * 2, ctx->ls));
     ProfScope ps(ctx, prof_cls, (double)n * (double)n * (double)m, 4.0 * (double)n * (double)n);
-    if (nq == 2)
+    if (nq == 4) {
+        constexpr size_t WIDE_LDS = sizeof(double) * NB * 64 + 16;
+        if (!ctx->trsmw_lds_set) {
+            FR_HIP(ctx, hipFuncSetAttribute((const void*)trsm_narrow_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS));
+            ctx->trsmw_lds_set = true;
+        }
+        hipLaunchKernelGGL(trsm_narrow_wide_kernel<4>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), WIDE_LDS, ctx->ls, a);
+    } else if (nq == 2)
         hipLaunchKernelGGL(trsm_narrow_half_kernel<2>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     else if (ngroups >= 2)
         hipLaunchKernelGGL(trsm_narrow_half_kernel<1>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);

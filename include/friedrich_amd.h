@@ -126,7 +126,8 @@ const char* fr_last_error(const fr_ctx* ctx);
  *                    n x 1 solves instead */
 int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
 /* Observability: "solve_retries" = how often an entry point of this context repeated its work on the recursive path because a
- * persistent solve gave up on a hand-off (0 in normal operation); "comm_timeouts" = how often a wait for a collective ran out;
+ * persistent solve gave up on a hand-off (0 in normal operation); "comm_timeouts" = how often a wait for a collective ran out; "stale_status_drops" = time-outs
+ * left unread by an entry point that returned early and dropped by the next one;
  * "pool_bytes" = bytes held by the workspace pool.
  * Environment read when a context is created (operators / tests; none is needed in normal use):
  *   FRIEDRICH_AMD_DIST_SCHEDULE = 0 | 1 | 2, FRIEDRICH_AMD_COMM_TIMEOUT_MS   the options of the same name without touching the host program

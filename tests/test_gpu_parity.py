@@ -256,6 +256,55 @@ def test_solves_match_oracle(ctx, n, m):
     chol.free()
 
 
+@pytest.mark.parametrize("n,m", [(4096, 192), (4096 + 700, 256), (6144 + 512, 700), (4100, 200)])
+def test_big_leaf_solves_match_oracle(ctx, n, m):
+    """A few hundred right-hand sides against >= 4096 rows: left-looking over 2048-row blocks with explicit 2048-block inverses
+    (chol.hip: trsm_big; both leaf variants: split along K up to 640 columns, mirrored 32-row tiles above), the rows behind the
+    last whole block through the 512-leaf recursion (700 / 4 rows: with and without a whole 512-block) -- forward
+    (solve_lower_triangular, mod.rs:260-263) and forward + backward (Cholesky::solve, mod.rs:298, 379) against the oracle's
+    substitutions, and against the library's own 512-leaf recursion."""
+    k = ("squared_exp", 0.9, 1.3)
+    X = rand_inputs(n, 6, n + m)
+    B = np.asfortranarray(np.random.default_rng(m).standard_normal((n, m)))
+    with O.threads():
+        st, L_o, _ = O.make_cholesky_cov_matrix_cols(k, X, 0.3)
+        L_o = np.tril(L_o)
+        W_o = O.solve_lower(L_o, B)[1]
+        Z_o = O.chol_solve(L_o, B)
+    chol = ctx.cholesky_from_inputs(k, X, 0.3)
+    W, Z = chol.solve_lower(B), chol.solve(B)
+    assert rel_err(W, W_o) < TOL and rel_err(Z, Z_o) < TOL
+    ctx.set_option("bigleaf_max", 0)
+    try:
+        W0, Z0 = chol.solve_lower(B), chol.solve(B)
+    finally:
+        ctx.set_option("bigleaf_max", -1)
+    assert rel_err(W, W0) < 1e-11 and rel_err(Z, Z0) < 1e-11
+    chol.free()
+
+
+def test_big_leaf_inverses_follow_add_rows(ctx):
+    """The cached 512- and 2048-block inverses are extended, not rebuilt, when rows are appended (the old blocks stay valid:
+    algebra/mod.rs:108-124 only appends): a factor grown 4096 -> 6656 in 512-row chunks (its L21 solves of 512 right-hand sides
+    take the big leaves themselves) solves like the directly factored one, block boundaries at 4096 (exact) and 6144 crossed."""
+    k = ("squared_exp", 0.9, 1.3)
+    n0, n1, m = 4096, 6656, 320
+    X = rand_inputs(n1, 5, 17)
+    B = np.asfortranarray(np.random.default_rng(3).standard_normal((n1, m)))
+    grown = ctx.cholesky_from_inputs(k, X[:n0], 0.3, capacity_hint=n1)
+    assert rel_err(grown.solve(B[:n0]), ctx.cholesky_from_inputs(k, X[:n0], 0.3).solve(B[:n0])) < 1e-11
+    for hi in range(n0 + 512, n1 + 1, 512):
+        grown.add_rows(k, np.asfortranarray(X[:hi]), 512, 0.3)
+        if hi in (n0 + 512, n1):
+            grown.solve_lower(B[:hi])  # (uses and extends the caches between appends)
+    direct = ctx.cholesky_from_inputs(k, X, 0.3)
+    assert rel_err(grown.l(), direct.l()) < 1e-10
+    assert rel_err(grown.solve(B), direct.solve(B)) < 1e-9
+    assert rel_err(grown.solve_lower(B), direct.solve_lower(B)) < 1e-9
+    grown.free()
+    direct.free()
+
+
 def test_upload_download_roundtrip(ctx):
     k = ("squared_exp", 0.8, 1.3)
     n = 333
@@ -455,6 +504,30 @@ def test_grad_terms_match_oracle(ctx, kernel):
     fin = np.isfinite(gs_o)
     assert np.array_equal(np.isfinite(gs), fin)
     assert np.max(np.abs(gs[fin] - gs_o[fin])) < 1e-8 * (np.max(np.abs(gs_o[fin])) + 1.0)
+    chol.free()
+
+
+@pytest.mark.parametrize("ls", [-0.7, -2e-3], ids=["finite", "overflowing"])
+def test_grad_terms_matern2_negative_length_scale(ctx, ls):
+    """The Matern-5/2 gradient keeps the reference's SIGNED length scale in its exponent (kernel.rs:881-900): a negative ls
+    evaluates exp(+x).  ls = -0.7: finite values through the positive-argument branch of the in-tree exp; ls = -2e-3:
+    exp(+x) overflows -- the reference gets +inf there (the gradient is then inf / NaN), and so must the device, entry for
+    entry (round 3's exp returned NaN for an infinite argument where libm returns +inf)."""
+    n, d = 200, 2
+    X = rand_inputs(n, d, 5)
+    y = np.sin(X.sum(axis=1))
+    kernel, noise = ("matern2", ls, 1.2), 0.3
+    gp = O.OracleGP(O.ZeroPrior(), kernel, noise, None, X, y)
+    chol = ctx.cholesky_from_inputs(kernel, X, noise)
+    assert rel_err(chol.l(), np.tril(gp.L)) < 1e-9  # (the kernel itself takes |ls|: kernel.rs:873)
+    g_o = gp.gradient()
+    g, _ = chol.grad_terms(kernel, y, noise, scaled=False, nb_parameters=2)
+    fin = np.isfinite(g_o)
+    assert np.array_equal(np.isfinite(g), fin), (g, g_o)
+    # (where exp(+x) overflows both gradients are non-finite; WHICH non-finite value -- inf - inf = NaN in the reference's
+    # association, +-inf in the fused reduction's -- depends on the order of the sums and is not compared)
+    if fin.any():
+        assert np.max(np.abs(g[fin] - g_o[fin])) < 1e-8 * (np.max(np.abs(g_o[fin])) + 1.0)
     chol.free()
 
 
