@@ -36,8 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_NB = 1024  # block size of the run profiles/r03/fit32k_counters.json was collected with
-PMC_FILE = os.path.join("profiles", "r03", "fit32k_counters.json")
+PMC_NB = 1024  # block size of the run profiles/r04/fit32k_counters.json was collected with
+PMC_FILE = os.path.join("profiles", "r04", "fit32k_counters.json")
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; scripts/mfma_f64_peak measures 77.0-77.6 on the box
 
 

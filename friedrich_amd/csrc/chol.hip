@@ -916,7 +916,8 @@ static bool use_big_leaves(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64
     // 0.36 / 0.85 / 1.93 against 0.33 / 0.73 / 2.39; 256 columns 0.39 / 0.94 / 2.42 against 0.38 / 1.14 / 4.1 (recursion: 0.47 /
     // 1.08 / 2.68); 1024 columns 0.54 / 1.63 / 5.11 against the recursion's 1.06 / 2.65 / 7.38; 2048 columns 0.96 / 2.73 / 9.24
     // against 1.39 / 3.73 / 11.6
-    const int64_t mmax = ctx->bigleaf_max >= 0 ? ctx->bigleaf_max : 2048;
+    // ... and 4096 columns at N = 16384 / 32768 (the predict half of the bench step): forward solve 20.4 / 72.8 -> 17.3 / 66.8 ms
+    const int64_t mmax = ctx->bigleaf_max >= 0 ? ctx->bigleaf_max : 4096;
     return ctx->leaf512 != 0 && !c->refine && n == c->n && n >= 2 * GB && m <= mmax && (m >= 192 || (m >= 96 && n >= 12288));
 }
 

@@ -82,10 +82,10 @@ struct fr_ctx {
     int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
     int64_t narrow_batched_max = -1;  // right-hand sides up to which the persistent solve runs in column groups of 16 (trsm_narrow.hip); -1: chosen from n and m (chol.hip)
     int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0 / -1: never; A/B only)
-    int64_t narrow_wide_min = -1;  // ... with at least this many: 64 per column group, the wide kernel (0: never, -1: 128)
+    int64_t narrow_wide_min = -1;  // ... with at least this many: 64 per column group, the wide kernel (0 / -1: never; A/B only)
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
     int64_t bigleaf_max = -1;   // solves with at most this many right-hand sides (and >= 4096 rows) run left-looking over 2048-row blocks
-                                // with explicit 2048-block inverses (chol.hip: trsm_big); -1: 2048; 0: never
+                                // with explicit 2048-block inverses (chol.hip: trsm_big); -1: 4096; 0: never
     int64_t trsv = 1;           // solves with few right-hand sides as one persistent launch per direction (trsv.hip, trsm_narrow.hip)
     int64_t tri_inverse = 1;    // gradient terms: L^-1 and W^T W skip the structural zeros (chol_tri_inverse); 0: dense products
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)

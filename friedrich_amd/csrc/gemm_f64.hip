@@ -25,7 +25,7 @@
 
 namespace fr {
 
-template <bool A_KMAJ, bool B_KMAJ, int BMT = BM>
+template <bool A_KMAJ, bool B_KMAJ, int BMT = BM, bool MIRROR = false>
 __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
 {
 
@@ -92,10 +92,12 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
     }
     const int64_t n0 = tn * BN;
     if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) return;
-    const int reps = g.mirror_tiles > 0 ? 2 : 1;
+    // (MIRROR is a template parameter with kernel symbols of its own: as a run-time loop around the ONE call site of the tile
+    // function it cost the trailing-update kernel 17 registers and 228 scratch instructions -- found as doubled WRITE_SIZE)
+    constexpr int reps = MIRROR ? 2 : 1;
 #pragma nounroll
     for (int rep = 0; rep < reps; ++rep) {
-        const int64_t m0 = (rep == 0 ? tm : g.mirror_tiles - 1 - tm) * BMT;
+        const int64_t m0 = ((MIRROR && rep == 1) ? g.mirror_tiles - 1 - tm : tm) * BMT;
         GemmArgs gt = g;  // (ONE call site of the tile function: a second inlined copy would double the kernel)
         if (g.tri) {
             // triangular operand(s): skip the part of the contraction that only multiplies structural zeros
@@ -114,7 +116,7 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
             gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
         else
             gemm_f64_tile_m32<A_KMAJ, B_KMAJ>(gt, lds, m0, n0);
-        if (rep + 1 < reps) __syncthreads();  // (the LDS stages are reused by the mirrored tile)
+        if (MIRROR && rep == 0) __syncthreads();  // (the LDS stages are reused by the mirrored tile)
     }
 }
 
@@ -145,6 +147,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_m32_kernel(const GemmArgs g0)
     g.Cin += bz * g.batch_c;
     g.D += bz * g.batch_d;
     gemm_f64_body<A_KMAJ, B_KMAJ, BMS>(g, lds);
+}
+
+// 32-row tiles in mirrored pairs (GemmArgs::mirror_tiles): the big solve leaves with their triangular left operand
+template <bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(256, 2) void gemm_f64_m32_mirror_kernel(const GemmArgs g0)
+{
+    __shared__ double lds[2 * (TILE_A_S + TILE_ELEMS)];
+    GemmArgs g = g0;
+    const int64_t bz = blockIdx.y;
+    g.A += bz * g.batch_a;
+    g.B += bz * g.batch_b;
+    g.Cin += bz * g.batch_c;
+    g.D += bz * g.batch_d;
+    gemm_f64_body<A_KMAJ, B_KMAJ, BMS, true>(g, lds);
 }
 
 __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g)
@@ -356,7 +372,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     if (small) g.tiles_m = (d.M + BMS - 1) / BMS;
     g.tri_kslice = d.tri_kslice;
     g.mirror_tiles = 0;
-    if (d.mirror && !d.lower && d.batch <= 1 && g.tiles_m >= 2 && g.tiles_m % 2 == 0) {
+    if (d.mirror && small && d.b_kmajor && !d.lower && d.batch <= 1 && g.tiles_m >= 2 && g.tiles_m % 2 == 0) {
         g.mirror_tiles = g.tiles_m;
         g.tiles_m /= 2;
     }
@@ -450,7 +466,11 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.batch_d = d.batch_d;
     if (d.batch > 1 && d.lower) return set_err(ctx, FR_INVALID_ARGUMENT, "batched GEMM is full-mode only");
     dim3 grid((unsigned)ntiles, (unsigned)(d.batch > 1 ? d.batch : 1)), block(256);
-    if (small && !d.a_kmajor && !d.b_kmajor)
+    if (g.mirror_tiles > 0 && !d.a_kmajor)
+        hipLaunchKernelGGL((gemm_f64_m32_mirror_kernel<false, true>), grid, block, 0, ctx->ls, g);
+    else if (g.mirror_tiles > 0)
+        hipLaunchKernelGGL((gemm_f64_m32_mirror_kernel<true, true>), grid, block, 0, ctx->ls, g);
+    else if (small && !d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL((gemm_f64_m32_kernel<false, false>), grid, block, 0, ctx->ls, g);
     else if (small && !d.a_kmajor && d.b_kmajor)
         hipLaunchKernelGGL((gemm_f64_m32_kernel<false, true>), grid, block, 0, ctx->ls, g);

@@ -712,6 +712,24 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
     potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
 }
 
+// The same body without the register cap (157 VGPRs, nothing in scratch; capped at 128 it spills 76 B per lane, 41 scratch
+// instructions spread over its phases).  The cap exists so that the kernel fits BESIDE a resident GEMM workgroup; while XCDs
+// are set aside for the panel chain, and on the chain stream of a sharded factorisation, the diagonal-block kernel has its CU
+// to itself and the cap only costs.  FRIEDRICH_AMD_K4_UNCAPPED = 0 / 1 forces a variant (A/B runs).
+__global__ __launch_bounds__(PT, 2) void potf2_uncapped_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
+                                                            double sub, double* __restrict__ inv, int64_t ldinv,
+                                                            int64_t* __restrict__ info, double* __restrict__ cest,
+                                                            unsigned* __restrict__ xcc_word)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (xcc_word && threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_store(xcc_word, (xcc & 7u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
+}
+
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub, double* inv,
                  int64_t ldinv, int64_t* info, double* cest)
 {
@@ -720,11 +738,15 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
     if (!ctx->potf2_lds_set) {  // per context (= per device): the attribute belongs to the device's copy of the kernel
         FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
+        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_uncapped_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
         ctx->potf2_lds_set = true;
     }
+    static const int force = getenv("FRIEDRICH_AMD_K4_UNCAPPED") ? atoi(getenv("FRIEDRICH_AMD_K4_UNCAPPED")) : -1;
+    const bool uncapped = force >= 0 ? force == 1 : (ctx->reserve_now > 0 || ctx->world > 1);
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv,
-                       info, cest, ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr);
+    hipLaunchKernelGGL(uncapped ? potf2_uncapped_kernel : potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode,
+                       sub, inv, ldinv, info, cest, ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

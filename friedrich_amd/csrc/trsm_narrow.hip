@@ -801,11 +801,12 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     fr_chol* c = const_cast<fr_chol*>(cc);  // the transposed copy is a cache: logically const
     const int64_t n = c->n;
     if (n <= 0 || m <= 0) return FR_OK;
-    // right-hand sides per column group: 16 below narrow_wide_min (128) right-hand sides; from there on 64 (the wide kernel:
-    // four MFMA tiles per wave on the same factor fragments, one product on the chain).  The 32-wide pair variant of the
-    // half-tile kernel (option narrow_pair_min, round 3's rule: from 128 right-hand sides against >= 12288 rows) stays
-    // selectable for A/B runs (scripts/narrow_wide_ab.py).
-    const int64_t wide_min = ctx->narrow_wide_min >= 0 ? ctx->narrow_wide_min : 128;
+    // right-hand sides per column group: 16.  Two wider variants stay selectable for A/B runs (scripts/narrow_wide_ab.py) and are
+    // off by default: 64 per group from narrow_wide_min right-hand sides on (the wide kernel: four MFMA tiles per wave on the same
+    // factor fragments, two banded products on the chain -- measured slower than groups of 16 wherever the groups are used at
+    // all: its chain step carries a 128 x 128 x 64 product, 6.8 us of a CU's matrix cores, where 16 columns cost 1.7), 32 per
+    // group from narrow_pair_min on (round 3's rule for >= 12288 rows; those solves now take the big leaves, chol.hip).
+    const int64_t wide_min = ctx->narrow_wide_min >= 0 ? ctx->narrow_wide_min : 0;
     const int64_t pair_min = ctx->narrow_pair_min >= 0 ? ctx->narrow_pair_min : 0;
     const int nq = (wide_min > 0 && m >= wide_min) ? 4 : ((pair_min > 0 && m >= pair_min) ? 2 : 1);
     const int MRT = 16 * nq;

@@ -1,0 +1,47 @@
+"""The throughput kernels must not spill: a register spill in the trailing-update kernel shows up as doubled WRITE_SIZE and a
+few per cent of a fit, and nothing else notices (round 4: a run-time loop around the tile function's one call site cost
+syrk_lower_f64_kernel 17 registers and 228 scratch instructions until it became a template parameter).  Compiles gemm_f64.hip
+and gram.hip for gfx950 with the build's flags and reads the compiler's own resource remarks -- no GPU needed."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def resources(src):
+    cmd = [HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "friedrich_amd", "csrc"), "-I/opt/rocm/include", "-Rpass-analysis=kernel-resource-usage", "-c",
+           os.path.join(ROOT, "friedrich_amd", "csrc", src), "-o", os.devnull]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            res[cur] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur:
+            res[cur][m.group(1).split(" ")[0]] = int(m.group(2))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_throughput_kernels_do_not_spill():
+    r = resources("gemm_f64.hip")
+    checked = 0
+    for name, v in r.items():
+        if "syrk_lower_f64_kernel" in name or "15gemm_f64_kernel" in name or "19gemm_f64_m32_kernel" in name:
+            assert v["ScratchSize"] == 0, (name, v)
+            assert v["Occupancy"] >= 2, (name, v)
+            checked += 1
+    assert checked == 9, sorted(r)
+    g = resources("gram.hip")
+    leaf = [v for n, v in g.items() if "gram_kernel" in n and "ILi1ELi2" in n]  # the squared-exponential leaf of the bench
+    assert leaf and all(v["ScratchSize"] == 0 for v in leaf), g
