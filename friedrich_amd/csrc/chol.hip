@@ -855,9 +855,11 @@ static int leaf_big(fr_ctx* ctx, const fr_chol* c, int64_t row0, double* B, int6
     //    one in dispatch order the 32-row tiles took 180 us: the launch is as long as its deepest tiles).  Both run at half
     //    the rate of the dense updates: the paired tiles are bound by the L2 (a 32 x 128 tile moves 20 KiB per 131 kflop), the
     //    slices by the workgroups that hold two deep ones on one CU.  FRIEDRICH_AMD_LEAF_MIRROR = 0 / 1 forces a variant.
+    //    (Also measured: 128-row tiles claimed in dispatch order, deepest contractions first, where 16 x m / 128 of them fill the
+    //    chip -- 2048 / 4096 columns at N = 8192 / 32768: 2.84 / 66.6 ms against 2.64 / 64.3 with the mirrored pairs.  Not kept.)
     static const int leaf_force = getenv("FRIEDRICH_AMD_LEAF_MIRROR") ? atoi(getenv("FRIEDRICH_AMD_LEAF_MIRROR")) : -1;
-    const bool leaf_mirror = leaf_force >= 0 ? leaf_force == 1 : m > 640;
-    if (leaf_mirror) {
+    const int variant = leaf_force >= 0 ? leaf_force : (m > 640 ? 1 : 0);
+    if (variant == 1) {
         g.force_small = true;
         g.mirror = true;
     } else {
