@@ -1362,6 +1362,18 @@ static int upload_rows(fr_ctx* ctx, const double* src, int64_t ldsrc, double* ds
 {
     if (rows <= 0 || cols <= 0) return FR_OK;
     const bool dev = is_device_ptr(src);
+    if (!dev) {
+        // host data: packed into the pinned bounce buffer by the CPU, then one DMA the host does not wait for (a pageable
+        // source would make the copy synchronous and cost a round trip per call: fr_chol_add_rows uploads 512 x d doubles)
+        double* pin = (double*)pinned_get(ctx, sizeof(double) * (size_t)rows * (size_t)cols);
+        if (pin) {
+            FR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the previous user of the bounce buffer (a no-op on an idle stream)
+            for (int64_t j = 0; j < cols; ++j) memcpy(pin + j * rows, src + j * ldsrc, sizeof(double) * (size_t)rows);
+            FR_HIP(ctx, hipMemcpy2DAsync(dst, sizeof(double) * lddst, pin, sizeof(double) * rows, sizeof(double) * rows, cols,
+                                         hipMemcpyHostToDevice, ctx->stream));
+            return FR_OK;
+        }
+    }
     FR_HIP(ctx, hipMemcpy2DAsync(dst, sizeof(double) * lddst, src, sizeof(double) * ldsrc, sizeof(double) * rows, cols,
                                  dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     if (!dev) FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1533,6 +1545,11 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     // purposes: a persistent L21 solve that gave up on a hand-off is repeated on the recursive path (solve_retry), and an
     // append whose new diagonal blocks turn out ill-conditioned is repeated with iterative refinement (the policy of
     // assemble_and_factor; the estimates come from the re-aligned inverse blocks).
+    bool readback_ok = false;
+    if (!ctx->readback && hipHostMalloc(&ctx->readback, 4096, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->readback = nullptr;  // (falls back to separate read-backs)
+    }
     auto append = [&]() -> int {
         struct Scope {
             fr_ctx* ctx;
@@ -1587,6 +1604,18 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
                 const int64_t j = b * IB, sb = imin(IB, n_all - j);
                 FR_TRY(invert_block128(ctx, c->A + j + j * ld, ld, sb, c->dinv + b * INV_ELEMS, c->cest + b));
             }
+        // ONE synchronisation per append: the status of a persistent solve, the conditioning estimates of the blocks that
+        // changed and the zero-diagonal flag of the new rows (what the next append's checked solve asks first) come back
+        // together.  (Round 3: a synchronisation each for the append, the estimates, the next call's diagonal check and its
+        // upload of the new inputs -- ~250 us of idle GPU per add_samples(512), measured on a kernel trace.)
+        const int64_t b_lo = n_old / IB, b_hi = (n_all + IB - 1) / IB;
+        readback_ok = ctx->readback && (size_t)(b_hi - b_lo + 1) * sizeof(double) <= 4096;
+        if (readback_ok) {
+            FR_HIP(ctx, hipMemsetAsync(c->info + 2, 0, sizeof(int64_t), ctx->stream));
+            FR_TRY(launch_diag_check_zero(ctx, c->A + n_old + n_old * ld, nb_new, ld, c->info + 2));
+            FR_HIP(ctx, hipMemcpyAsync(ctx->readback, c->info + 2, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+            FR_HIP(ctx, hipMemcpyAsync((double*)ctx->readback + 1, c->cest + b_lo, sizeof(double) * (size_t)(b_hi - b_lo), hipMemcpyDeviceToHost, ctx->stream));
+        }
         FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return check_status_word(ctx);
     };
@@ -1595,8 +1624,19 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
         c->n = n_old;
         return st;
     }
+    if (readback_ok) {
+        // (the old rows' diagonal was checked before the append: the flag of the grown factor is that of its new rows)
+        c->diag_zero = *(const int64_t*)ctx->readback != 0;
+        c->diag_gen = c->gen;
+    }
     if (ctx->refine == -1 && ctx->world <= 1) {
-        FR_TRY(fetch_max_cest(c));
+        if (readback_ok) {
+            const double* h = (const double*)ctx->readback + 1;
+            for (int64_t b = 0; b < (n_all + IB - 1) / IB - n_old / IB; ++b)
+                if (h[b] > c->max_cest) c->max_cest = h[b];  // (the estimates of the old blocks are in max_cest already)
+        } else {
+            FR_TRY(fetch_max_cest(c));
+        }
         if (!c->refine && c->max_cest > ctx->refine_threshold) {
             c->refine = true;  // an ill-conditioned appended block: once more with the refinement step behind every inverse product
             st = solve_retry(ctx, append);

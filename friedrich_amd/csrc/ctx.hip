@@ -467,6 +467,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (ctx->trsv_gran) (void)hipFree(ctx->trsv_gran);
     if (ctx->trsmn_buf) (void)hipFree(ctx->trsmn_buf);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->readback) (void)hipHostFree(ctx->readback);
     if (ctx->xcc_word) (void)hipFree(ctx->xcc_word);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->claim_ring) (void)hipFree(ctx->claim_ring);

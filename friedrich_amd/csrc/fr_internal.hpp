@@ -136,6 +136,7 @@ struct fr_ctx {
     // pinned bounce buffer of the host <-> device staging (grow-only)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
+    void* readback = nullptr;  // 4 KiB of pinned host memory for small results read back with an operation's own synchronisation
     // hand-off payload + flags of the multi-column persistent solves (trsm_narrow.hip), grow-only
     void* trsmn_buf = nullptr;
     size_t trsmn_buf_cap = 0;
