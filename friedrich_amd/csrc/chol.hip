@@ -856,7 +856,9 @@ static int leaf_big(fr_ctx* ctx, const fr_chol* c, int64_t row0, double* B, int6
     //    the rate of the dense updates: the paired tiles are bound by the L2 (a 32 x 128 tile moves 20 KiB per 131 kflop), the
     //    slices by the workgroups that hold two deep ones on one CU.  FRIEDRICH_AMD_LEAF_MIRROR = 0 / 1 forces a variant.
     //    (Also measured: 128-row tiles claimed in dispatch order, deepest contractions first, where 16 x m / 128 of them fill the
-    //    chip -- 2048 / 4096 columns at N = 8192 / 32768: 2.84 / 66.6 ms against 2.64 / 64.3 with the mirrored pairs.  Not kept.)
+    //    chip -- 2048 / 4096 columns at N = 8192 / 32768: 2.84 / 66.6 ms against 2.64 / 64.3 with the mirrored pairs; and 128-row
+    //    tiles in mirrored pairs, 8 pairs x m / 128 workgroups with a contraction of 2176 each -- 4096 columns at N = 16384 /
+    //    32768: 16.6 / 64.3 ms against 16.7 / 64.5, 2048 columns 9.8 against 8.6.  Neither kept.)
     static const int leaf_force = getenv("FRIEDRICH_AMD_LEAF_MIRROR") ? atoi(getenv("FRIEDRICH_AMD_LEAF_MIRROR")) : -1;
     const int variant = leaf_force >= 0 ? leaf_force : (m > 640 ? 1 : 0);
     if (variant == 1) {
