@@ -912,18 +912,32 @@ static int trsm_big(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t
     return FR_OK;
 }
 
-// measured (scripts/narrow_wide_ab.py): see use_big_leaves
-static bool use_big_leaves(const fr_ctx* ctx, const fr_chol* c, int64_t n, int64_t m)
+// When the 2048-row leaves are taken.  Measured, forward solve of a device operand (scripts/solve_mid.py; "other" = what the
+// library did before: column groups of 16 / the 512-leaf recursion / K9 up to 16 columns), milliseconds big | other:
+//   N = 4096:   2 columns 0.120 | 0.192,  16: 0.124 | 0.209,  17: 0.124 | 0.310,  64: 0.140 | 0.308,  128: 0.141 | 0.313,  192: 0.199 | 0.355
+//   N = 8192:   2: 0.316 | 0.384,  16: 0.319 | 0.384,  24: 0.336 | 0.634,  64: 0.361 | 0.628,  128: 0.368 | 0.710,  1024: 1.63 | 2.65 (variance)
+//   N = 12288:  16: 0.584 | 0.596,  17: 0.593 | 0.972,  128: 0.645 | 1.40
+//   N = 16384:  2: 0.875 | 0.790,  16: 0.910 | 0.796 (K9's chain wins),  24: 0.93 | 1.29,  128: 1.00 | 2.44,  1024: 5.11 | 7.38 (variance)
+//   N = 32768:  24: 2.94 | 2.94,  32: 2.97 | 2.91,  48: 3.05 | 3.91,  128: 3.10 | 4.33,  4096: 64.3 | 72.8
+// i.e. the time of a leaf sweep hardly depends on the number of columns up to 128 (2 n / 2048 - 1 launches of one tile column).
+// The leaves need their inverse blocks first -- two more block levels per factor, about the cost of two such solves
+// (ensure_invbig) -- so with fewer than 192 right-hand sides they are taken from the THIRD narrow solve against a factor on
+// (or at once when the blocks exist: after add_rows the caches are only extended).
+static bool use_big_leaves(fr_ctx* ctx, const fr_chol* cc, int64_t n, int64_t m, bool count)
 {
-    // measured against the column groups and the 512-leaf recursion (scripts/narrow_wide_ab.py, predict_variance at
-    // N = 4096 / 8192 / 16384): 64 columns 0.43 / 0.98 / 2.30 ms against 0.32 / 0.67 / 1.44 in groups of 16; 128 columns
-    // 0.36 / 0.85 / 1.93 against 0.33 / 0.73 / 2.39; 256 columns 0.39 / 0.94 / 2.42 against 0.38 / 1.14 / 4.1 (recursion: 0.47 /
-    // 1.08 / 2.68); 1024 columns 0.54 / 1.63 / 5.11 against the recursion's 1.06 / 2.65 / 7.38; 2048 columns 0.96 / 2.73 / 9.24
-    // against 1.39 / 3.73 / 11.6
-    // ... and 4096 columns at N = 16384 / 32768 (the predict half of the bench step): forward solve 20.4 / 72.8 -> 17.3 / 66.8 ms
+    fr_chol* c = const_cast<fr_chol*>(cc);  // (the solve counter is a cache statistic: logically const)
     const int64_t mmax = ctx->bigleaf_max >= 0 ? ctx->bigleaf_max : 4096;
-    return ctx->leaf512 != 0 && !c->refine && n == c->n && n >= 2 * GB && m <= mmax && (m >= 192 || (m >= 96 && n >= 12288));
+    if (!(ctx->leaf512 != 0 && !c->refine && n == c->n && n >= 2 * GB && m >= 2 && m <= mmax)) return false;
+    if (ctx->bigleaf_min >= 0) return m >= ctx->bigleaf_min;  // explicit (A/B runs)
+    if (m <= 16 && n >= 12288) return false;                  // K9
+    if (m < 48 && n >= 24576) return false;                   // column groups: the same time, no blocks to build
+    if (m >= 192) return true;
+    const bool ready = c->invbig_rows > 0 && c->invbig_rows + GB >= (n / GB) * GB;  // (at most one block to add)
+    if (ready) return true;
+    if (count) ++c->narrow_solves;
+    return c->narrow_solves >= 3;
 }
+
 
 // ---- a few right-hand sides (likelihood, K^-1 y, predicting a handful of points) -----------------------------------------
 // Same recursion on memory-bound kernels that read L once per 16 columns (a matrix-vector kernel for one column): the GEMM's
@@ -1019,7 +1033,7 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         return trsm_fwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, true, cls);
-    if (use_big_leaves(ctx, c, n, m) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
+    if (use_big_leaves(ctx, c, n, m, true) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
         FR_TRY(ensure_inv512(ctx, c, cls));  // (the rows behind the last whole 2048-block take the 512-row leaves)
         FR_TRY(ensure_invbig(ctx, c, cls));
         WsGuard wb(ctx);
@@ -1099,7 +1113,7 @@ int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         return trsm_bwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, false, cls);
-    if (use_big_leaves(ctx, c, n, m) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
+    if (use_big_leaves(ctx, c, n, m, true) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
         FR_TRY(ensure_inv512(ctx, c, cls));
         FR_TRY(ensure_invbig(ctx, c, cls));
         WsGuard wb(ctx);
@@ -1129,6 +1143,7 @@ static void chol_release(fr_chol* c)
     if (c->invbig) (void)hipFree(c->invbig);
     c->invbig = nullptr;
     c->invbig_cap = c->invbig_rows = 0;
+    c->narrow_solves = 0;
     if (c->cest) (void)hipFree(c->cest);
     c->cest = nullptr;
     if (c->dinvt) (void)hipFree(c->dinvt);
@@ -1257,6 +1272,7 @@ int potrf_device(fr_ctx* ctx, fr_chol* c, int64_t j0, int64_t n, int mode, doubl
 {
     c->inv512_rows = 0;
     c->invbig_rows = 0;
+    c->narrow_solves = 0;
     ++c->gen;
     return potrf_blocked(ctx, c->A + j0 + j0 * c->ld_a, c->ld_a, n, j0, mode, sub, c->dinv + (j0 / IB) * INV_ELEMS, c->info,
                          c->nb);
@@ -1335,6 +1351,7 @@ static int assemble_and_factor_once(fr_chol* c, const fr_kprog* kernel, double n
     ctx->cur_cest = c->cest;
     c->inv512_rows = 0;
     c->invbig_rows = 0;
+    c->narrow_solves = 0;
     ++c->gen;
     drain_stale_status(ctx);  // (a time-out left behind by an earlier call must not be read as this factorisation's)
     FR_HIP(ctx, hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream));
@@ -1684,7 +1701,8 @@ static int solve_in_place(fr_chol* c, double* B, int64_t m, int64_t ldb, bool bo
 {
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
-    const bool persistent = ctx->trsv && !c->refine && c->n > 0 && m > 0 && (m == 1 || use_column_groups(ctx, c, c->n, m));
+    const bool persistent = ctx->trsv && !c->refine && c->n > 0 && m > 0 && (m == 1 || use_column_groups(ctx, c, c->n, m)) &&
+                            !(m > 1 && use_big_leaves(ctx, c, c->n, m, false) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max));
     WsGuard bk(ctx);
     double* backup = nullptr;
     if (persistent && is_device_ptr(B) && ldb >= c->n) {

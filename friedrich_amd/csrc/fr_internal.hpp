@@ -84,6 +84,7 @@ struct fr_ctx {
     int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0 / -1: never; A/B only)
     int64_t narrow_wide_min = -1;  // ... with at least this many: 64 per column group, the wide kernel (0 / -1: never; A/B only)
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
+    int64_t bigleaf_min = -1;   // ... and at least this many (-1: by measurement, chol.hip: use_big_leaves)
     int64_t bigleaf_max = -1;   // solves with at most this many right-hand sides (and >= 4096 rows) run left-looking over 2048-row blocks
                                 // with explicit 2048-block inverses (chol.hip: trsm_big); -1: 4096; 0: never
     int64_t trsv = 1;           // solves with few right-hand sides as one persistent launch per direction (trsv.hip, trsm_narrow.hip)
@@ -179,6 +180,7 @@ struct fr_chol {
     double* invbig = nullptr;
     int64_t invbig_cap = 0;  // blocks allocated
     int64_t invbig_rows = 0;
+    int64_t narrow_solves = 0;  // solves with fewer than 192 right-hand sides since the factor last changed (use_big_leaves)
     int64_t* info = nullptr;  // device: [0] = 1 + first failing column (0: none), [1] = n_subst,
                               //         [2] = 1 if a zero diagonal was seen, [3..] substituted columns
     int64_t info_cap = 0;
