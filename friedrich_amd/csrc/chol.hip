@@ -425,6 +425,13 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     if (world > 1 && nb % IB != 0) return set_err(ctx, FR_INVALID_ARGUMENT, "multi-GPU factorisation needs nb %% 128 == 0");
     const bool la = (world > 1) || (ctx->lookahead && ctx->stream2 && n > 2 * nb && ctx->ls == ctx->stream);
     if (!la) {
+        // (no second stream: the diagonal-block kernels have their CU to themselves -- the uncapped symbol, potf2.hip)
+        struct Alone {
+            fr_ctx* ctx;
+            bool saved;
+            ~Alone() { ctx->k4_alone = saved; }
+        } alone{ctx, ctx->k4_alone};
+        ctx->k4_alone = true;
         for (int64_t k = 0; k < n; k += nb) {
             const int64_t kb = imin(nb, n - k);
             FR_TRY(factor_panel(ctx, A, ld, n, k, kb, col0, mode, sub, dinv, info, T));
@@ -1661,6 +1668,14 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
             st = solve_retry(ctx, append);
             if (st != FR_OK) c->n = n_old;
         }
+    }
+    if (st == FR_OK && !c->refine && c->inv512_rows > 0) {
+        // The inverse-block caches are in use (the append's own L21 solve took them): extend them over the new rows NOW, behind
+        // the synchronisation -- the few small launches run while the host is on its way back to the caller and into the next
+        // call (~80 us of idle GPU per append on the trace) instead of in front of the next solve.  Best effort: a failure
+        // here only leaves the extension to that solve.
+        const int st2 = ensure_inv512(ctx, c, FR_PROF_GEMM_PANEL);
+        if (st2 == FR_OK && c->invbig_rows > 0) (void)ensure_invbig(ctx, c, FR_PROF_GEMM_PANEL);
     }
     return st;
 }

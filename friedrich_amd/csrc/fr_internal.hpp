@@ -112,6 +112,7 @@ struct fr_ctx {
     int64_t prof_launches[FR_PROF_COUNT] = {0};
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
+    bool k4_alone = false;         // the running factorisation has no second stream: nothing shares the diagonal-block kernel's CU
     int reserve_now = 0;           // XCDs reserved right now (set by the factorisation around the launches it applies to)
     unsigned panel_epoch = 0;      // number of the panel being factored on the panel stream (see claim_item)
     unsigned* xcc_word = nullptr;    // device: [0] = 1 + XCC_ID of the XCD the diagonal-block kernels run on (0: unknown), [1] = last panel whose chain is finished

@@ -743,7 +743,7 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
         ctx->potf2_lds_set = true;
     }
     static const int force = getenv("FRIEDRICH_AMD_K4_UNCAPPED") ? atoi(getenv("FRIEDRICH_AMD_K4_UNCAPPED")) : -1;
-    const bool uncapped = force >= 0 ? force == 1 : (ctx->reserve_now > 0 || ctx->world > 1);
+    const bool uncapped = force >= 0 ? force == 1 : (ctx->reserve_now > 0 || ctx->world > 1 || ctx->k4_alone);
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
     hipLaunchKernelGGL(uncapped ? potf2_uncapped_kernel : potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode,
                        sub, inv, ldinv, info, cest, ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr);
