@@ -1041,12 +1041,13 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, true, cls);
     if (use_big_leaves(ctx, c, n, m, true) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
-        FR_TRY(ensure_inv512(ctx, c, cls));  // (the rows behind the last whole 2048-block take the 512-row leaves)
-        FR_TRY(ensure_invbig(ctx, c, cls));
+        // (the rows behind the last whole 2048-block take the 512-row leaves).  The inverse blocks are a cache of n / 2048 x 32 MiB:
+        // if it cannot be built (memory), the solve takes the paths below instead of failing
         WsGuard wb(ctx);
-        double* tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m);
-        if (!tmpb) return FR_OUT_OF_MEMORY;
-        return trsm_big(ctx, c, n, B, m, ldb, cls, true, tmpb);
+        double* tmpb = nullptr;
+        if (ensure_inv512(ctx, c, cls) == FR_OK && ensure_invbig(ctx, c, cls) == FR_OK && (tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m)) != nullptr)
+            return trsm_big(ctx, c, n, B, m, ldb, cls, true, tmpb);
+        (void)hipGetLastError();
     }
     if (use_column_groups(ctx, c, n, m)) return launch_trsm_narrow(ctx, c, B, m, ldb, true, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, true);
@@ -1121,12 +1122,11 @@ int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
     }
     if (m == 1 && n == c->n && ctx->trsv) return launch_trsv(ctx, c, B, false, cls);
     if (use_big_leaves(ctx, c, n, m, true) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
-        FR_TRY(ensure_inv512(ctx, c, cls));
-        FR_TRY(ensure_invbig(ctx, c, cls));
         WsGuard wb(ctx);
-        double* tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m);
-        if (!tmpb) return FR_OUT_OF_MEMORY;
-        return trsm_big(ctx, c, n, B, m, ldb, cls, false, tmpb);
+        double* tmpb = nullptr;
+        if (ensure_inv512(ctx, c, cls) == FR_OK && ensure_invbig(ctx, c, cls) == FR_OK && (tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m)) != nullptr)
+            return trsm_big(ctx, c, n, B, m, ldb, cls, false, tmpb);
+        (void)hipGetLastError();
     }
     if (use_column_groups(ctx, c, n, m)) return launch_trsm_narrow(ctx, c, B, m, ldb, false, cls);
     if (m <= ctx->narrow_max && n == c->n && n >= 4 * IB) return narrow_solve(ctx, c, n, B, m, ldb, cls, false);

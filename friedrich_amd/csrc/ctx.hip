@@ -561,11 +561,6 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->narrow_batched_max = value;
         return FR_OK;
     }
-    if (!strcmp(name, "narrow_pair_min")) {
-        if (value < -1) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow_pair_min must be >= -1");
-        ctx->narrow_pair_min = value;
-        return FR_OK;
-    }
     if (!strcmp(name, "bigleaf_min")) {
         if (value < -1) return set_err(ctx, FR_INVALID_ARGUMENT, "bigleaf_min must be >= -1");
         ctx->bigleaf_min = value;
@@ -574,11 +569,6 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "bigleaf_max")) {
         if (value < -1) return set_err(ctx, FR_INVALID_ARGUMENT, "bigleaf_max must be >= -1");
         ctx->bigleaf_max = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "narrow_wide_min")) {
-        if (value < -1) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow_wide_min must be >= -1");
-        ctx->narrow_wide_min = value;
         return FR_OK;
     }
     if (!strcmp(name, "leaf512")) {

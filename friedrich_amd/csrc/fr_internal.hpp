@@ -81,8 +81,6 @@ struct fr_ctx {
     int64_t splitk = 1;         // GEMMs with few result tiles and a deep contraction are cut along K (gemm_f64.hip)
     int64_t narrow_max = 16;    // solves with at most this many right-hand sides take the memory-bound kernels (chol.hip)
     int64_t narrow_batched_max = -1;  // right-hand sides up to which the persistent solve runs in column groups of 16 (trsm_narrow.hip); -1: chosen from n and m (chol.hip)
-    int64_t narrow_pair_min = -1;  // narrow solves with at least this many right-hand sides: 32 per column group (0 / -1: never; A/B only)
-    int64_t narrow_wide_min = -1;  // ... with at least this many: 64 per column group, the wide kernel (0 / -1: never; A/B only)
     int64_t leaf512 = 1;        // wide triangular solves end in 512-row leaves (explicit 512-block inverses); 0: 128-row leaves
     int64_t bigleaf_min = -1;   // ... and at least this many (-1: by measurement, chol.hip: use_big_leaves)
     int64_t bigleaf_max = -1;   // solves with at most this many right-hand sides (and >= 4096 rows) run left-looking over 2048-row blocks
@@ -101,7 +99,6 @@ struct fr_ctx {
     bool potf2_lds_set = false;  // dynamic-LDS attributes applied on this device (per context = per device)
     bool trsv_lds_set = false;
     bool trsmn_lds_set = false;
-    bool trsmw_lds_set = false;
     bool prior_lds_set = false;
     // profiling
     bool prof = false;

@@ -34,8 +34,7 @@ struct TrsmnArgs {
     const double* A;    // factor buffer: lower triangle L; strict upper off-diagonal blocks hold L^T (backward)
     int64_t ld, n;
     const double* inv;  // inverse blocks (forward) or transposed inverse blocks (backward)
-    const double* mchain;  // single-group / wide kernels: the chain products M_b = inv_b * (tile next to the diagonal), block b at b * 128 * 128
-    const double* mchain2; // wide kernel: the same with the tile TWO blocks from the diagonal
+    const double* mchain;  // single-group kernel: the chain products M_b = inv_b * (tile next to the diagonal), block b at b * 128 * 128
     double* B;          // n x m right-hand sides in, solutions out
     int64_t ldb;
     int m;
@@ -228,166 +227,12 @@ __global__ __launch_bounds__(NTH, 4) void trsm_narrow_half_kernel(const TrsmnArg
     }
 }
 
-// ---- wide column groups (m >= 128): 64 right-hand sides per workgroup ---------------------------------------------------------
-// With 16 (32) right-hand sides per group a solve of m columns streams the factor m / 16 (m / 32) times, and its
-// n / 128 x m / 16 blocks need several rounds of the chip (two workgroups per CU): add_samples(512) onto 7680 rows ran 3.75
-// rounds of a 60-step chain (1.6 ms for 3e10 flop: an MFMA-sized job on a memory-shaped kernel).  Here a wave owns 16 rows and
-// NQ = 4 accumulator tiles -- every factor fragment feeds four MFMAs -- so the factor is read m / 64 times and a solve of 512
-// columns onto 8192 rows is ONE round.  What bounds it then is the chain of hand-offs, so the chain carries one product, as in
-// the single-group kernel, and here also for the dependency before it (with one product, 6.8 us of a CU's matrix cores at 64
-// columns, the path "x_(r-2) arrives -> its tile -> closing product -> ready for x_(r-1)" was as long as the chain step
-// itself: measured 19 us per step with M alone):
-//     x_r = y'' - M2_r x_(r-2) - M_r x_(r-1),     y'' = W_r (b_r - sum_(q < r-2) L[r, q] x_q),
-//     M_r = W_r L[r, r-1],  M2_r = W_r L[r, r-2]   cached per factor (ensure_chain_products).
-// Items of a block, in order: the tiles of all dependencies but the last two; the inverse block (operand t'); M2; M.
-// LDS: one operand block [128 k][64 columns] = 64 KiB, so two workgroups share a CU (two groups' chains side by side); a
-// row is 512 B = all 64 banks, so the four k-rows one fragment read touches would collide four ways: the 16-column segment
-// index is XORed with k & 3.
-template <int NQ>
-__device__ __forceinline__ int wide_idx(int k, int c)
-{
-    return k * (16 * NQ) + (c ^ ((k & 3) << 4));
-}
-
-template <int NQ>
-__global__ __launch_bounds__(NTH, 4) void trsm_narrow_wide_kernel(const TrsmnArgs a0)
-{
-    constexpr int MRT = 16 * NQ;
-    extern __shared__ __attribute__((aligned(16))) double wide_lds[];
-    double* const xs = wide_lds;                                           // the operand block of the current item
-    int* const claim_slot = reinterpret_cast<int*>(wide_lds + NB * MRT);  // (behind it)
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int last = a0.nblk - 1;
-    TrsmnArgs a = a0;
-    {
-        const int grp = blockIdx.y;
-        a.B += (int64_t)grp * MRT * a.ldb;
-        a.m = a.m - grp * MRT < MRT ? a.m - grp * MRT : MRT;
-        a.xg += (int64_t)grp * a.nblk * (NB * MRT);
-        a.flags += (int64_t)grp * a.nblk;
-        a.tickets += grp;
-    }
-#pragma nounroll
-    for (;;) {
-        const int bi = claim_block(a.tickets, a.nblk, claim_slot);
-        if (bi < 0) return;
-        const int blk = a.bwd ? last - bi : bi;
-        const int cnt = a.bwd ? last - blk : blk;      // dependencies; the neighbour is the last of them
-        // items: the tiles of dep(0 .. cnt - 3); the inverse block (operand t' -> y''); then ONE product per arriving block of
-        // the two nearest dependencies: M2 (operand -x two blocks away), M (operand -x_neighbour)
-        const int nt = cnt >= 2 ? cnt - 2 : 0;
-        const int nitems = nt + 1 + (cnt >= 2 ? 1 : 0) + (cnt >= 1 ? 1 : 0);
-        const int64_t b0 = (int64_t)blk * NB;
-        const int64_t row = b0 + 16 * w + l15;
-        auto frag_of = [&](int q) -> Frag {
-            if (q < nt) return item_frag(a, blk, a.bwd ? last - q : q, false);
-            if (q == nt) return item_frag(a, blk, 0, true);
-            Frag f;  // a chain product (rows / columns outside a last, partial block: see ensure_chain_products)
-            f.base = ((q == nt + 1 && cnt >= 2) ? a.mchain2 : a.mchain) + (int64_t)blk * (NB * NB);
-            f.stride = NB;
-            f.mrows = f.kcols = NB;
-            return f;
-        };
-        // the accumulators start at -b: after the tiles they hold -(b - sum L x) = -t'
-        d4n_t acc[NQ];
-#pragma unroll
-        for (int j = 0; j < NQ; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = 16 * j + lq + 4 * i;
-                acc[j][i] = (row < a.n && q < a.m) ? -a.B[row + (int64_t)q * a.ldb] : 0.0;
-            }
-        double H0[16], H1[16];  // first / second half of the current item; the next half is always in flight
-        load_half(frag_of(0), 0, w, l15, lq, H0);
-        const double* xrd[NQ];
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) xrd[j] = xs + lq * MRT + ((16 * j + l15) ^ (lq << 4));
-#pragma nounroll
-        for (int q = 0; q < nitems; ++q) {
-            load_half(frag_of(q), 1, w, l15, lq, H1);
-            const bool is_w = q == nt;
-            if (!is_w) {
-                // a solution block -> LDS (the chain products take their block NEGATED: x = y'' + M2 (-x_2) + M (-x_neighbour));
-                // the barrier inside the wait also tells that every wave is done with the operand before
-                const bool is_m = q > nt;
-                const int dist = (q == nt + 1 && cnt >= 2) ? 2 : 1;
-                const int dep = is_m ? (a.bwd ? blk + dist : blk - dist) : (a.bwd ? last - q : q);
-                if (!handoff_wait_ge<false>(a.flags + dep, 1, a.status)) return;  // no acquire fence: write-through stores, sc1 loads
-                const gvd2* src = (const gvd2*)(a.xg + (int64_t)dep * (NB * MRT));
-                constexpr int PIECES = (NB * MRT) / (2 * NTH), BATCH = 4;  // 16-byte pieces per lane, four in flight (registers)
-#pragma unroll
-                for (int i0 = 0; i0 < PIECES; i0 += BATCH) {
-                    d2_t v[BATCH];
-#pragma unroll
-                    for (int i = 0; i < BATCH; ++i) v[i] = src[t + NTH * (i0 + i)];
-#pragma unroll
-                    for (int i = 0; i < BATCH; ++i) {
-                        const int e = 2 * (t + NTH * (i0 + i));
-                        const d2_t u = is_m ? -v[i] : v[i];
-                        *reinterpret_cast<d2_t*>(xs + wide_idx<NQ>(e / MRT, e % MRT)) = u;
-                    }
-                }
-                __syncthreads();
-            } else {
-                // t' = -acc, the operand of the closing product with the inverse block (every wave is done with the last
-                // solution block first); the accumulators restart at zero and end as y'
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < NQ; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        xs[wide_idx<NQ>(16 * w + l15, 16 * j + lq + 4 * i)] = -acc[j][i];
-                        acc[j][i] = 0.0;
-                    }
-                __syncthreads();
-            }
-            // operand fragments one k-step ahead of their MFMAs, and no further (sched_barrier: left to itself the scheduler hoists
-            // the LDS reads of a whole half -- 128 registers -- and spills the factor fragments)
-            // (k = 64 H + 4 u + lq: k & 3 == lq for every read of a lane, so its swizzled column is fixed per accumulator tile and the
-            // reads are one lane base + immediate offsets)
-            double xa[NQ], xn[NQ];
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) xa[j] = xrd[j][0];
-#pragma unroll
-            for (int H = 0; H < 2; ++H) {
-                if (H == 1 && q + 1 < nitems) load_half(frag_of(q + 1), 0, w, l15, lq, H0);
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    if (64 * H + 4 * (u + 1) < NB) {  // element (k = 64 H + 4 (u + 1) + lq, column 16 j + l15) of the operand block
-#pragma unroll
-                        for (int j = 0; j < NQ; ++j) xn[j] = xrd[j][(64 * H + 4 * (u + 1)) * MRT];
-                    }
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[j], H == 0 ? H0[u] : H1[u], acc[j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) xa[j] = xn[j];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // publish (write-through), flag, then the caller's copy
-        double* dst = a.xg + (int64_t)blk * (NB * MRT);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __hip_atomic_store((gdbl*)(dst + (16 * w + l15) * MRT + 16 * j + lq + 4 * i), acc[j][i], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) __hip_atomic_store((hgi32*)(a.flags + blk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = 16 * j + lq + 4 * i;
-                if (row < a.n && q < a.m) a.B[row + (int64_t)q * a.ldb] = acc[j][i];
-            }
-        __syncthreads();  // xs and the claim slot are reused by the next block of this workgroup
-    }
-}
+// (Round 4 built the 64-column generalisation of this kernel -- trsm_narrow_wide_kernel<4>: four accumulator tiles per wave on the
+// same factor fragments, a swizzled 64 KiB operand block, the two nearest dependencies as cached banded products M, M2 -- and the
+// 32-column pair variant of round 3 was still here.  Both measured slower than groups of 16 wherever column groups are used at all
+// (the chain step of a 64-column group carries a 128 x 128 x 64 product, 6.8 us of a CU's matrix
+// cores) and were removed; the code is in the history at 6fd4683.  Solves with more right-hand sides take the 2048-row leaves of
+// chol.hip.)
 
 // ---- one column group (m <= 16) ------------------------------------------------------------------------------------------
 // The solve is a chain of n / 128 hand-offs; what one step costs is what the whole solve costs.  Round 2's step was: flag poll,
@@ -716,7 +561,8 @@ static int ensure_transposed(fr_ctx* ctx, fr_chol* c)
 }
 
 // The chain products: M_b = W_b L[b, b - k] (forward) / W_b^T L[b + k, b]^T (backward; both operands from the transposed
-// copy), k = 1 (the neighbour: single-group and wide kernels) and k = 2 (wide kernel), b = every block with such a dependency --
+// copy), k = the distance of the tile from the diagonal (1: the neighbour, what the single-group kernel uses; the routine is
+// general in k: round 4's wide kernel also banded k = 2), b = every block with such a dependency --
 // ONE batched product of 128^3 per block row (n = 32768: 1 GFLOP, 32 MiB per direction and distance), cached per factor like
 // the transposed copy: valid for the factor's generation AND its row count (add_rows solves against the old rows under the
 // new generation before the factor grows).  (Round 3 first formed M inside the solve, 31 us at the start of every block's
@@ -801,14 +647,8 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     fr_chol* c = const_cast<fr_chol*>(cc);  // the transposed copy is a cache: logically const
     const int64_t n = c->n;
     if (n <= 0 || m <= 0) return FR_OK;
-    // right-hand sides per column group: 16.  Two wider variants stay selectable for A/B runs (scripts/narrow_wide_ab.py) and are
-    // off by default: 64 per group from narrow_wide_min right-hand sides on (the wide kernel: four MFMA tiles per wave on the same
-    // factor fragments, two banded products on the chain -- measured slower than groups of 16 wherever the groups are used at
-    // all: its chain step carries a 128 x 128 x 64 product, 6.8 us of a CU's matrix cores, where 16 columns cost 1.7), 32 per
-    // group from narrow_pair_min on (round 3's rule for >= 12288 rows; those solves now take the big leaves, chol.hip).
-    const int64_t wide_min = ctx->narrow_wide_min >= 0 ? ctx->narrow_wide_min : 0;
-    const int64_t pair_min = ctx->narrow_pair_min >= 0 ? ctx->narrow_pair_min : 0;
-    const int nq = (wide_min > 0 && m >= wide_min) ? 4 : ((pair_min > 0 && m >= pair_min) ? 2 : 1);
+    // 16 right-hand sides per column group
+    const int nq = 1;
     const int MRT = 16 * nq;
     const int ngroups = (int)((m + MRT - 1) / MRT);
     if (ngroups > 65535) return set_err(ctx, FR_INVALID_ARGUMENT, "narrow solve: too many right-hand sides");
@@ -831,14 +671,10 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     a.ld = c->ld_a;
     a.n = n;
     a.inv = fwd ? c->dinv : c->dinvt;
-    a.mchain = a.mchain2 = nullptr;
-    if (nq == 4 || (nq == 1 && ngroups == 1)) {
+    a.mchain = nullptr;
+    if (ngroups == 1) {
         FR_TRY(ensure_chain_products(ctx, c, fwd, 1, prof_cls));
         a.mchain = c->mchain[fwd ? 0 : 1];
-    }
-    if (nq == 4) {
-        FR_TRY(ensure_chain_products(ctx, c, fwd, 2, prof_cls));
-        a.mchain2 = c->mchain[2 + (fwd ? 0 : 1)];
     }
     a.B = B;
     a.ldb = ldb;
@@ -853,19 +689,10 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     if (ctx->test_max_wgs > 0 && G > ctx->test_max_wgs) G = ctx->test_max_wgs;
     a.bwd = fwd ? 0 : 1;
     FR_HIP(ctx, hipMemsetAsync(a.flags, 0, sizeof(int) * (size_t)(nblk + 1) * (size_t)ngroups, ctx->ls));
-    if (nq == 1 && ngroups == 1)  // the single-group kernel awaits the neighbour's block on the payload itself: fill it with the sentinel
+    if (ngroups == 1)  // the single-group kernel awaits the neighbour's block on the payload itself: fill it with the sentinel
         FR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)a.xg, (int)SENT32, (size_t)nblk * NB * MR * 2, ctx->ls));
     ProfScope ps(ctx, prof_cls, (double)n * (double)n * (double)m, 4.0 * (double)n * (double)n);
-    if (nq == 4) {
-        constexpr size_t WIDE_LDS = sizeof(double) * NB * 64 + 16;
-        if (!ctx->trsmw_lds_set) {
-            FR_HIP(ctx, hipFuncSetAttribute((const void*)trsm_narrow_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS));
-            ctx->trsmw_lds_set = true;
-        }
-        hipLaunchKernelGGL(trsm_narrow_wide_kernel<4>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), WIDE_LDS, ctx->ls, a);
-    } else if (nq == 2)
-        hipLaunchKernelGGL(trsm_narrow_half_kernel<2>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
-    else if (ngroups >= 2)
+    if (ngroups >= 2)
         hipLaunchKernelGGL(trsm_narrow_half_kernel<1>, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), 0, ctx->ls, a);
     else
     {

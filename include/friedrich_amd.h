@@ -96,7 +96,7 @@ void fr_ctx_destroy(fr_ctx* ctx);
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
-/* Tunables (16 names; everything else the library decides from the problem size):
+/* Tunables (17 names; everything else the library decides from the problem size):
  *   "nb"             outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
  *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
@@ -114,7 +114,10 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "splitk"         1 (default): products with few result tiles and a deep contraction are cut along K; 0: never
  *   "narrow_max"     16 (default): solves with at most this many right-hand sides use memory-bound kernels instead of the
  *                    128-wide GEMM tiles;  "narrow_batched_max" (-1: by size): up to this many right-hand sides the persistent
- *                    solve runs in column groups;  "narrow_pair_min" (-1: by size): from this many on, 32 per group
+ *                    solve runs in column groups of 16
+ *   "bigleaf_max"    -1 (default: 4096): solves with 2 .. this many right-hand sides against >= 4096 rows run left-looking over
+ *                    2048-row blocks with explicit inverses of the 2048 x 2048 diagonal blocks (built on demand, extended after
+ *                    fr_chol_add_rows); 0: never.  "bigleaf_min" (-1: by measurement): at least this many right-hand sides
  *   "leaf512"        1 (default): wide triangular solves (>= 256 right-hand sides) end in 512-row leaves against
  *                    explicit inverses of the 512 x 512 diagonal blocks, built on demand; 0: 128-row leaves only
  *   "trsv"           1 (default): solves with few right-hand sides run as one persistent launch per direction; 0: the

@@ -1,5 +1,5 @@
 """Developer probe: mid-size right-hand-side counts (128 .. 1024) -- the recursive GEMM path against the persistent solve in
-column groups of 16, 32 (pair) and 64 (wide kernel) right-hand sides.  predict_variance = cross-Gram + ONE forward solve +
+column groups of 16 right-hand sides and the 2048-row leaves (round 4 also measured 32- and 64-column groups with this script: history at 6fd4683).  predict_variance = cross-Gram + ONE forward solve +
 epilogue; solve() = forward + backward on a device operand.   narrow_wide_ab.py [n,n,...]"""
 import sys, time
 import numpy as np
@@ -9,11 +9,10 @@ from friedrich_amd import synth
 from friedrich_amd.device import Context
 ctx = Context()
 dev = torch.device("cuda", 0)
-MODES = [("gemm", dict(narrow_batched_max=0, narrow_wide_min=0, narrow_pair_min=0, bigleaf_max=0)),
-         ("big", dict(narrow_batched_max=0, narrow_wide_min=0, narrow_pair_min=0, bigleaf_max=-1)),
-         ("g16", dict(narrow_batched_max=4096, narrow_wide_min=0, narrow_pair_min=0, bigleaf_max=0)),
-         ("g64", dict(narrow_batched_max=4096, narrow_wide_min=64, narrow_pair_min=0, bigleaf_max=0)),
-         ("auto", dict(narrow_batched_max=-1, narrow_wide_min=-1, narrow_pair_min=-1, bigleaf_max=-1))]
+MODES = [("gemm", dict(narrow_batched_max=0, bigleaf_max=0, bigleaf_min=-1)),
+         ("big", dict(narrow_batched_max=0, bigleaf_max=-1, bigleaf_min=1)),
+         ("g16", dict(narrow_batched_max=4096, bigleaf_max=0, bigleaf_min=-1)),
+         ("auto", dict(narrow_batched_max=-1, bigleaf_max=-1, bigleaf_min=-1))]
 for n in [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["4096", "8192", "16384", "32768"])]:
     X, y, Xq = synth.make_problem(n, 8, cfg=4, m=2048)
     ls = ctx.mean_pairwise_distance(X)

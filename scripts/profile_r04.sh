@@ -14,11 +14,11 @@ for c in 1 2 4; do
   cat $O/config${c}_run.txt | grep -v amdgpu
 done
 # configs[4] with round 3's solve path (column groups of 16) for the before / after comparison: kernel stats + FETCH_SIZE of both
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/config4b_stats -o c4b -- python scripts/config_run.py 4 --bigleaf_max=0 --narrow_pair_min=0 > $O/config4_round3path_run.txt 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/config4b_stats -o c4b -- python scripts/config_run.py 4 --bigleaf_max=0 > $O/config4_round3path_run.txt 2>/dev/null
 cp $(find $O/config4b_stats -name "*kernel_stats.csv" | head -1) $O/config4_round3path_kernel_stats.csv
 grep -v amdgpu $O/config4_round3path_run.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/c4after_fetch -o f -- python scripts/config_run.py 4 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/c4before_fetch -o f -- python scripts/config_run.py 4 --bigleaf_max=0 --narrow_pair_min=0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/c4before_fetch -o f -- python scripts/config_run.py 4 --bigleaf_max=0 > /dev/null 2>&1
 python - <<'PY' > gpurun_out/r04p/config4_fetch_before_after.json
 import collections, csv, glob, json
 out = {"what": "configs[4] (4096 rows + 8 x add_samples(512) + sample_at(256), twice): rocprofv3 --pmc FETCH_SIZE per kernel, x2 (gfx950 correction), GB summed over all launches; 'before' = bigleaf_max=0 (round 3's column groups of 16), 'after' = the default path", "GB": {}}

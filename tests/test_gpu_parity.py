@@ -848,12 +848,6 @@ def test_narrow_persistent_solves_2_to_16_columns(ctx, n, m):
     finally:
         ctx.set_option("trsv", 1)
     assert np.array_equal(chol.solve(B[:n]), z)  # deterministic
-    if m > 16:  # 32 right-hand sides per column group (two MFMA tiles on the same factor fragments): the same numbers
-        ctx.set_option("narrow_pair_min", 17)
-        try:
-            assert np.array_equal(chol.solve(B[:n]), z) and np.array_equal(chol.solve_lower(B[:n]), w_)
-        finally:
-            ctx.set_option("narrow_pair_min", -1)
     L = chol.l()
     assert rel_err(L, np.tril(L_o)) < TOL and np.all(np.triu(L, 1) == 0.0)
     chol.add_rows(k, np.asfortranarray(X), 40, 0.1)
