@@ -78,6 +78,13 @@ static int rccl_load(fr_ctx* ctx)
             return set_err((ctx), FR_RCCL_ERROR, "%s failed: %s", #call, g_rccl.GetErrorString(r__)); \
     } while (0)
 
+// inside a CallGuard named `guard`: no call on handles the watchdog has taken over
+#define FR_NCCL_G(ctx, call)                                                                                   \
+    do {                                                                                                       \
+        if (guard.taken_over()) return set_err((ctx), FR_RCCL_ERROR, "communicators aborted by the watchdog"); \
+        FR_NCCL(ctx, call);                                                                                    \
+    } while (0)
+
 static inline int64_t now_ms()
 {
     return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -132,7 +139,7 @@ static void watch_main(fr_ctx* ctx, CommWatch* w)
         uint64_t expect = c;
         if (!w->call.compare_exchange_strong(expect, kWatchAborting)) continue;  // the call returned in the meantime
         abort_handles(ctx);  // (the host thread is inside RCCL and touches the handles no more: see CallGuard)
-        ++ctx->comm_timeouts;
+        __atomic_fetch_add(&ctx->comm_timeouts, (int64_t)1, __ATOMIC_RELAXED);
         w->aborted.store(1);
     }
 }
@@ -171,6 +178,9 @@ struct CallGuard {
         w->call_t0.store(now_ms());
         w->call.store(mine);
     }
+    // true once the watchdog has taken the communicators over: the handles must not be used any more (checked in front of
+    // every RCCL call of a guarded sequence -- a grouped send / receive is several calls)
+    bool taken_over() const { return w && w->call.load() == kWatchAborting; }
     ~CallGuard()
     {
         if (!w) return;
@@ -269,7 +279,7 @@ static bool local_barrier(fr_ctx* ctx, const void* publish, LocalPub* snapshot =
     const int64_t T = ctx->comm_timeout_ms > 0 ? ctx->comm_timeout_ms : 120000;
     const bool ok = g->cv.wait_for(lk, std::chrono::milliseconds(T), [&] { return g->gen != my_gen || g->broken; });
     if (!ok || g->broken) {
-        if (!ok) ++ctx->comm_timeouts;
+        if (!ok) __atomic_fetch_add(&ctx->comm_timeouts, (int64_t)1, __ATOMIC_RELAXED);
         g->broken = true;
         g->cv.notify_all();
         return false;
@@ -371,15 +381,15 @@ int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root, int 
     if (ctx->local) return local_scatter(ctx, (char*)buf, 8 * count_per_rank, root);
     ncclComm_t comm = pick_comm(ctx, which);
     CallGuard guard(ctx);
-    FR_NCCL(ctx, g_rccl.GroupStart());
+    FR_NCCL_G(ctx, g_rccl.GroupStart());
     if (ctx->rank == root) {
         for (int r = 0; r < ctx->world; ++r)
             if (r != root)
-                FR_NCCL(ctx, g_rccl.Send(buf + (size_t)r * count_per_rank, count_per_rank, ncclDouble, r, comm, ctx->ls));
+                FR_NCCL_G(ctx, g_rccl.Send(buf + (size_t)r * count_per_rank, count_per_rank, ncclDouble, r, comm, ctx->ls));
     } else {
-        FR_NCCL(ctx, g_rccl.Recv(buf + (size_t)ctx->rank * count_per_rank, count_per_rank, ncclDouble, root, comm, ctx->ls));
+        FR_NCCL_G(ctx, g_rccl.Recv(buf + (size_t)ctx->rank * count_per_rank, count_per_rank, ncclDouble, root, comm, ctx->ls));
     }
-    FR_NCCL(ctx, g_rccl.GroupEnd());
+    FR_NCCL_G(ctx, g_rccl.GroupEnd());
     return FR_OK;
 }
 
@@ -394,14 +404,14 @@ int comm_fanout(fr_ctx* ctx, double* buf, size_t count, int root, int which)
     if (ctx->local) return local_bcast(ctx, buf, 8 * count, root);
     ncclComm_t comm = pick_comm(ctx, which);
     CallGuard guard(ctx);
-    FR_NCCL(ctx, g_rccl.GroupStart());
+    FR_NCCL_G(ctx, g_rccl.GroupStart());
     if (ctx->rank == root) {
         for (int r = 0; r < ctx->world; ++r)
-            if (r != root) FR_NCCL(ctx, g_rccl.Send(buf, count, ncclDouble, r, comm, ctx->ls));
+            if (r != root) FR_NCCL_G(ctx, g_rccl.Send(buf, count, ncclDouble, r, comm, ctx->ls));
     } else {
-        FR_NCCL(ctx, g_rccl.Recv(buf, count, ncclDouble, root, comm, ctx->ls));
+        FR_NCCL_G(ctx, g_rccl.Recv(buf, count, ncclDouble, root, comm, ctx->ls));
     }
-    FR_NCCL(ctx, g_rccl.GroupEnd());
+    FR_NCCL_G(ctx, g_rccl.GroupEnd());
     return FR_OK;
 }
 
@@ -488,7 +498,7 @@ int comm_stream_sync(fr_ctx* ctx, hipStream_t s, const char* what)
         }
         if (now_ms() - t0 > ctx->comm_timeout_ms) break;
     }
-    ++ctx->comm_timeouts;
+    __atomic_fetch_add(&ctx->comm_timeouts, (int64_t)1, __ATOMIC_RELAXED);
     const int64_t waited = now_ms() - t0;
     comm_abort(ctx);
     comm_drain(ctx);
