@@ -27,6 +27,8 @@ def test_bench_prints_one_contract_line():
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    sb = d["step_breakdown_ms"]  # one untimed step with events around every launch: where a step's time goes
+    assert sb["syrk"] > 0 and sb["potf2"] > 0 and sb["gemm_panel"] > 0 and sb["comm"] == 0.0
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key

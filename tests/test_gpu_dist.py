@@ -183,6 +183,18 @@ def test_rccl_single_rank_communicator():
         _, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
         assert rel_err(np.tril(chol.l()), np.tril(L_o)) < TOL
         chol.free()
+        # detach and attach again (what a host does after FR_RCCL_ERROR): the context is single-rank in between
+        ctx.comm_finalize()
+        with pytest.raises(Exception):  # (attached twice without a finalize in between)
+            ctx.comm_init(0, 1, ctx.comm_unique_id())
+            ctx.comm_init(0, 1, ctx.comm_unique_id())
+        ctx.comm_finalize(abort=True)
+        ctx.comm_init(0, 1, ctx.comm_unique_id())
+        ctx.comm_selftest()
+        ctx.set_option("comm_timeout_ms", 5000)
+        with pytest.raises(Exception):
+            ctx.set_option("comm_timeout_ms", -1)
+        assert ctx.counter("comm_timeouts") == 0
     finally:
         ctx.close()
 
