@@ -283,6 +283,32 @@ def test_big_leaf_solves_match_oracle(ctx, n, m):
     chol.free()
 
 
+@pytest.mark.parametrize("m", [2, 16, 40])
+def test_narrow_solves_switch_to_big_leaves_on_the_third_solve(ctx, m):
+    """With fewer than 192 right-hand sides the 2048-row leaves are taken from the third narrow solve against a factor on
+    (building their inverse blocks costs about two solves: chol.hip, use_big_leaves): the first solves run on K9 / the column
+    groups, the later ones on the leaves -- every one of them against the oracle, forward and forward + backward, and the
+    switch is undone by a refactorisation (the counter and the caches belong to a factor)."""
+    n = 4100
+    k = ("matern2", 0.9, 1.1)
+    X = rand_inputs(n, 4, 4100 + m)
+    B = np.asfortranarray(np.random.default_rng(m).standard_normal((n, m)))
+    with O.threads():
+        st, L_o, _ = O.make_cholesky_cov_matrix_cols(k, X, 0.2)
+        L_o = np.tril(L_o)
+        W_o, Z_o = O.solve_lower(L_o, B)[1], O.chol_solve(L_o, B)
+    chol = ctx.cholesky_from_inputs(k, X, 0.2)
+    for rep in range(2):
+        outs = []
+        for i in range(4):
+            outs.append((chol.solve_lower(B), chol.solve(B)))
+            assert rel_err(outs[-1][0], W_o) < TOL and rel_err(outs[-1][1], Z_o) < TOL, (rep, i)
+        # two different paths produced these: equal to rounding, not bit for bit
+        assert rel_err(outs[0][0], outs[3][0]) < 1e-11
+        chol.refactor(k, 0.2)
+    chol.free()
+
+
 def test_big_leaf_inverses_follow_add_rows(ctx):
     """The cached 512- and 2048-block inverses are extended, not rebuilt, when rows are appended (the old blocks stay valid:
     algebra/mod.rs:108-124 only appends): a factor grown 4096 -> 6656 in 512-row chunks (its L21 solves of 512 right-hand sides
