@@ -298,3 +298,107 @@ def test_chain_rounds_cover_every_tile_once():
             assert r["owner"] == r["p"] % world and r["next"] == (r["p"] + 1) % world
             for rank, q in r["near"].items():
                 assert q > r["p"] and q % world == rank and all(j % world != rank for j in range(r["p"] + 1, q))
+
+
+# ---- the guarded start of a sharded run over a REAL torch.distributed group (gloo, 2 processes) ----------------------------
+# friedrich_amd.sharding.TorchLink / guarded_schedule / reattach are what bench.py runs between the ranks of an N > 1 launch;
+# the GPU tests drive the same functions with thread-ranks (ThreadLink).  Here the link is the one bench.py uses -- object
+# all-gather and broadcast over a gloo group -- and the library context is a stand-in that records what the policy asks of it.
+class _FakeCtx:
+    def __init__(self, rank, fail_attach_at=None):
+        self.rank, self.log, self.attached, self.opts = rank, [], 0, {}
+        self.fail_attach_at = fail_attach_at
+
+    def set_option(self, name, value):
+        self.opts[name] = value
+
+    def comm_unique_id(self):
+        return bytes([self.attached % 251]) * 128
+
+    def comm_init(self, rank, world, uid):
+        from friedrich_amd.device import FriedrichError
+
+        assert len(uid) == 128 and rank == self.rank
+        self.attached += 1
+        self.log.append(("init", uid[0]))
+        if self.fail_attach_at is not None and self.attached == self.fail_attach_at and rank == 1:
+            raise FriedrichError(8, "injected: communicator init failed on rank 1")
+
+    def comm_selftest(self):
+        self.log.append(("selftest",))
+
+    def comm_finalize(self, abort=False):
+        self.log.append(("finalize", bool(abort)))
+
+
+def _worker_guard(rank, world, port, out_dir, scenario):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datetime
+    import json
+
+    import torch.distributed as dist
+
+    from friedrich_amd import sharding
+    from friedrich_amd.device import FriedrichError
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+    link = sharding.TorchLink(dist, rank, world, ctl)
+    ctx = _FakeCtx(rank, fail_attach_at=2 if scenario == "attach_fails" else None)
+    link.attach(ctx)
+
+    def preflight(s):
+        if scenario == "all_pass":
+            return None
+        if s == 2:  # wrong factor on rank 1 only: rank 0 must learn it
+            return "factor deviates" if rank == 1 else None
+        if s == 1 and scenario != "attach_fails":  # a time-out inside the library on rank 0 only
+            if rank == 0:
+                raise FriedrichError(8, "sharded factorisation timed out")
+            return None
+        return None
+
+    schedule, reasons, took = sharding.guarded_schedule(ctx, link, preflight, timeout_ms=1234)
+    assert link.gather(rank) == list(range(world))
+    link.barrier()
+    with open(os.path.join(out_dir, f"g{rank}.json"), "w") as f:
+        json.dump({"schedule": schedule, "reasons": reasons, "took": sorted(took), "log": ctx.log, "opts": ctx.opts}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["all_pass", "two_fall_backs", "attach_fails"])
+def test_guarded_schedule_over_gloo(tmp_path, scenario):
+    import json
+
+    import torch.multiprocessing as tmp_mp
+
+    world = 2
+    port = 33100 + (os.getpid() % 2000) + len(scenario)
+    tmp_mp.spawn(_worker_guard, args=(world, port, str(tmp_path), scenario), nprocs=world, join=True)
+    res = [json.load(open(tmp_path / f"g{r}.json")) for r in range(world)]
+    # both ranks reach the same decision with the same reasons, whoever saw the failure
+    assert res[0]["schedule"] == res[1]["schedule"] and res[0]["reasons"] == res[1]["reasons"]
+    for r in res:
+        assert r["opts"]["comm_timeout_ms"] == 1234
+    if scenario == "all_pass":
+        assert res[0]["schedule"] == 2 and res[0]["reasons"] == [] and res[0]["took"] == [2]
+        assert [e[0] for e in res[0]["log"]] == ["init", "selftest"]
+    elif scenario == "two_fall_backs":
+        assert res[0]["schedule"] == 0 and len(res[0]["reasons"]) == 2
+        assert "schedule 2: rank 1: factor deviates" in res[0]["reasons"][0] and "schedule 1: rank 0" in res[0]["reasons"][1]
+        for r in res:
+            # after every failure: communicator dropped WITHOUT waiting for the peer, a fresh one attached and self-tested
+            assert [e[0] for e in r["log"]] == ["init", "selftest", "finalize", "init", "selftest", "finalize", "init", "selftest"]
+            assert all(e[1] for e in r["log"] if e[0] == "finalize")
+            assert r["opts"]["dist_schedule"] == 0
+        # the fresh ids came from rank 0 and reached rank 1
+        assert [e[1] for e in res[1]["log"] if e[0] == "init"][1:] == [e[1] for e in res[0]["log"] if e[0] == "init"][1:]
+    else:
+        # schedule 2 fails its preflight; re-attaching fails on rank 1: both ranks end without communicator (replicas)
+        assert res[0]["schedule"] == -1 and any("attaching a fresh communicator failed" in x for x in res[0]["reasons"])
+        for r in res:
+            assert r["log"][-1] == ["finalize", True]
