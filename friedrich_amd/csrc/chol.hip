@@ -1589,10 +1589,12 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
         // K21 = k(new, old), K22 = lower(k(new, new)) + noise^2 I       (algebra/mod.rs:115-121)
         FR_TRY(launch_gram_sym(ctx, *kernel, c->X + n_old, nb_new, c->ld_x, d, noise * noise, A22, ld));
         // L21 = K21 L11^-T ; K22 -= L21 L21^T ; L22 = chol(K22) with insert_column's plain sqrt (mode 2)
-        if (n_old >= 4 * IB && nb_new >= IB) {
-            // a short, wide block: solving from the right would be GEMMs of nb_new rows (four tile rows, ~120 launches); the
-            // transposed problem  L21^T = L11^-1 K12  is a forward solve with nb_new right-hand sides (tall GEMMs, 512-row
-            // leaves), then one transposition into place
+        if (n_old >= 4 * IB) {
+            // a short, wide block: solving from the right would be GEMMs of nb_new rows (four tile rows, ~120 launches; with ONE new
+            // row -- the Bayesian-optimisation loop of readme.md:7 -- a recursion of ~3 n / 128 one-row products: 5.0 / 19.4 ms at
+            // N = 8192 / 32768, measured in round 4); the transposed problem  L21^T = L11^-1 K12  is a forward solve with nb_new
+            // right-hand sides -- whatever trsm_lower_fwd picks for that count: the single-column kernel, K9, the 2048-row
+            // leaves -- then one transposition into place
             WsGuard wg(ctx);
             const int64_t ldw = round_up(n_old, kAlign);
             double* W = wg.get(sizeof(double) * (size_t)ldw * (size_t)nb_new);

@@ -350,7 +350,7 @@ struct GemmDesc {
     // tile counts per XCD are unequal work
     bool dynamic = false;
     bool tri_splitk = false;   // a triangular-operand product may be cut along K like any other (slices of structural zeros retire at once)
-    int64_t tri_kslice = 0;    // (set by the split-K path: slice length of a batched triangular-operand launch)
+    int64_t kslice = 0, k_total = 0;  // (set by the split-K path: slice length and whole contraction of the batched launch)
     bool mirror = false;       // a workgroup takes row tile i and then row tile (last - i): equal work per workgroup with a triangular left operand
     bool force_small = false;  // 32-row tiles whatever the tile count, triangular operands included (the big solve leaves: chol.hip)
 };

@@ -99,11 +99,12 @@ __device__ __forceinline__ void gemm_f64_body(const GemmArgs& g, double* lds)
     for (int rep = 0; rep < reps; ++rep) {
         const int64_t m0 = ((MIRROR && rep == 1) ? g.mirror_tiles - 1 - tm : tm) * BMT;
         GemmArgs gt = g;  // (ONE call site of the tile function: a second inlined copy would double the kernel)
+        // (k0: where this launch's -- this batch member's -- part of the contraction starts in the whole one)
+        const int64_t k0 = g.kslice * (int64_t)blockIdx.y;
+        if (g.kslice > 0 && k0 + g.K > g.k_total) gt.K = g.k_total > k0 ? g.k_total - k0 : 0;  // the last, shorter slice
         if (g.tri) {
             // triangular operand(s): skip the part of the contraction that only multiplies structural zeros
-            // (k0: where this launch's -- this batch member's -- part of the contraction starts in the whole one)
-            const int64_t k0 = g.tri_kslice * (int64_t)blockIdx.y;
-            int64_t kbeg = k0, kend = k0 + g.K;
+            int64_t kbeg = k0, kend = k0 + gt.K;
             if ((g.tri & 1) && m0 > kbeg) kbeg = m0;
             if ((g.tri & 2) && n0 > kbeg) kbeg = n0;
             if ((g.tri & 4) && m0 + BMT < kend) kend = m0 + BMT;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void rows_solve_kernel(const RowsSolveArgs 
     GemmArgs g;
     g.M = a.rows;
     g.own_world = 1; g.own_rank = 0; g.own_nb = 1; g.own_col0 = 0;
-    g.mirror_tiles = 0; g.tri_kslice = 0;
+    g.mirror_tiles = 0; g.kslice = 0; g.k_total = 0;
     g.lower = 0; g.tri = 0; g.place = 0; g.nres = 0; g.epoch = 0; g.ntiles = 0; g.xcc_word = nullptr; g.claim = nullptr; g.max_exit = 0;
     g.tiles_m = 1; g.tiles_n = 1; g.sw_log2 = 0; g.super_m = 1; g.nsuper = 0; g.per_xcd = 0;
     g.batch_a = g.batch_b = g.batch_c = g.batch_d = 0;
@@ -305,12 +306,14 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
         int64_t S = (kSplitkTarget + tiles - 1) / tiles;
         if (S > d.K / kSplitkSlice) S = d.K / kSplitkSlice;
         if (S > 32) S = 32;
-        while (S > 1 && (d.K % S != 0 || (d.K / S) % BK != 0)) --S;
+        // slices of a whole number of K-steps; the last one takes what is left (shorter, possibly ragged: a contraction of
+        // 32769 -- one row appended to a factor of 32768 -- used to find no divisor and ran as ONE 2048-step tile, 3.5 ms)
+        int64_t ks = S > 1 ? round_up((d.K + S - 1) / S, BK) : d.K;
+        if (S > 1) S = (d.K + ks - 1) / ks;
         if (S > 1) {
             WsGuard w(ctx);
             double* part = w.get(sizeof(double) * (size_t)S * (size_t)d.M * (size_t)d.N);
             if (!part) return FR_OUT_OF_MEMORY;
-            const int64_t ks = d.K / S;
             GemmDesc p = d;
             p.K = ks;
             p.lower = false;
@@ -320,7 +323,8 @@ int launch_gemm(fr_ctx* ctx, const GemmDesc& d)
             p.batch_a = d.a_kmajor ? ks : ks * d.lda;
             p.batch_b = d.b_kmajor ? ks : ks * d.ldb;
             p.batch_c = p.batch_d = d.M * d.N;
-            p.tri_kslice = d.tri ? ks : 0;  // (slices that only meet structural zeros write zeros and retire)
+            p.kslice = ks;  // (slices that only meet structural zeros of a triangular operand write zeros and retire)
+            p.k_total = d.K;
             FR_TRY(launch_gemm_plain(ctx, p));
             const double* cin = d.Cin ? d.Cin : d.D;
             const int64_t ldcin = d.Cin ? d.ldcin : d.ldd;
@@ -370,7 +374,8 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
                         g.tiles_m * g.tiles_n * (d.batch > 1 ? d.batch : 1) <= small_max) ||
                        (d.force_small && !d.lower && d.M > BMS && d.D != d.B);
     if (small) g.tiles_m = (d.M + BMS - 1) / BMS;
-    g.tri_kslice = d.tri_kslice;
+    g.kslice = d.kslice;
+    g.k_total = d.k_total;
     g.mirror_tiles = 0;
     if (d.mirror && small && d.b_kmajor && !d.lower && d.batch <= 1 && g.tiles_m >= 2 && g.tiles_m % 2 == 0) {
         g.mirror_tiles = g.tiles_m;

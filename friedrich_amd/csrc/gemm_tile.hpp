@@ -51,9 +51,10 @@ struct GemmArgs {
     // tile tm and then row tile mirror_tiles - 1 - tm -- with a triangular left operand (tri 1 / 4) the two contractions add
     // up to the same length for every workgroup (the big solve leaves: chol.hip)
     int64_t mirror_tiles;
-    // split-K launches with triangular operands: batch member z holds the slice [z * tri_kslice, (z + 1) * tri_kslice) of the
-    // contraction; the restriction above is applied in the coordinates of the whole contraction (0: not sliced)
-    int64_t tri_kslice;
+    // split-K launches: batch member z holds the slice [z * kslice, min((z + 1) * kslice, k_total)) of the contraction (K == kslice;
+    // the last slice may be shorter and ragged); the triangular restriction above is applied in the coordinates of the whole
+    // contraction (0: not sliced)
+    int64_t kslice, k_total;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile

@@ -414,7 +414,11 @@ def test_posterior_failure_status(ctx):
 
 
 # ---- add_samples -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("n0,chunks", [(4, [4]), (100, [1, 27, 128]), (130, [200, 64]), (256, [256])])
+@pytest.mark.parametrize("n0,chunks", [(4, [4]), (100, [1, 27, 128]), (130, [200, 64]), (256, [256]),
+                                       # >= 512 old rows: every append is the transposed forward solve -- one new row on the
+                                       # single-column kernel (the Bayesian-optimisation loop), a few on K9, 17+ in column groups;
+                                       # 1203 / 2049 old rows: a Schur product whose contraction has no divisor (ragged split-K slices)
+                                       (640, [1, 1, 3, 16, 17, 130]), (1203, [1, 40]), (2049, [1, 2])])
 def test_add_rows_matches_oracle_and_refit(ctx, n0, chunks):
     k = ("matern2", 0.8, 1.0)
     d = 3
