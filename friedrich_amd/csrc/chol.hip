@@ -1071,6 +1071,10 @@ constexpr int64_t TRINV_BASE = 2048;
 static int trinv_rec(fr_ctx* ctx, const fr_chol* c, int64_t row0, int64_t n, double* W, int64_t ldw, double* T, double* tmp, int cls)
 {
     if (n <= TRINV_BASE) {
+        // a whole 2048-row diagonal block whose explicit inverse is cached (ensure_invbig: two batched block levels for ALL blocks
+        // of the factor, where the solve of the identity below is ~25 launches per block): the base case is a copy
+        if (n == GB && row0 % GB == 0 && row0 + GB <= c->invbig_rows)
+            return launch_copy(ctx, c->invbig + (row0 / GB) * GB * GB, GB, W, ldw, GB, GB);
         FR_TRY(launch_set_identity(ctx, W, n, ldw));
         return trsm_fwd_rec(ctx, c, row0, n, W, n, ldw, cls, tmp);
     }
@@ -1105,6 +1109,9 @@ int chol_tri_inverse(fr_ctx* ctx, const fr_chol* c, double* W, int64_t ldw, doub
     }
     FR_HIP(ctx, hipMemsetAsync(W, 0, sizeof(double) * (size_t)ldw * (size_t)n, ctx->ls));
     FR_TRY(ensure_inv512(ctx, c, cls));
+    // (n = 2048 x a power of two: the halving below ends in whole 2048-row diagonal blocks, whose inverses ensure_invbig builds
+    // for the whole factor in six batched launches; best effort)
+    if (n % GB == 0 && ((n / GB) & (n / GB - 1)) == 0 && n >= 2 * GB && ensure_invbig(ctx, c, cls) != FR_OK) (void)hipGetLastError();
     WsGuard w(ctx);
     double* tmp = w.get(sizeof(double) * (size_t)LB * (size_t)TRINV_BASE);
     if (!tmp) return FR_OUT_OF_MEMORY;

@@ -561,7 +561,7 @@ def test_grad_terms_matern2_negative_length_scale(ctx, ls):
     chol.free()
 
 
-@pytest.mark.parametrize("n", [2700, 5200])
+@pytest.mark.parametrize("n", [2700, 4096, 5200])  # (4096: the halving ends in whole 2048-row blocks, whose cached inverses are copied)
 def test_grad_terms_triangular_inverse_path(ctx, n):
     """Above 2048 rows the gradient's K^-1 = W^T W comes from the recursive triangular inverse and products that skip the
     structural zeros (chol.hip: chol_tri_inverse; GemmArgs::tri, tiles claimed): against the oracle's gradient
