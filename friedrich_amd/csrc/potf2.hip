@@ -45,6 +45,10 @@ constexpr int SB = 32;   // sub-block
 constexpr int SBE = SB * SB;
 constexpr int PT = 512;  // 8 waves; <= 128 VGPRs so that they fit beside ONE resident GEMM workgroup
 constexpr int NSLOT = 10;
+#ifndef FR_K4_EXP
+#define FR_K4_EXP 0
+#endif
+constexpr int K4X = FR_K4_EXP;  // developer experiments of scripts/mk_potf2_phases.py (0 in the product build)
 constexpr size_t POTF2_LDS = (size_t)NSLOT * SBE * sizeof(double) + 16 + SB * sizeof(double);  // + the column counter of the panel wave + 32 dummy words (see f_step)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every
@@ -505,12 +509,24 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
 
         // ---- P1
         double xs[HB];
+#if FR_K4_EXP == 2 || FR_K4_EXP == 4
+        // experiment: the four followers of a stage on waves 1, 2, 3, 5 -- wave 4 (the pivot wave's SIMD partner) idles in P1
+        const int q4 = (u < 3) ? u : ((u == 4) ? 3 : -1);
+        const int nt4 = m3 ? 0 : (nblk - 1 - b);
+        const bool do_x = want_inv && q4 == nt4;
+        {
+            const int it = b + 1 + q4;
+            const int c1 = q4 - nt4 - 1;
+            const bool do_t = q4 >= 0 && q4 < nt4;
+            const bool do_1 = want_inv && q4 > nt4 && c1 < b;
+#else
         const bool do_x = (u == 3) && want_inv;
         {
             const int it = b + 1 + u;            // update waves 0..2: T on sub-block it
             const int c1 = u - 4;                // update waves 4..6: (1) on W_b,c1
             const bool do_t = (u < 3) && !m3 && (it < nblk);
             const bool do_1 = (u >= 4) && want_inv && (c1 < b);
+#endif
             double* S = lds + (do_t ? slot_of(it, b) : (do_1 ? slot_of(b, c1) : 0));
             if (do_t || do_x || do_1) {
                 double one = 1.0;
@@ -521,7 +537,7 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
                     const double v = S[r + SB * (HB * h + k)];
                     xs[k] = do_x ? ((HB * h + k == r) ? one : 0.0) : v;
                 }
-                trsm_fwd(xs, Lbb, h, colflag, SB * b);
+                if (K4X != 1 && !((K4X == 3 || K4X == 4) && !do_x)) trsm_fwd(xs, Lbb, h, colflag, SB * b);  // (experiments 1 / 3: no followers / only X)
             }
             if (do_t || do_1) {
                 const int gr = SB * it + r;

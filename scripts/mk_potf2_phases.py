@@ -23,11 +23,11 @@ for idx in range(3):
     body += "        lds_barrier();\n        if (ts && w == 1 && lane == 0) ts[16 + 8 * b + %d] = __builtin_amdgcn_s_memtime();\n" % idx + parts[idx + 1]
 kern = head + "    const int u = w - 1;\n" + body + "    // ---- store the inverse" + rest
 # the kernel wrapper passes the stamp buffer on and stamps the end
-kern = kern.replace("unsigned* __restrict__ xcc_word)\n{", "unsigned* __restrict__ xcc_word, long long* ts)\n{", 1)
+kern = kern.replace("unsigned* __restrict__ xcc_word)\n{", "unsigned* __restrict__ xcc_word, long long* ts)\n{", 2)
 assert "long long* ts)" in kern
 call = "    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);\n"
-assert kern.count(call) == 1
-kern = kern.replace(call, "    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest, ts);\n    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n", 1)
+assert kern.count(call) == 2
+kern = kern.replace(call, '    { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); if ((threadIdx.x & 63) == 0) ts[40 + (threadIdx.x >> 6)] = hwid; }\n    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest, ts);\n    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n', 2)
 prog = '''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -39,7 +39,7 @@ prog = '''#include <hip/hip_runtime.h>
 namespace fr {
 ''' + kern + '''}
 int main(int argc, char** argv){
-  const bool noise = argc > 1;
+  const bool noise = argc > 1 && argv[1][0] == 'n'; const bool capped = argc > 2 && argv[2][0] == 'c';
   fr_ctx* ctx = nullptr; double *NA = nullptr, *NC = nullptr; const int64_t NM = 16384, NK = 512;
   if (noise) {
     if (fr_ctx_create(&ctx, 0) != FR_OK) { printf("ctx failed\\n"); return 1; }
@@ -50,16 +50,18 @@ int main(int argc, char** argv){
   for(int c=0;c<n;++c) for(int r=0;r<n;++r) h[r+c*n]= (r==c? n+1.0 : 1.0/(1.0+abs(r-c)));
   double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*64);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_uncapped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
   for(int rep=0;rep<3;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
     if (noise) { for (int g = 0; g < 6; ++g) fr_gemm(ctx, 0, 1, NM, NM, NK, -1.0, NA, NM, NA, NM, 1.0, NC, NM); usleep(6000); }
     hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,hs);
-    hipLaunchKernelGGL(fr::potf2_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,(double*)nullptr,(unsigned*)nullptr,ts); (void)hipEventRecord(e1,hs); (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL(capped ? fr::potf2_kernel : fr::potf2_uncapped_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,(double*)nullptr,(unsigned*)nullptr,ts); (void)hipEventRecord(e1,hs); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms,e0,e1);
     long long t[64]; (void)hipMemcpy(t,ts,8*64,hipMemcpyDeviceToHost);
     if (rep==2) { printf("event %.1f us; shader-clock cycles: load %lld", ms*1e3, t[1]-t[0]);
       long long prev=t[1]; for(int b=0;b<4;++b){ printf(" | F%d %lld upd %lld", b, t[2+2*b]-prev, t[3+2*b]-t[2+2*b]); prev=t[3+2*b]; }
       printf(" | store %lld | total %lld\\n", t[10]-prev, t[10]-t[0]);
+      printf("  wave -> SIMD:"); for (int w = 0; w < 8; ++w) printf(" %d:%lld", w, (t[40+w] >> 4) & 3); printf("  (cu %lld)\\n", (t[40] >> 8) & 15);
       for(int b=0;b<4;++b){ printf("  stage %d (update wave 0): P2 products %lld | P3 %lld\\n", b, t[16+8*b+1]-t[16+8*b], t[16+8*b+2]-t[16+8*b+1]); } }
   }
   return 0; }
