@@ -298,7 +298,94 @@ __device__ __forceinline__ void f_step(double (&a)[HB], FState& st, double d, do
     }
 }
 
-template <bool M3, bool FULL>
+// ---- the same elimination step, software-pipelined (round 5) ------------------------------------------------------
+// Measured (scripts/mk_potf2_phases.py, FR_K4_EXP = 1): with every follower wave switched off F_b still takes ~480 cycles per
+// column -- the step is bound by the pivot wave's OWN dependencies, in order: reciprocal-pivot chain (13 dependent f64
+// operations), then the LDS round trip of the column (write -> eight broadcast reads -> s_waitcnt), then the sixteen rank-1
+// FMAs; nothing overlaps because the wave issues in order and the FMAs wait for the round trip.  Here the rank-1 update of
+// column J is applied one step LATE (step J + 1, from broadcasts requested in step J: they have landed, no wait), which leaves
+// two things the next pivot needs in time:
+//   * the next diagonal value: every lane keeps  dd = a(r, r) - sum_k L(r, k)^2  of ITS row, updated with its own L(r, J) --
+//     no broadcast, no LDS;
+//   * column J + 1 complete before step J + 1 scales it: its update from column J is one FMA with L(J + 1, J) read from the
+//     pivot lane (v_readlane), issued in the shadow of the reciprocal-pivot chain.
+// The dependent chain of a step is then  q = a ip -> dd -= q^2 -> readlane -> rsq + Newton -> select; everything else fills
+// its issue gaps.
+template <bool FULL, int J>
+__device__ __forceinline__ void f_step_lazy(double (&a)[HB], FState& st, double& dd, double d, double ip, unsigned& excmask, int& dlo,
+                                            int& dhi, double lprev, const ColBcast& cbp)
+{
+    constexpr int hJ = J / HB, kJ = J % HB;
+    constexpr int hN = (J + 1) / HB, kN = (J + 1) % HB;
+    constexpr int NST = ChainShape<false>::NST;
+    constexpr bool next = J + 1 < SB;
+    // ---- critical path: column J scaled by the reciprocal pivot, the row's diagonal accumulator, the next pivot candidate
+    const double v = a[kJ];
+    const double q = v * ip;
+    const bool keep = FULL ? (st.r > J) : (st.r > J && st.row_ok && J < st.ncols_ok);
+    const double l_own = keep ? q : 0.0;  // (padding rows / columns stay the identity: 0 * inf must not leak)
+    PivotChain ch;
+    if constexpr (next) {
+        if constexpr (FULL) dd = __builtin_fma(-q, q, dd);
+        else dd = __builtin_fma(-l_own, l_own, dd);
+        pin(dd);
+        ch.d = readlane_f64(dd, (J + 1) + SB * hJ);  // (the accumulators live in the half that owns column J)
+        chain_stage<false, 0>(ch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- L(r, J) in both halves; L(J + 1, J) for the early update of column J + 1
+    const double l = bcast_half<hJ>(l_own);
+    double sl = 0.0;
+    if constexpr (next) sl = readlane_f64(q, (J + 1) + SB * hJ);
+    if constexpr (next) chain_stage<false, 1>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the LDS image of column J and the counter (as f_step); its broadcasts for the NEXT step's rank-1 update are requested
+    // at once (a second set of 32 registers: nothing in this step waits for them)
+    {
+        double* wp = (st.h == hJ) ? st.cptr + SB * J : st.dummy;
+        *wp = (st.r == J) ? ip : l_own;
+        *st.flag = st.flag_base + J + 1;
+    }
+    ColBcast cb;
+    if constexpr (J + 2 < SB) col_load<J + 1, 0>(cb, st.bufh + SB * J - SB * (J + 1));  // (column J, liveness of columns > J + 1)
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dlo) : "s"(__builtin_amdgcn_readfirstlane(__double2loint(d))), "n"(J));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dhi) : "s"(__builtin_amdgcn_readfirstlane(__double2hiint(d))), "n"(J));
+    if constexpr (next) chain_stage<false, 2>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the rank-1 update of column J - 1, one step late (columns > J; its broadcasts were requested a step ago), in four
+    // groups between the stages of the reciprocal-pivot chain
+    constexpr bool lazy = (J >= 1 && J + 1 < SB);
+    if constexpr (lazy) f_pairs<J, 0, HB / 8>(a, lprev, cbp);
+    if constexpr (next) chain_stage<false, 3>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (lazy) f_pairs<J, HB / 8, HB / 4>(a, lprev, cbp);
+    if constexpr (next) chain_stage<false, 4>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (lazy) f_pairs<J, HB / 4, 3 * HB / 8>(a, lprev, cbp);
+    if constexpr (next) chain_stage<false, 5>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (lazy) f_pairs<J, 3 * HB / 8, HB / 2>(a, lprev, cbp);
+    // ---- column J + 1 takes column J's update now (its slot belongs to half hN)
+    if constexpr (next) {
+        const double lf = (st.h == hN) ? l : 0.0;
+        a[kN] = __builtin_fma(-lf, sl, a[kN]);
+        pin(a[kN]);
+        if constexpr (J == HB - 1) {  // the accumulators move to the half that owns the columns from here on
+            dd = bcast_half<0>(dd);
+            pin(dd);
+        }
+    }
+    if constexpr (next) chain_stage<false, 6>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (next) chain_stage<false, 7>(ch);
+    if constexpr (next) {
+        double ipn = ch.r;
+        pivot_select(st, ch.d, J + 1, ipn, excmask);
+        f_step_lazy<FULL, J + 1>(a, st, dd, ch.d, ipn, excmask, dlo, dhi, l, cb);
+    }
+}
+
+template <bool M3, bool FULL, bool LAZY = false>
 __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, double* __restrict__ A, int64_t lda, int n,
                                                 int64_t col0, int mode, double sub, int64_t* __restrict__ info)
 {
@@ -337,7 +424,13 @@ __device__ __forceinline__ void factor_subblock(double* lds, int b, int lane, do
         pivot_select(st, d0, 0, ip, excmask);
     }
     int dlo = 0, dhi = 0;  // lane J: the diagonal value d_J the pivot of column J was taken from
-    f_step<M3, FULL, 0>(a, st, d0, ip, excmask, dlo, dhi);
+    if constexpr (LAZY && !M3) {
+        double dd = image[st.r + SB * st.r];  // a(r, r): the row's diagonal accumulator (both halves)
+        ColBcast none;
+        f_step_lazy<FULL, 0>(a, st, dd, d0, ip, excmask, dlo, dhi, 0.0, none);
+    } else {
+        f_step<M3, FULL, 0>(a, st, d0, ip, excmask, dlo, dhi);
+    }
     if constexpr (!M3) {
         // ---- the factored sub-block to global memory, from its image (L below the diagonal, 1 / pivot on it): every lane
         // forms the diagonal entry of ITS row, sqrt(d) = d ip with one Heron correction (the pivot rule's replacement where
@@ -432,6 +525,7 @@ __device__ __forceinline__ void trsm_fwd(double (&x)[HB], const double* image, i
     trsm_step<0>(x, bufh, h, cb, ip0, flag, flag_base, avail);
 }
 
+template <bool LAZY>
 __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
                                             double sub, double* __restrict__ inv, int64_t ldinv,
                                             int64_t* __restrict__ info, double* __restrict__ cest = nullptr)
@@ -495,9 +589,9 @@ __device__ __forceinline__ void potf2_block(double* lds, double* __restrict__ A,
             if (m3)
                 factor_subblock<true, false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
             else if (n == PB)
-                factor_subblock<false, true>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+                factor_subblock<false, true, LAZY>(lds, b, lane, A, lda, n, col0, mode, sub, info);
             else
-                factor_subblock<false, false>(lds, b, lane, A, lda, n, col0, mode, sub, info);
+                factor_subblock<false, false, LAZY>(lds, b, lane, A, lda, n, col0, mode, sub, info);
             lds_barrier();
             lds_barrier();
             lds_barrier();
@@ -725,7 +819,7 @@ __global__ __launch_bounds__(PT, 4) void potf2_kernel(double* __restrict__ A, in
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_store(xcc_word, (xcc & 7u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
+    potf2_block<false>(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
 }
 
 // The same body without the register cap (157 VGPRs, nothing in scratch; capped at 128 it spills 76 B per lane, 41 scratch
@@ -743,7 +837,7 @@ __global__ __launch_bounds__(PT, 2) void potf2_uncapped_kernel(double* __restric
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_store(xcc_word, (xcc & 7u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
+    potf2_block<K4X != 5>(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
 }
 
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub, double* inv,

@@ -25,9 +25,15 @@ kern = head + "    const int u = w - 1;\n" + body + "    // ---- store the inver
 # the kernel wrapper passes the stamp buffer on and stamps the end
 kern = kern.replace("unsigned* __restrict__ xcc_word)\n{", "unsigned* __restrict__ xcc_word, long long* ts)\n{", 2)
 assert "long long* ts)" in kern
-call = "    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);\n"
-assert kern.count(call) == 2
-kern = kern.replace(call, '    { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); if ((threadIdx.x & 63) == 0) ts[40 + (threadIdx.x >> 6)] = hwid; }\n    potf2_block(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest, ts);\n    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n', 2)
+import re
+n_calls = 0
+def _stamp(m):
+    global n_calls
+    n_calls += 1
+    return ('    { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); if ((threadIdx.x & 63) == 0) ts[40 + (threadIdx.x >> 6)] = hwid; }\n'
+            + m.group(0).replace("cest);", "cest, ts);") + "    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n")
+kern = re.sub(r"    potf2_block<[^>]*>\(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest\);\n", _stamp, kern)
+assert n_calls == 2, n_calls
 prog = '''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
