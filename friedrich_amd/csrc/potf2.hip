@@ -840,6 +840,643 @@ __global__ __launch_bounds__(PT, 2) void potf2_uncapped_kernel(double* __restric
     potf2_block<K4X != 5>(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest);
 }
 
+// =====================================================================================================================
+// Flat variant of the diagonal-block kernel (round 5): full 128 x 128 blocks, factor + inverse, the CU to itself.
+//
+// What the phase stamps and scripts/lat_probe.hip said about the staged kernel above: a single wave issues one instruction
+// per ~5.2 cycles, so a pivot step costs (instructions of the pivot wave) x 5.2 whatever the other seven waves do -- 75
+// instructions, ~460 cycles per column, 4 x 14.6 k cycles -- and the 32^3 products between the stages (25 k cycles) wait
+// behind barriers.  Here the pivot wave carries almost nothing but the chain, and there are no stages:
+//
+//   * one ROW per lane.  Wave PA holds rows 0..63 of the block, PB rows 64..127; XA / XB hold rows 0..63 / 64..127 of
+//     X^T = I L^-T (the inverse as "one more block of rows below the factor": row c of X^T is column c of L^-1).
+//   * columns in MICRO-PANELS of four.  A lane keeps only the four values of its row in the current micro-panel.  The pivot
+//     wave (PA for columns 0..63, then PB) runs the chain  q = a ip -> dd -= q^2 -> v_readlane -> rsq + Newton  of the lazy
+//     step above and the three in-panel updates (multipliers read from the pivot lanes with v_readlane); the other row
+//     waves FOLLOW a whole micro-panel at a time from the 4 x 4 triangle the pivot wave published (ten f64 operations).
+//   * the rank-4 update of everything to the right of a micro-panel is v_mfma_f64_16x16x4 -- K = 4 IS the instruction's
+//     contraction -- on four UPDATE waves: the 36 lower tiles of the block and the 36 upper tiles of X^T stay in their
+//     accumulator registers (18 tiles per wave, NEGATED so that the products add) from the first load to the end; finished
+//     micro-panels travel through a ring in LDS as operands; after micro-panel p the update waves hand the columns of
+//     micro-panel p + 2 (four accumulator registers' worth per tile) back through a staging buffer, and the row waves
+//     apply micro-panel p + 1 to them themselves (sixteen FMAs with broadcast multipliers).
+//   * no barrier inside: eight progress counters in LDS (one per wave), polled.
+// The dependency chain is then 128 pivot steps of ~45 instructions; the matrix-core work (~960 MFMAs) and the followers
+// run beside it.
+namespace flat {
+
+constexpr int R = 8;          // ring depth (micro-panels)
+constexpr int LAG = 3;        // the update waves hand micro-panel q's columns back with every update of micro-panels <= q - LAG; the row
+                              // waves apply the LAG - 1 micro-panels in between themselves.  (LAG = 2: the loop pivot wave -> followers ->
+                              // update waves -> pivot wave has to close within ONE micro-panel of the pivot wave, and does not: measured
+                              // 1.2 k of 3.0 k cycles per micro-panel blocked)
+constexpr int NSTG = 4;       // staging slots
+constexpr int PS = 144;       // column stride of a micro-panel image in LDS, in doubles: 128 rows + 16 (operand reads of the
+                              // MFMA layout -- 16 rows x 4 columns per wave-instruction -- then hit 64 distinct banks)
+constexpr int PSZ = 4 * PS;   // doubles per micro-panel image
+constexpr int OFF_L = 0;                  // L ring: finished micro-panels of the factor (rows 0..127)
+constexpr int OFF_Y = R * PSZ;            // Y ring: finished micro-panels of X^T
+constexpr int OFF_FS = 2 * R * PSZ;          // staging, factor rows: columns of micro-panel q (slot q % NSTG) with every update of micro-panels <= q - LAG
+constexpr int OFF_XS = OFF_FS + NSTG * PSZ;  // staging, X^T rows
+constexpr int OFF_END = OFF_XS + NSTG * PSZ;
+constexpr int OFF_IP = OFF_END + 16;      // reciprocal pivots of the micro-panels in the ring (R x 4 x 64 copies)
+#ifdef FR_K4_TS
+constexpr size_t LDS_BYTES = (size_t)(OFF_IP + 256 * R) * sizeof(double) + 512;
+#else
+constexpr size_t LDS_BYTES = (size_t)(OFF_IP + 256 * R) * sizeof(double);  // + progress counters, exception masks, reduction scratch, reciprocal pivots
+#endif
+
+struct Tile {
+    int kind, rt, ct;  // kind 0: tile (rt, ct), rt >= ct, of the block being factored; 1: tile (rt, ct), rt <= ct, of X^T
+};
+// 18 tiles per update wave, dealt so that the number of live tiles per micro-panel is level across the waves (<= 11).  A tile
+// of the block is live while its columns lie beyond the micro-panel (p <= 4 ct + 2); a tile of X^T also only once its rows have
+// begun (p >= 4 rt).  The panel loop of an update wave is FULLY specialised (template parameters p4, pp): which tiles a
+// micro-panel touches is known at compile time, the wave runs straight-line code -- reads, products, hand-back -- with no
+// per-tile test (a run-time test per tile costs more than the product: the structurizer turns eighteen uniform branches, or a
+// switch with fall-through, into chains of flag registers and serialises the LDS reads behind them; measured 2.1-2.7 k cycles per
+// micro-panel against ~0.7 k of matrix-pipe time).
+constexpr Tile TILES[4][18] = {
+    {{0, 3, 3}, {0, 4, 1}, {0, 5, 2}, {0, 5, 5}, {0, 6, 0}, {0, 6, 2}, {0, 7, 3}, {0, 7, 4}, {0, 7, 7}, {1, 0, 1}, {1, 0, 5}, {1, 1, 1}, {1, 2, 4}, {1, 3, 6}, {1, 3, 7}, {1, 5, 5}, {1, 6, 6}, {1, 6, 7}},
+    {{0, 1, 0}, {0, 2, 0}, {0, 2, 2}, {0, 3, 1}, {0, 5, 4}, {0, 6, 3}, {0, 6, 5}, {0, 7, 1}, {0, 7, 2}, {1, 0, 0}, {1, 0, 7}, {1, 1, 5}, {1, 1, 6}, {1, 2, 5}, {1, 3, 4}, {1, 4, 6}, {1, 5, 6}, {1, 5, 7}},
+    {{0, 0, 0}, {0, 2, 1}, {0, 3, 2}, {0, 4, 4}, {0, 5, 3}, {0, 6, 1}, {0, 6, 6}, {0, 7, 0}, {1, 0, 2}, {1, 0, 4}, {1, 0, 6}, {1, 1, 4}, {1, 2, 3}, {1, 2, 7}, {1, 3, 3}, {1, 3, 5}, {1, 4, 5}, {1, 7, 7}},
+    {{0, 1, 1}, {0, 3, 0}, {0, 4, 0}, {0, 4, 2}, {0, 4, 3}, {0, 5, 0}, {0, 5, 1}, {0, 6, 4}, {0, 7, 5}, {0, 7, 6}, {1, 0, 3}, {1, 1, 2}, {1, 1, 3}, {1, 1, 7}, {1, 2, 2}, {1, 2, 6}, {1, 4, 4}, {1, 4, 7}},
+};
+constexpr bool tile_live(Tile t, int p)
+{
+    return p <= 4 * t.ct + 2 && (t.kind == 0 || p >= 4 * t.rt);
+}
+
+#ifdef FR_K4_TS
+__device__ long long k4ts[128];  // developer stamps (scripts/mk_potf2_phases.py): per wave [8 w + 0] role cycles, [1] cycles spent waiting, [2] waits that blocked
+#define FR_K4_WAIT_BEGIN const long long tw0 = __builtin_amdgcn_s_memtime(); bool blocked = false;
+#define FR_K4_WAIT_BLOCKED blocked = true;
+// (accumulated in LDS with no-return atomics: a read-modify-write of global memory here would wait for every outstanding store)
+extern __shared__ __attribute__((aligned(16))) double k4lds[];
+#define FR_K4_TSLOT(i) (reinterpret_cast<unsigned long long*>(k4lds + flat::OFF_IP + 256 * flat::R) + 8 * (threadIdx.x >> 6) + (i))
+#define FR_K4_TADD(i, v) if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(FR_K4_TSLOT(i), (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define FR_K4_WAIT_END if (blocked) { FR_K4_TADD(1, __builtin_amdgcn_s_memtime() - tw0) FR_K4_TADD(2, 1) }
+#else
+#define FR_K4_WAIT_BEGIN
+#define FR_K4_WAIT_BLOCKED
+#define FR_K4_WAIT_END
+#endif
+// The counters are read and written with explicit DS instructions: a `volatile` access through a generic pointer is NOT
+// rewritten to the LDS address space by the compiler -- it becomes flat_load / flat_store with sc0 sc1 and an s_waitcnt vmcnt(0),
+// i.e. every poll and every publish would also wait for the wave's outstanding global stores of factor columns (measured: the
+// first version of this kernel spent ~25 k of a pivot wave's 60 k cycles there).
+__device__ __forceinline__ unsigned lds_off(const void* p)
+{
+    return (unsigned)(uintptr_t)p;  // (low half of a generic pointer into LDS = the LDS byte offset)
+}
+// four counters p[0..3] all >= target (skip0: p[0] does not count): ONE 16-byte LDS read per poll
+__device__ __forceinline__ void wait4(const int* p, int target, bool skip0 = false)
+{
+    FR_K4_WAIT_BEGIN
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    const unsigned addr = lds_off(p);
+    for (;;) {
+        i4_t a;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(addr) : "memory");
+        const int a0 = __builtin_amdgcn_readfirstlane(a[0]), a1 = __builtin_amdgcn_readfirstlane(a[1]);
+        const int a2 = __builtin_amdgcn_readfirstlane(a[2]), a3 = __builtin_amdgcn_readfirstlane(a[3]);
+        if (min(min(skip0 ? a1 : a0, a1), min(a2, a3)) >= target) break;
+        FR_K4_WAIT_BLOCKED
+        __builtin_amdgcn_s_sleep(1);
+    }
+    FR_K4_WAIT_END
+}
+__device__ __forceinline__ void wait1(const int* p, int target)
+{
+    FR_K4_WAIT_BEGIN
+    const unsigned addr = lds_off(p);
+    for (;;) {
+        int a;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(addr) : "memory");
+        if (__builtin_amdgcn_readfirstlane(a) >= target) break;
+        FR_K4_WAIT_BLOCKED
+        __builtin_amdgcn_s_sleep(1);
+    }
+    FR_K4_WAIT_END
+}
+__device__ __forceinline__ void publish(int* p, int v)
+{
+    // (LDS operations of one wave execute in order: everything this wave wrote before is visible to a wave that sees v)
+    asm volatile("ds_write_b32 %0, %1" : : "v"(lds_off(p)), "v"(v) : "memory");
+}
+
+// A row wave's registers: the row's four values in the current micro-panel, and its FINAL values in the two micro-panels before
+// it (multipliers of the updates the wave applies itself).  Micro-panel q's final values land in lp[q & 1] -- the set of
+// micro-panel q - 2, dead by then -- so the panel loops are unrolled by two and nothing is ever copied.
+struct RowState {
+    double n[4];
+    double lp[2][4];
+};
+static_assert(LAG == 3, "the row waves keep exactly two finished micro-panels");
+
+// columns of micro-panel q for this lane's row (every update of micro-panels <= q - 3 applied by the update waves), then the
+// updates of micro-panels q - 2 and q - 1:  n[c] -= sum_k lp[k] L(4 q + c, 4 (q - g) + k), multipliers broadcast from the L ring
+template <int PAR>
+__device__ __forceinline__ void load_panel(RowState& s, const double* lds, int stage_off, int row, int q)
+{
+    const double* st = lds + stage_off + (q & (NSTG - 1)) * PSZ + row;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s.n[c] = st[PS * c];
+#pragma unroll
+    for (int g = 2; g >= 1; --g) {
+        if (q >= g) {
+            const double (&lp)[4] = s.lp[g == 2 ? PAR : 1 - PAR];
+            const double* lr = lds + OFF_L + ((q - g) & (R - 1)) * PSZ + 4 * q;
+            double2 m[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[k][0] = *reinterpret_cast<const double2*>(lr + PS * k);
+                m[k][1] = *reinterpret_cast<const double2*>(lr + PS * k + 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s.n[0] = __builtin_fma(-lp[k], m[k][0].x, s.n[0]);
+                s.n[1] = __builtin_fma(-lp[k], m[k][0].y, s.n[1]);
+                s.n[2] = __builtin_fma(-lp[k], m[k][1].x, s.n[2]);
+                s.n[3] = __builtin_fma(-lp[k], m[k][1].y, s.n[3]);
+            }
+        }
+    }
+}
+
+// reciprocal pivots of the micro-panels in the ring: 64 copies of each (the pivot wave writes one per lane: a store of one word
+// by all 64 lanes is a 64-way conflict), the readers broadcast copy 0
+constexpr int IPS = 4 * 64;  // doubles per micro-panel
+
+// a follower's micro-panel: the 4 x 4 triangle of micro-panel q from the L ring, its reciprocal pivots, then
+// l_j = n_j ip_j;  n_c -= l_j L(4 q + c, 4 q + j);  the final values go to dst[]
+__device__ __forceinline__ void follow_panel(RowState& s, double (&dst)[4], const double* lds, int q)
+{
+    const double* lr = lds + OFF_L + (q & (R - 1)) * PSZ + 4 * q;
+    const double* ipr = lds + OFF_IP + IPS * (q & (R - 1));
+    double2 t[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        t[k][0] = *reinterpret_cast<const double2*>(lr + PS * k);
+        t[k][1] = *reinterpret_cast<const double2*>(lr + PS * k + 2);
+    }
+    const double ip0 = ipr[0], ip1 = ipr[64], ip2 = ipr[128], ip3 = ipr[192];
+    dst[0] = s.n[0] * ip0;
+    s.n[1] = __builtin_fma(-dst[0], t[0][0].y, s.n[1]);
+    s.n[2] = __builtin_fma(-dst[0], t[0][1].x, s.n[2]);
+    s.n[3] = __builtin_fma(-dst[0], t[0][1].y, s.n[3]);
+    dst[1] = s.n[1] * ip1;
+    s.n[2] = __builtin_fma(-dst[1], t[1][1].x, s.n[2]);
+    s.n[3] = __builtin_fma(-dst[1], t[1][1].y, s.n[3]);
+    dst[2] = s.n[2] * ip2;
+    s.n[3] = __builtin_fma(-dst[2], t[2][1].y, s.n[3]);
+    dst[3] = s.n[3] * ip3;
+}
+
+// The pivot wave does not store its columns: the OTHER block-row wave does (it follows / idles meanwhile) -- rows rbase ..
+// rbase + 63 of micro-panel q from the L ring to A, the diagonal entries as 1 / ip (the reciprocal pivot is 1 / sqrt(d) to an ulp;
+// the substitute, the failure NaN and plain-sqrt mode's sqrt(0) = 1 / inf all come out by themselves).
+__device__ __forceinline__ void store_panel(const double* lds, int lane, int rbase, int q, double* __restrict__ gcol /* &A[rbase + lane] */, int64_t lda)
+{
+    const double* rr = lds + OFF_L + (q & (R - 1)) * PSZ + rbase + lane;
+    const double* ipr = lds + OFF_IP + IPS * (q & (R - 1));
+    double v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = rr[PS * c];
+    const double ipv[4] = {ipr[0], ipr[64], ipr[128], ipr[192]};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double p = __builtin_amdgcn_rcp(ipv[c]);
+        p = __builtin_fma(__builtin_fma(-ipv[c], p, 1.0), p, p);
+        p = __builtin_fma(__builtin_fma(-ipv[c], p, 1.0), p, p);
+        p = (ipv[c] == __builtin_inf()) ? 0.0 : p;  // (rcp(inf) = 0, but the Newton steps make 0 * inf of it)
+        gcol[(int64_t)(4 * q + c) * lda] = (rbase + lane == 4 * q + c) ? p : v[c];
+    }
+}
+
+// one elimination step of the pivot wave: column J = 4 q + j; jl = lane of the micro-panel's first diagonal row; the column's final
+// values go to dst[j]
+template <bool MODE2, int j>
+__device__ __forceinline__ void pivot_step(RowState& s, double (&dst)[4], double alt, double& dd, double& ip, int lane, int jl, double* ring_row,
+                                           double* ipr_lane)
+{
+    const double qv = s.n[j] * ip;
+    const bool keep = lane > jl + j;
+    const double l = keep ? qv : 0.0;
+    PivotChain ch;
+    dd = __builtin_fma(-l, l, dd);
+    pin(dd);
+    ch.d = readlane_f64(dd, (jl + j + 1) & 63);  // next pivot candidate (unused after the wave's last column)
+    chain_stage<false, 0>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    // column J for the followers and the update waves (zeros on and above the diagonal), its reciprocal pivot beside it
+    ring_row[PS * j] = l;
+    ipr_lane[64 * j] = ip;
+    chain_stage<false, 1>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    chain_stage<false, 2>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (j + 1 < 4) {
+        const double m1 = readlane_f64(l, (jl + j + 1) & 63);
+        s.n[j + 1] = __builtin_fma(-l, m1, s.n[j + 1]);
+        pin(s.n[j + 1]);
+    }
+    chain_stage<false, 3>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (j + 2 < 4) {
+        const double m2 = readlane_f64(l, (jl + j + 2) & 63);
+        s.n[j + 2] = __builtin_fma(-l, m2, s.n[j + 2]);
+        pin(s.n[j + 2]);
+    }
+    chain_stage<false, 4>(ch);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (j + 3 < 4) {
+        const double m3 = readlane_f64(l, (jl + j + 3) & 63);
+        s.n[j + 3] = __builtin_fma(-l, m3, s.n[j + 3]);
+        pin(s.n[j + 3]);
+    }
+    chain_stage<false, 5>(ch);
+    chain_stage<false, 6>(ch);
+    dst[j] = l;
+    // pivot rule for the next column (which columns it fired on is worked out at the end, from the lanes' d): plain-sqrt mode
+    // tests d != 0 (negative and NaN propagate through rsq), the others d > 0
+    const bool ok = MODE2 ? (ch.d != 0.0) : (ch.d > 0.0);
+    ip = ok ? ch.r : alt;
+}
+
+template <bool MODE2, int H, int PAR>
+__device__ __forceinline__ void pivot_panel(RowState& s, double* lds, int* prog, int lane, int row, double alt, double& dd, double& ip, int q)
+{
+    const int jl = 4 * q - 64 * H;
+#ifdef FR_K4_TS
+    const long long tpw = __builtin_amdgcn_s_memtime();
+#endif
+    // micro-panel q's columns have come back from the update waves (they are past micro-panel q - LAG) ...
+    wait4(prog + 4, q - LAG + 1);
+    // ... and the ring slot of micro-panel q - R may be overwritten when every follower is past micro-panel q - R + LAG - 1, the
+    // last to read its multipliers; looked at every fourth micro-panel, for the four to come
+    if ((q & 3) == 0) wait4(prog, q + 3 - R + LAG);
+#ifdef FR_K4_TS
+    const long long tp0 = __builtin_amdgcn_s_memtime();
+    FR_K4_TADD(6, tp0 - tpw)
+#endif
+    load_panel<PAR>(s, lds, OFF_FS, row, q);
+#ifdef FR_K4_TS
+    pin(s.n[0]); pin(s.n[1]); pin(s.n[2]); pin(s.n[3]);
+    const long long tp1 = __builtin_amdgcn_s_memtime();
+#endif
+    double* rr = lds + OFF_L + (q & (R - 1)) * PSZ + row;
+    double* ipr = lds + OFF_IP + IPS * (q & (R - 1)) + lane;
+    pivot_step<MODE2, 0>(s, s.lp[PAR], alt, dd, ip, lane, jl, rr, ipr);
+    pivot_step<MODE2, 1>(s, s.lp[PAR], alt, dd, ip, lane, jl, rr, ipr);
+    pivot_step<MODE2, 2>(s, s.lp[PAR], alt, dd, ip, lane, jl, rr, ipr);
+    pivot_step<MODE2, 3>(s, s.lp[PAR], alt, dd, ip, lane, jl, rr, ipr);
+#ifdef FR_K4_TS
+    pin(ip);
+    const long long tp2 = __builtin_amdgcn_s_memtime();
+    FR_K4_TADD(4, tp1 - tp0) FR_K4_TADD(5, tp2 - tp1)
+#endif
+    publish(prog + H, q + 1);
+}
+
+template <bool MODE2, int H>
+__device__ __forceinline__ void pivot_phase(RowState& s, double* lds, int* prog, int lane, int row, double alt, double& dd)
+{
+    double d = readlane_f64(dd, 0), ip, p0;
+    sqrt_rsqrt(d, p0, ip);
+    ip = (MODE2 ? (d != 0.0) : (d > 0.0)) ? ip : alt;
+    // the chain is the critical path of the launch: its wave wins the issue slot over whichever wave shares its SIMD (an update
+    // wave's products, a follower's polls)
+    __builtin_amdgcn_s_setprio(3);
+    for (int q = 16 * H; q < 16 * H + 16; q += 2) {
+        pivot_panel<MODE2, H, 0>(s, lds, prog, lane, row, alt, dd, ip, q);
+        pivot_panel<MODE2, H, 1>(s, lds, prog, lane, row, alt, dd, ip, q + 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// a follower's micro-panel of the block rows 64 .. 127 (wave 1 while wave 0 pivots)
+template <int PAR>
+__device__ __forceinline__ void d_follow(RowState& s, double* lds, int* prog, int lane, int row, double& dd, int q, double* __restrict__ A,
+                                         double* __restrict__ gcol, int64_t lda)
+{
+    // (the columns and the earlier micro-panels' multipliers are there BEFORE the pivot wave is through micro-panel q: only the
+    // 4 x 4 triangle waits for it -- this wave's latency sits between the pivot wave and the update waves)
+    wait1(prog + 0, q);
+    wait4(prog + 4, q - LAG + 1);
+    load_panel<PAR>(s, lds, OFF_FS, row, q);
+    wait1(prog + 0, q + 1);
+    follow_panel(s, s.lp[PAR], lds, q);
+    double* rr = lds + OFF_L + (q & (R - 1)) * PSZ + row;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dd = __builtin_fma(-s.lp[PAR][c], s.lp[PAR][c], dd);
+        rr[PS * c] = s.lp[PAR][c];
+    }
+    publish(prog + 1, q + 1);  // (the update waves go on; the stores are nobody's dependency)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gcol[(int64_t)(4 * q + c) * lda] = s.lp[PAR][c];
+    store_panel(lds, lane, 0, q, A + lane, lda);
+}
+
+// Rows 64 H .. 64 H + 63 of the block: pivot wave for its own 64 columns; before that (H = 1) follower of the other wave's columns,
+// after it (H = 0) nothing of its own is left -- in both cases it also stores the pivoting wave's columns
+template <int H>
+__device__ __forceinline__ void d_wave(double* lds, int* prog, int lane, double* __restrict__ A, int64_t lda, bool mode2, double alt, double& dd)
+{
+    const int row = 64 * H + lane;
+    RowState s;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s.lp[g][c] = 0.0;
+    dd = A[row + (int64_t)row * lda];
+    double* gcol = A + row;
+    if constexpr (H == 1) {
+        for (int q = 0; q < 16; q += 2) {
+            d_follow<0>(s, lds, prog, lane, row, dd, q, A, gcol, lda);
+            d_follow<1>(s, lds, prog, lane, row, dd, q + 1, A, gcol, lda);
+        }
+    }
+#ifdef FR_K4_TS
+    const long long tpl = __builtin_amdgcn_s_memtime();
+#endif
+    if (mode2) pivot_phase<true, H>(s, lds, prog, lane, row, alt, dd);
+    else pivot_phase<false, H>(s, lds, prog, lane, row, alt, dd);
+#ifdef FR_K4_TS
+    FR_K4_TADD(7, __builtin_amdgcn_s_memtime() - tpl)
+#endif
+    if constexpr (H == 0) {
+        // the other wave pivots now: its columns 64 .. 127 go to memory from here, with zeros in rows 0 .. 63 (above the diagonal:
+        // refinement uses L_bb as a plain 128 x 128 operand)
+        for (int q = 16; q < 32; ++q) {
+            wait1(prog + 1, q + 1);
+            store_panel(lds, lane, 64, q, A + 64 + lane, lda);
+            publish(prog + 0, q + 1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gcol[(int64_t)(4 * q + c) * lda] = 0.0;
+        }
+    }
+}
+
+// a micro-panel of rows 64 G .. 64 G + 63 of X^T = I L^-T
+template <int G, int PAR>
+__device__ __forceinline__ void x_follow(RowState& s, double* lds, int* prog, int row, int q, double* __restrict__ gi, double& wmax, double& nanacc)
+{
+    // (rows 4 q .. 4 q + 3 of the earlier micro-panels -- the multipliers -- belong to the wave that pivots micro-panel q)
+    const int* pv = prog + (q < 16 ? 0 : 1);
+    wait1(pv, q);
+    wait4(prog + 4, q - LAG + 1);
+    load_panel<PAR>(s, lds, OFF_XS, row, q);
+    wait1(pv, q + 1);
+    follow_panel(s, s.lp[PAR], lds, q);
+    double* rr = lds + OFF_Y + (q & (R - 1)) * PSZ + row;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rr[PS * c] = s.lp[PAR][c];
+    publish(prog + 2 + G, q + 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        wmax = __builtin_fmax(wmax, __builtin_fabs(s.lp[PAR][c]));
+        nanacc = __builtin_fma(s.lp[PAR][c], 0.0, nanacc);
+    }
+    *reinterpret_cast<double2*>(gi + 4 * q) = double2{s.lp[PAR][0], s.lp[PAR][1]};
+    *reinterpret_cast<double2*>(gi + 4 * q + 2) = double2{s.lp[PAR][2], s.lp[PAR][3]};
+}
+
+// Rows 64 G .. 64 G + 63 of X^T = I L^-T
+template <int G>
+__device__ __forceinline__ void x_wave(double* lds, int* prog, int lane, double* __restrict__ inv, int64_t ldinv, double& wmax, double& nanacc)
+{
+    const int row = 64 * G + lane;
+    RowState s;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s.lp[g][c] = 0.0;
+    double* gi = inv + (int64_t)row * ldinv;  // column `row` of the inverse: W(j, row) = X^T(row, j)
+    if constexpr (G == 1) {
+        // columns 0..63 of these rows are zero (above the diagonal of X^T's transpose): stored while the wave has nothing to do
+        for (int j = 0; j < 64; j += 2) *reinterpret_cast<double2*>(gi + j) = double2{0.0, 0.0};
+    }
+    for (int q = 16 * G; q < 32; q += 2) {
+        x_follow<G, 0>(s, lds, prog, row, q, gi, wmax, nanacc);
+        x_follow<G, 1>(s, lds, prog, row, q + 1, gi, wmax, nanacc);
+    }
+}
+
+// ---- update waves ----------------------------------------------------------------------------------------------------
+template <int U, int I>
+__device__ __forceinline__ void u_init(d4_t (&acc)[18], const double* __restrict__ A, int64_t lda, int l15, int lq)
+{
+    if constexpr (I < 18) {
+        constexpr Tile T = TILES[U][I];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = 16 * T.rt + l15, c = 16 * T.ct + lq + 4 * g;
+            if constexpr (T.kind == 0) acc[I][g] = -A[r + (int64_t)c * lda];
+            else acc[I][g] = (r == c) ? -1.0 : 0.0;
+        }
+        u_init<U, I + 1>(acc, A, lda, l15, lq);
+    }
+}
+
+// micro-panel P applied to the wave's live tiles (first operand <-> column of the tile, second <-> row)
+// (FIRST = true: the tiles whose columns are handed back after this micro-panel; false: the others -- their products may still be
+// in the matrix pipe while the hand-back is written)
+template <int U, int P, bool FIRST, int I>
+__device__ __forceinline__ void u_apply(d4_t (&acc)[18], const double* lring, const double* yring)
+{
+    if constexpr (I < 18) {
+        constexpr Tile T = TILES[U][I];
+        if constexpr (tile_live(T, P) && ((T.ct == (P + LAG) / 4) == FIRST)) {
+            const double a = lring[16 * T.ct];
+            const double b = (T.kind == 0) ? lring[16 * T.rt] : yring[16 * T.rt];
+            if (K4X != 6) acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[I], 0, 0, 0);
+            else acc[I][0] += a + b;  // (experiment 6: no matrix-core work: wrong results, chain pace only)
+        }
+        u_apply<U, P, FIRST, I + 1>(acc, lring, yring);
+    }
+}
+
+// columns of micro-panel Q = P + LAG (tile column Q / 4, accumulator register Q % 4) handed back through the staging buffers
+template <int U, int Q, int I>
+__device__ __forceinline__ void u_extract(const d4_t (&acc)[18], double* fs, double* xs)
+{
+    if constexpr (I < 18) {
+        constexpr Tile T = TILES[U][I];
+        if constexpr (T.ct == Q / 4) {
+            double* dst = (T.kind == 0) ? fs : xs;
+            dst[16 * T.rt] = -acc[I][Q % 4];
+        }
+        u_extract<U, Q, I + 1>(acc, fs, xs);
+    }
+}
+
+template <int U, int P>
+__device__ __forceinline__ void u_panels(d4_t (&acc)[18], double* lds, int* prog, int lane_off)
+{
+    if constexpr (P <= 30) {
+#ifdef FR_K4_TS
+        const long long tu0 = __builtin_amdgcn_s_memtime();
+#endif
+        // (from micro-panel 16 on, wave 0 only stores the other wave's columns: its counter guards the ring, nobody's operands)
+        wait4(prog, P + 1, P >= 16);
+#ifdef FR_K4_TS
+        const long long tu1 = __builtin_amdgcn_s_memtime();
+#endif
+        const double* lring = lds + OFF_L + (P & (R - 1)) * PSZ + lane_off;
+        const double* yring = lds + OFF_Y + (P & (R - 1)) * PSZ + lane_off;
+        u_apply<U, P, true, 0>(acc, lring, yring);
+        u_apply<U, P, false, 0>(acc, lring, yring);
+#ifdef FR_K4_TS
+        const long long tu2 = __builtin_amdgcn_s_memtime();
+#endif
+        constexpr int Q = P + LAG;
+        if constexpr (Q < 32) {
+            double* fs = lds + OFF_FS + (Q & (NSTG - 1)) * PSZ + lane_off;
+            double* xs = lds + OFF_XS + (Q & (NSTG - 1)) * PSZ + lane_off;
+            u_extract<U, Q, 0>(acc, fs, xs);
+        }
+        publish(prog + 4 + U, P + 1);
+#ifdef FR_K4_TS
+        const long long tu3 = __builtin_amdgcn_s_memtime();
+        FR_K4_TADD(6, tu1 - tu0) FR_K4_TADD(4, tu2 - tu1) FR_K4_TADD(5, tu3 - tu2)
+#endif
+        u_panels<U, P + 1>(acc, lds, prog, lane_off);
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void u_wave(double* lds, int* prog, int lane, const double* __restrict__ A, int64_t lda)
+{
+    const int l15 = lane & 15, lq = lane >> 4;
+    d4_t acc[18];
+    u_init<U, 0>(acc, A, lda, l15, lq);
+    u_panels<U, 0>(acc, lds, prog, l15 + PS * lq);
+    publish(prog + 4 + U, 64);
+}
+
+}  // namespace flat
+
+__global__ __launch_bounds__(PT, 2) void potf2_flat_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
+                                                        double sub, double* __restrict__ inv, int64_t ldinv,
+                                                        int64_t* __restrict__ info, double* __restrict__ cest,
+                                                        unsigned* __restrict__ xcc_word)
+{
+    using namespace flat;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int hw = __builtin_amdgcn_readfirstlane(t >> 6);
+    // role of hardware wave hw: 0 / 1 the block's row waves, 2 / 3 the rows of X^T, 4 .. 7 the update waves.  Waves hw and hw + 4
+    // of a workgroup share a SIMD (observed on every run, not promised): the pivot waves are paired with the X^T followers and the
+    // update waves with each other -- an update wave's FP64 products on the pivot wave's SIMD hold its dependent f64 operations up
+    // (38.2 -> 34.2 us; with no products at all 33.6; experiment 8 = roles in wave order)
+    const int w = (K4X != 8) ? ((hw & 1) | ((hw & 2) << 1) | ((hw & 4) >> 1)) : hw;
+    if (xcc_word && t == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_store(xcc_word, (xcc & 7u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int* prog = reinterpret_cast<int*>(lds + OFF_END);                                  // 8 progress counters
+    unsigned long long* excs = reinterpret_cast<unsigned long long*>(lds + OFF_END + 4);  // 2 exception masks
+    double* red = lds + OFF_END + 6;                                                    // 8 reduction slots
+    // ---- prologue: micro-panels 0 .. LAG - 1 straight into the staging slots, zeros where a wave reads before anyone wrote
+    if (w < 2) {
+        const int r = 64 * w + lane;
+        double v[4 * LAG];
+#pragma unroll
+        for (int c = 0; c < 4 * LAG; ++c) v[c] = A[r + (int64_t)c * lda];
+#pragma unroll
+        for (int c = 0; c < 4 * LAG; ++c) lds[OFF_FS + (c >> 2) * PSZ + r + PS * (c & 3)] = v[c];
+    } else if (w < 4) {
+        const int r = 64 * (w - 2) + lane;
+#pragma unroll
+        for (int c = 0; c < 4 * NSTG; ++c) lds[OFF_XS + (c >> 2) * PSZ + r + PS * (c & 3)] = (r == c && c < 4 * LAG) ? 1.0 : 0.0;
+#pragma unroll
+        for (int sl = 0; sl < R; ++sl)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds[OFF_Y + sl * PSZ + r + PS * c] = 0.0;
+    }
+    if (t < 8) prog[t] = (t == 3) ? 16 : 0;
+#ifdef FR_K4_TS
+    if (t < 64) reinterpret_cast<unsigned long long*>(lds + OFF_IP + 256 * R)[t] = 0ull;
+#endif
+    lds_barrier();
+
+    const bool mode2 = (mode == 2);
+    double p_exc = __builtin_nan(""), ip_exc = p_exc;
+    const bool substitute = (mode == 1 && sub > 0.0);
+    if (substitute) sqrt_rsqrt(sub, p_exc, ip_exc);
+    // what the reciprocal pivot becomes when the rule's test fails: 1 / sqrt(substitute) or NaN (failure); plain-sqrt mode
+    // (add_rows): +inf, the reference's division by sqrt(0)
+    const double alt = mode2 ? __builtin_inf() : ip_exc;
+    double wmax = 0.0, nanacc = 0.0, dmin = __builtin_inf();
+#ifdef FR_K4_TS
+    const long long trole0 = __builtin_amdgcn_s_memtime();
+    (void)0;
+#endif
+    double dd = 0.0;
+    if (w == 0) d_wave<0>(lds, prog, lane, A, lda, mode2, alt, dd);
+    else if (w == 1) d_wave<1>(lds, prog, lane, A, lda, mode2, alt, dd);
+    else if (w == 2) x_wave<0>(lds, prog, lane, inv, ldinv, wmax, nanacc);
+    else if (w == 3) x_wave<1>(lds, prog, lane, inv, ldinv, wmax, nanacc);
+    else if (w == 4) u_wave<0>(lds, prog, lane, A, lda);
+    else if (w == 5) u_wave<1>(lds, prog, lane, A, lda);
+    else if (w == 6) u_wave<2>(lds, prog, lane, A, lda);
+    else u_wave<3>(lds, prog, lane, A, lda);
+
+#ifdef FR_K4_TS
+    if (lane == 0) { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); const long long tr = __builtin_amdgcn_s_memtime() - trole0;
+        for (int i = 0; i < 8; ++i) k4ts[8 * w + i] = (i == 0) ? tr : ((i == 3) ? (long long)((hwid >> 4) & 3) : (long long)*FR_K4_TSLOT(i)); }
+#endif
+    // ---- epilogue: the diagonal of the factor from the recorded d, the log, the conditioning estimate
+    if (w < 2) {
+        const int r = 64 * w + lane;
+        // a lane's accumulator dd stayed d_r, the value its pivot was taken from, once its column had passed
+        const double d = dd;
+        double p, ipd;
+        sqrt_rsqrt(d, p, ipd);
+        const bool bad = !(mode == 2 || d > 0.0);
+        ipd = bad ? ip_exc : ipd;
+        dmin = __builtin_fabs(ipd);
+        dmin = (dmin != dmin) ? -1.0 : dmin;  // (NaN marker: resolved below)
+        const unsigned long long exc = __ballot(bad);
+        if (lane == 0) excs[w] = exc;
+    }
+    // wave reductions: max |W| (NaN sticks through nanacc), min |W_ii|
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        wmax = __builtin_fmax(wmax, __shfl_xor(wmax, off, 64));
+        nanacc += __shfl_xor(nanacc, off, 64);
+        dmin = __builtin_fmin(dmin, __shfl_xor(dmin, off, 64));
+    }
+    if (lane == 0) red[w] = (w < 2) ? dmin : ((w < 4) ? ((nanacc != nanacc) ? nanacc : wmax) : 0.0);
+    lds_barrier();
+    if (t == 0) {
+        const unsigned long long e0 = excs[0], e1 = excs[1];
+        if (e0 | e1) {
+            if (substitute) {
+                int64_t qn = info[1];
+                for (int j = 0; j < 64; ++j)
+                    if ((e0 >> j) & 1ull) info[3 + qn++] = col0 + j;
+                for (int j = 0; j < 64; ++j)
+                    if ((e1 >> j) & 1ull) info[3 + qn++] = col0 + 64 + j;
+                info[1] = qn;
+            } else if (info[0] == 0) {
+                const int first = e0 ? (__builtin_ffsll((long long)e0) - 1) : (64 + __builtin_ffsll((long long)e1) - 1);
+                info[0] = 1 + col0 + first;
+            }
+        }
+        if (cest) {
+            const double dm = __builtin_fmin(red[0], red[1]);
+            const double wa = red[2], wb = red[3];
+            double wm = (wa != wa) ? wa : ((wb != wb) ? wb : __builtin_fmax(wa, wb));
+            *cest = (dm < 0.0) ? __builtin_nan("") : wm / dm;
+        }
+    }
+}
+
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub, double* inv,
                  int64_t ldinv, int64_t* info, double* cest)
 {
@@ -850,13 +1487,23 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
         FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_uncapped_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
+        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_flat_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)flat::LDS_BYTES));
         ctx->potf2_lds_set = true;
     }
     static const int force = getenv("FRIEDRICH_AMD_K4_UNCAPPED") ? atoi(getenv("FRIEDRICH_AMD_K4_UNCAPPED")) : -1;
+    static const int force_flat = getenv("FRIEDRICH_AMD_K4_FLAT") ? atoi(getenv("FRIEDRICH_AMD_K4_FLAT")) : -1;
     const bool uncapped = force >= 0 ? force == 1 : (ctx->reserve_now > 0 || ctx->world > 1 || ctx->k4_alone);
+    // the flat kernel: full blocks with their inverse, wherever the diagonal-block kernel has its CU to itself
+    const bool flat_ok = nbk == PB && mode != 3 && inv != nullptr;
+    const bool use_flat = flat_ok && (force_flat >= 0 ? force_flat == 1 : uncapped);
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
-    hipLaunchKernelGGL(uncapped ? potf2_uncapped_kernel : potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode,
-                       sub, inv, ldinv, info, cest, ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr);
+    if (use_flat)
+        hipLaunchKernelGGL(potf2_flat_kernel, dim3(1), dim3(PT), flat::LDS_BYTES, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv, info,
+                           cest, ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr);
+    else
+        hipLaunchKernelGGL(uncapped ? potf2_uncapped_kernel : potf2_kernel, dim3(1), dim3(PT), POTF2_LDS, ctx->ls, A, lda, (int)nbk, col0, mode,
+                           sub, inv, ldinv, info, cest, ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

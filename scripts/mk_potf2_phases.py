@@ -34,6 +34,7 @@ def _stamp(m):
             + m.group(0).replace("cest);", "cest, ts);") + "    if (threadIdx.x == 0) ts[10] = __builtin_amdgcn_s_memtime();\n")
 kern = re.sub(r"    potf2_block<[^>]*>\(lds, A, lda, n, col0, mode, sub, inv, ldinv, info, cest\);\n", _stamp, kern)
 assert n_calls == 2, n_calls
+kern = kern.replace('potf2_flat_kernel', 'potf2_flat_kernel_h')  # (the library exports a kernel of the same name and signature)
 prog = '''#include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -44,8 +45,11 @@ prog = '''#include <hip/hip_runtime.h>
 #include "fr_internal.hpp"
 namespace fr {
 ''' + kern + '''}
+#ifdef FR_K4_TS
+__global__ void copy_k4ts(long long* out) { if (threadIdx.x < 64) out[threadIdx.x] = fr::flat::k4ts[threadIdx.x]; }
+#endif
 int main(int argc, char** argv){
-  const bool noise = argc > 1 && argv[1][0] == 'n'; const bool capped = argc > 2 && argv[2][0] == 'c';
+  const bool noise = argc > 1 && argv[1][0] == 'n'; const bool capped = argc > 2 && argv[2][0] == 'c'; const bool flatk = argc > 2 && argv[2][0] == 'f';
   fr_ctx* ctx = nullptr; double *NA = nullptr, *NC = nullptr; const int64_t NM = 16384, NK = 512;
   if (noise) {
     if (fr_ctx_create(&ctx, 0) != FR_OK) { printf("ctx failed\\n"); return 1; }
@@ -57,6 +61,30 @@ int main(int argc, char** argv){
   double *A,*inv; int64_t* info; long long* ts; (void)hipMalloc(&A,n*n*8); (void)hipMalloc(&inv,n*n*8); (void)hipMalloc(&info,8*(3+n)); (void)hipMalloc(&ts,8*64);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_uncapped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::POTF2_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fr::potf2_flat_kernel_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr::flat::LDS_BYTES);
+  if (flatk) {
+    std::vector<double> L0(n*n), W0(n*n), L1(n*n), W1(n*n);
+    for (int which = 0; which < 2; ++which) {
+      for (int rep = 0; rep < 4; ++rep) {
+        (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n)); (void)hipMemset(inv,0,n*n*8);
+        if (noise) { for (int g = 0; g < 6; ++g) fr_gemm(ctx, 0, 1, NM, NM, NK, -1.0, NA, NM, NA, NM, 1.0, NC, NM); usleep(6000); }
+        hipEvent_t e0,e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0,hs);
+        if (which == 0) hipLaunchKernelGGL(fr::potf2_uncapped_kernel,dim3(1),dim3(512),fr::POTF2_LDS,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,(double*)nullptr,(unsigned*)nullptr,ts);
+        else hipLaunchKernelGGL(fr::potf2_flat_kernel_h,dim3(1),dim3(512),fr::flat::LDS_BYTES,hs,A,(int64_t)n,n,(int64_t)0,0,0.0,inv,(int64_t)n,info,(double*)nullptr,(unsigned*)nullptr);
+        (void)hipEventRecord(e1,hs); hipError_t er = hipDeviceSynchronize();
+        float ms; (void)hipEventElapsedTime(&ms,e0,e1);
+        printf("%s rep %d: %.1f us (%s)\\n", which ? "flat" : "staged", rep, ms*1e3, hipGetErrorString(er));
+      }
+      (void)hipMemcpy(which ? L1.data() : L0.data(), A, n*n*8, hipMemcpyDeviceToHost); (void)hipMemcpy(which ? W1.data() : W0.data(), inv, n*n*8, hipMemcpyDeviceToHost);
+    }
+#ifdef FR_K4_TS
+    { long long kt[128]; (void)hipDeviceSynchronize(); hipLaunchKernelGGL(copy_k4ts, dim3(1), dim3(128), 0, 0, ts); (void)hipDeviceSynchronize(); (void)hipMemcpy(kt, ts, sizeof(kt) < 8*64 ? sizeof(kt) : 8*64, hipMemcpyDeviceToHost); const char* nm[8] = {"PA","PB","XA","XB","U0","U1","U2","U3"};
+      for (int w = 0; w < 8; ++w) printf("  %s (SIMD %lld): role %lld cycles, waiting %lld in %lld blocked waits; pivot panels: all waits %lld load %lld steps %lld whole pivot phase %lld\\n", nm[w], kt[8*w+3], kt[8*w], kt[8*w+1], kt[8*w+2], kt[8*w+6], kt[8*w+4], kt[8*w+5], kt[8*w+7]); }
+#endif
+    double el = 0, ew = 0, ml = 0, mw = 0; for (int c = 0; c < n; ++c) for (int r = 0; r < n; ++r) { double a = L0[r+c*n], b = L1[r+c*n]; if (r < c) { a = 0; } el = fmax(el, fabs(a-b)); ml = fmax(ml, fabs(a)); ew = fmax(ew, fabs(W0[r+c*n]-W1[r+c*n])); mw = fmax(mw, fabs(W0[r+c*n])); if (!(fabs(a-b) < 1e-9) && r >= c && c < 3 && r < 6) printf("  L[%d,%d] staged %.12g flat %.12g\\n", r, c, a, b); }
+    printf("flat vs staged: max |dL| %.3e (max |L| %.3e)  max |dW| %.3e (max |W| %.3e)\\n", el, ml, ew, mw);
+    return 0;
+  }
   for(int rep=0;rep<3;++rep){
     (void)hipMemcpy(A,h.data(),n*n*8,hipMemcpyHostToDevice); (void)hipMemset(info,0,8*(3+n));
     if (noise) { for (int g = 0; g < 6; ++g) fr_gemm(ctx, 0, 1, NM, NM, NK, -1.0, NA, NM, NA, NM, 1.0, NC, NM); usleep(6000); }
