@@ -192,7 +192,7 @@ def run_rank(args, link, device_index, emit, mode):
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize(dev)
-        link.barrier()
+        sharding.sync_point(link)  # (raises PeerFailure when a peer reports a failed step instead of arriving)
         if mode.startswith("process") and sharded:
             import torch.distributed as dist
             dist.barrier()  # (the contract's barrier over RCCL; link.barrier is the control plane's)
@@ -244,15 +244,22 @@ def run_rank(args, link, device_index, emit, mode):
 
     res = None
     while res is None:
+        agreed = False
         try:
             res = measure()
             ok, why = True, None
+        except sharding.PeerFailure as e:
+            ok, why, agreed = False, str(e), True  # (the rendezvous inside measure() WAS the agreement)
         except FriedrichError as e:
             if not sharded or world == 1 or schedule is None or schedule < 0:
                 raise
             ok, why = False, str(e)
+        except BaseException:
+            link.abort()
+            raise
         if sharded and world > 1 and schedule is not None and schedule >= 0:
-            ok, why = sharding.agree(link, ok, why)
+            if not agreed:
+                ok, why = sharding.agree(link, ok, why)
             if not ok:
                 if res is not None:
                     res["chol"].free()
@@ -327,6 +334,20 @@ def run_rank(args, link, device_index, emit, mode):
 
             extras["fit_ms_h2d_inclusive"] = best_ms(fit_from_host, reps=2)
 
+    # sharded: one optimizer iteration's gradient terms with the rows of L^-1 dealt to the ranks (collective: every rank calls;
+    # outside the timed region) -- per rank in `per_rank`
+    grad_ms = None
+    if sharded and world > 1 and schedule is not None and schedule >= 0 and not args.no_extras:
+        try:
+            chol.grad_terms(kernel, y_d, noise, True, 2)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            chol.grad_terms(kernel, y_d, noise, True, 2)
+            ctx.synchronize()
+            grad_ms = 1e3 * (time.perf_counter() - t0)
+        except FriedrichError as e:
+            log(f"sharded grad_terms failed: {e}")
+
     # --verify: this rank's share of the predictions against a single-rank fit of the same rows on the same GPU (tests)
     verify_err = None
     if args.verify and m_loc > 0:
@@ -345,7 +366,8 @@ def run_rank(args, link, device_index, emit, mode):
     per_rank = link.gather({"elapsed": elapsed, "fit_ms": float(np.mean(fit_ms)), "pred_ms": float(np.mean(pred_ms)),
                             "classes": {k: round(v["ms"], 3) for k, v in res["classes"].items()},
                             "launches": {k: v["launches"] for k, v in res["classes"].items()},
-                            "prof_step_ms": res["prof_step_ms"], "comm_timeouts": ctx.counter("comm_timeouts"), "verify": verify_err})
+                            "prof_step_ms": res["prof_step_ms"], "comm_timeouts": ctx.counter("comm_timeouts"), "verify": verify_err,
+                            "grad_terms_ms": grad_ms})
     elapsed = max(r["elapsed"] for r in per_rank)
 
     info = chol.info()
@@ -422,6 +444,7 @@ def run_rank(args, link, device_index, emit, mode):
                 "gram_ms": [r["classes"]["gram"] for r in per_rank], "solve_ms": [r["classes"]["gemm_solve"] for r in per_rank],
                 "comm_calls": [r["launches"]["comm"] for r in per_rank], "step_with_events_ms": [round(r["prof_step_ms"], 3) for r in per_rank],
                 "comm_timeouts": [r["comm_timeouts"] for r in per_rank],
+                "grad_terms_ms": [None if r["grad_terms_ms"] is None else round(r["grad_terms_ms"], 3) for r in per_rank],
                 "note": "one untimed step with HIP events around every launch; comm_ms includes the wait for the peers; classes on "
                         "different streams overlap, so they do not add up to the step",
             }

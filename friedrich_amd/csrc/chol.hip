@@ -447,7 +447,9 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     }
     double* pbuf = nullptr;
     int64_t split_rows = 0;
-    const bool split = world > 1 && ctx->dist_schedule != 0;
+    // (a refined factorisation -- rare: ill-conditioned diagonal blocks -- takes the whole-panel schedule whatever the option
+    // says: its owner solves the panel's rows with the refinement step behind every inverse product, factor_panel)
+    const bool split = world > 1 && ctx->dist_schedule != 0 && !ctx->refine_now;
     if (world > 1) {
         // (split variant: head + W slices of whole 128-row blocks)
         split_rows = round_up((n + world - 1) / world, IB);
@@ -1045,8 +1047,12 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         // if it cannot be built (memory), the solve takes the paths below instead of failing
         WsGuard wb(ctx);
         double* tmpb = nullptr;
-        if (ensure_inv512(ctx, c, cls) == FR_OK && ensure_invbig(ctx, c, cls) == FR_OK && (tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m)) != nullptr)
+        if (ensure_inv512(ctx, c, cls) == FR_OK && ensure_invbig(ctx, c, cls) == FR_OK) {
+            // (scratch of 2048 x m: every other path needs a workspace of that order too -- no fall-through on this one, so that
+            // the only way to the persistent kernels below is a cache that could not be built, which solve_in_place rules out first)
+            if ((tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m)) == nullptr) return FR_OUT_OF_MEMORY;
             return trsm_big(ctx, c, n, B, m, ldb, cls, true, tmpb);
+        }
         (void)hipGetLastError();
     }
     if (use_column_groups(ctx, c, n, m)) return launch_trsm_narrow(ctx, c, B, m, ldb, true, cls);
@@ -1131,8 +1137,10 @@ int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
     if (use_big_leaves(ctx, c, n, m, true) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max)) {
         WsGuard wb(ctx);
         double* tmpb = nullptr;
-        if (ensure_inv512(ctx, c, cls) == FR_OK && ensure_invbig(ctx, c, cls) == FR_OK && (tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m)) != nullptr)
+        if (ensure_inv512(ctx, c, cls) == FR_OK && ensure_invbig(ctx, c, cls) == FR_OK) {
+            if ((tmpb = wb.get(sizeof(double) * (size_t)GB * (size_t)m)) == nullptr) return FR_OUT_OF_MEMORY;
             return trsm_big(ctx, c, n, B, m, ldb, cls, false, tmpb);
+        }
         (void)hipGetLastError();
     }
     if (use_column_groups(ctx, c, n, m)) return launch_trsm_narrow(ctx, c, B, m, ldb, false, cls);
@@ -1145,6 +1153,34 @@ int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
         if (!tmp) return FR_OUT_OF_MEMORY;
     }
     return trsm_bwd_rec(ctx, c, 0, n, B, m, ldb, cls, tmp);
+}
+
+// The leading k1 x k1 block of the factor as a solve of its own (the sharded gradient terms: grad.hip).  Only paths that wait
+// for nothing but stream order; the 2048-row leaves where k1 is a whole number of them, the 512-row leaves otherwise.
+int trsm_lower_bwd_leading(fr_ctx* ctx, const fr_chol* c, int64_t k1, double* B, int64_t m, int64_t ldb, int cls)
+{
+    if (k1 <= 0 || m <= 0) return FR_OK;
+    if (k1 > c->n) return set_err(ctx, FR_INVALID_ARGUMENT, "leading block larger than the factor");
+    if (c->refine) {
+        WsGuard w(ctx);
+        double* tmp = w.get(sizeof(double) * (size_t)IB * (size_t)m);
+        if (!tmp) return FR_OUT_OF_MEMORY;
+        return trsm_bwd_rec(ctx, c, 0, k1, B, m, ldb, cls, tmp);
+    }
+    if (k1 >= 2 * LB && ctx->leaf512 != 0) FR_TRY(ensure_inv512(ctx, c, cls));
+    WsGuard w(ctx);
+    if (ctx->leaf512 != 0 && m >= 2 && k1 >= 2 * GB && k1 % GB == 0 && ensure_invbig(ctx, c, cls) == FR_OK) {
+        double* tmpb = w.get(sizeof(double) * (size_t)GB * (size_t)m);
+        if (!tmpb) return FR_OUT_OF_MEMORY;
+        return trsm_big(ctx, c, k1, B, m, ldb, cls, false, tmpb);
+    }
+    (void)hipGetLastError();
+    double* tmp = nullptr;
+    if (ctx->leaf512 != 0 && k1 >= 2 * LB && k1 % LB == 0 && m >= 2) {
+        tmp = w.get(sizeof(double) * (size_t)LB * (size_t)m);
+        if (!tmp) return FR_OUT_OF_MEMORY;
+    }
+    return trsm_bwd_rec(ctx, c, 0, k1, B, m, ldb, cls, tmp);
 }
 
 static void chol_release(fr_chol* c)
@@ -1254,31 +1290,50 @@ int chol_fetch_info(fr_chol* c)
     return FR_OK;
 }
 
-// Multi-GPU: every rank logged only the pivots of the panels it owned; gather and merge the logs on the host.
+// Multi-GPU: every rank logged only the pivots of the panels it owned and holds the conditioning estimates of the diagonal
+// blocks it factored; ONE all-gather carries both (the estimates ride behind the log as bit patterns), the host merges:
+// the ranks end with the same substitution list, failure column and largest estimate -- and therefore take the same
+// refinement decision (assemble_and_factor).
 static int merge_info(fr_chol* c)
 {
     fr_ctx* ctx = c->ctx;
     const int W = ctx->world;
-    const int64_t len = 3 + c->n;
-    WsGuard g(ctx);
+    const int64_t nblk = (c->n + IB - 1) / IB;
+    const int64_t len = 3 + c->n + nblk;
+    WsGuard g(ctx), sg(ctx);
     int64_t* all = (int64_t*)g.get(sizeof(int64_t) * (size_t)(len * W));
-    if (!all) return FR_OUT_OF_MEMORY;
-    FR_TRY(comm_allgather_i64(ctx, c->info, all, (size_t)len));
+    int64_t* mine = (int64_t*)sg.get(sizeof(int64_t) * (size_t)len);
+    if (!all || !mine) return FR_OUT_OF_MEMORY;
+    FR_HIP(ctx, hipMemcpyAsync(mine, c->info, sizeof(int64_t) * (size_t)(3 + c->n), hipMemcpyDeviceToDevice, ctx->stream));
+    if (nblk > 0) {
+        if (c->cest)
+            FR_HIP(ctx, hipMemcpyAsync(mine + 3 + c->n, c->cest, sizeof(double) * (size_t)nblk, hipMemcpyDeviceToDevice, ctx->stream));
+        else
+            FR_HIP(ctx, hipMemsetAsync(mine + 3 + c->n, 0, sizeof(double) * (size_t)nblk, ctx->stream));
+    }
+    FR_TRY(comm_allgather_i64(ctx, mine, all, (size_t)len));
     std::vector<int64_t> host((size_t)(len * W));
     FR_HIP(ctx, hipMemcpyAsync(host.data(), all, sizeof(int64_t) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
     FR_TRY(comm_stream_sync(ctx, ctx->stream, "the merge of the substitution logs"));
     FR_TRY(check_status_word(ctx));  // a bounded device-side wait of the factorisation (hand-offs, counted tiles) gave up
     int64_t fail = -1;
     std::vector<int64_t> subst;
+    double max_cest = 0.0;
     for (int r = 0; r < W; ++r) {
         const int64_t* h = host.data() + (size_t)r * len;
         if (h[0] > 0 && (fail < 0 || h[0] - 1 < fail)) fail = h[0] - 1;
         for (int64_t i = 0; i < h[1] && i < c->n; ++i) subst.push_back(h[3 + i]);
+        for (int64_t b = 0; b < nblk; ++b) {
+            double v;
+            memcpy(&v, h + 3 + c->n + b, sizeof(double));
+            if (v > max_cest) max_cest = v;  // (NaN: a failed block, reported through fail_col)
+        }
     }
     std::sort(subst.begin(), subst.end());
     c->fail_col = fail;
     c->n_subst = (int64_t)subst.size();
     c->subst = subst;
+    c->max_cest = max_cest;
     return FR_OK;
 }
 
@@ -1335,11 +1390,13 @@ static int fetch_max_cest(fr_chol* c)
 static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise, int has_eps, double eps)
 {
     fr_ctx* ctx = c->ctx;
-    const bool sharded = ctx->world > 1;  // (the ranks would have to agree on the decision: not refined when sharded)
-    if (ctx->refine == 0 || sharded) c->refine = false;
-    if (ctx->refine == 1 && !sharded) c->refine = true;
+    // Sharded: the same policy.  The largest estimate is the maximum over every rank's blocks (merge_info), c->refine only
+    // ever changes as a function of it and of the (rank-uniform) options, so every rank decides alike; the repeat with
+    // refinement runs on the whole-panel schedule (potrf_blocked), whose owner solves its panel with the refined products.
+    if (ctx->refine == 0) c->refine = false;
+    if (ctx->refine == 1) c->refine = true;
     int st = assemble_and_factor_once(c, kernel, noise, has_eps, eps);
-    if (sharded || ctx->refine != -1 || (st != FR_OK && st != FR_NOT_POSITIVE_DEFINITE)) return st;
+    if (ctx->refine != -1 || (st != FR_OK && st != FR_NOT_POSITIVE_DEFINITE)) return st;
     const bool ill = c->max_cest > ctx->refine_threshold;
     if (!c->refine && ill) {
         c->refine = true;
@@ -1374,10 +1431,7 @@ static int assemble_and_factor_once(fr_chol* c, const fr_kprog* kernel, double n
     FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true));
     FR_TRY(chol_fetch_info(c));
     if (ctx->world > 1) {
-        // sharded: a rank holds the estimates of the blocks it factored only, and the ranks would have to agree on a
-        // repeat -- the refinement policy does not apply (assemble_and_factor), so no estimate is reported either
-        c->max_cest = 0.0;
-        FR_TRY(merge_info(c));
+        FR_TRY(merge_info(c));  // (also the largest conditioning estimate over every rank's blocks)
     } else {
         FR_TRY(fetch_max_cest(c));
     }
@@ -1602,12 +1656,43 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
             // N = 8192 / 32768, measured in round 4); the transposed problem  L21^T = L11^-1 K12  is a forward solve with nb_new
             // right-hand sides -- whatever trsm_lower_fwd picks for that count: the single-column kernel, K9, the 2048-row
             // leaves -- then one transposition into place
+            //
+            // Sharded: the nb_new right-hand sides -- the new rows -- are dealt to the ranks in equal
+            // slices; a rank assembles and solves its slice only (n_old^2 nb_new / W flop instead of all of them), ONE
+            // all-gather returns L21^T to everybody, and the rest -- transposition, the nb_new x nb_new Schur complement and its
+            // factorisation: 1 / (n_old / nb_new) of the work -- is repeated on every rank with the same deterministic kernels
+            // on the same data, so every rank ends with the bit-identical grown factor and no broadcast is needed.  The slice
+            // solves keep to the stream-ordered paths (no persistent kernel: a rank repeating ITS solve after a timed-out
+            // hand-off would issue the all-gather twice).
             WsGuard wg(ctx);
             const int64_t ldw = round_up(n_old, kAlign);
-            double* W = wg.get(sizeof(double) * (size_t)ldw * (size_t)nb_new);
+            const int Wn = ctx->world, me = ctx->rank;
+            const int64_t slice = Wn > 1 ? (nb_new + Wn - 1) / Wn : nb_new;
+            double* W = wg.get(sizeof(double) * (size_t)ldw * (size_t)(slice * Wn));
+            if (Wn > 1) {
+                bool all_ok = true;
+                FR_TRY(comm_agree(ctx, W != nullptr, &all_ok));
+                if (W && !all_ok) return set_err(ctx, FR_OUT_OF_MEMORY, "a peer rank could not allocate its add_rows workspace: append abandoned on every rank");
+            }
             if (!W) return FR_OUT_OF_MEMORY;
-            FR_TRY(launch_gram_cross(ctx, *kernel, c->X, n_old, c->ld_x, c->X + n_old, nb_new, c->ld_x, d, W, ldw));
-            FR_TRY(trsm_lower_fwd(ctx, c, n_old, W, nb_new, ldw, FR_PROF_GEMM_PANEL));
+            if (Wn > 1) {
+                const int64_t lo = imin(nb_new, (int64_t)me * slice), cols = imin(nb_new, lo + slice) - lo;
+                double* Ws = W + lo * ldw;
+                struct NoPersistent {
+                    fr_ctx* ctx;
+                    int64_t saved;
+                    ~NoPersistent() { ctx->trsv = saved; }
+                } np{ctx, ctx->trsv};
+                ctx->trsv = 0;
+                if (cols > 0) {
+                    FR_TRY(launch_gram_cross(ctx, *kernel, c->X, n_old, c->ld_x, c->X + n_old + lo, cols, c->ld_x, d, Ws, ldw));
+                    FR_TRY(trsm_lower_fwd(ctx, c, n_old, Ws, cols, ldw, FR_PROF_GEMM_PANEL));
+                }
+                FR_TRY(comm_allgather(ctx, W + (int64_t)me * slice * ldw, W, (size_t)(slice * ldw)));
+            } else {
+                FR_TRY(launch_gram_cross(ctx, *kernel, c->X, n_old, c->ld_x, c->X + n_old, nb_new, c->ld_x, d, W, ldw));
+                FR_TRY(trsm_lower_fwd(ctx, c, n_old, W, nb_new, ldw, FR_PROF_GEMM_PANEL));
+            }
             FR_TRY(launch_transpose(ctx, W, n_old, nb_new, ldw, A21, ld));
             FR_TRY(gemm(ctx, FR_PROF_SYRK, nb_new, nb_new, n_old, A21, ld, false, A21, ld, false, -1.0, 1.0, A22, ld, true));
         } else {
@@ -1651,7 +1736,7 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
             FR_HIP(ctx, hipMemcpyAsync(ctx->readback, c->info + 2, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
             FR_HIP(ctx, hipMemcpyAsync((double*)ctx->readback + 1, c->cest + b_lo, sizeof(double) * (size_t)(b_hi - b_lo), hipMemcpyDeviceToHost, ctx->stream));
         }
-        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FR_TRY(comm_stream_sync(ctx, ctx->stream, "add_rows"));  // (sharded: the stream holds an all-gather -- bounded wait)
         return check_status_word(ctx);
     };
     int st = solve_retry(ctx, append);
@@ -1664,13 +1749,28 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
         c->diag_zero = *(const int64_t*)ctx->readback != 0;
         c->diag_gen = c->gen;
     }
-    if (ctx->refine == -1 && ctx->world <= 1) {
+    if (ctx->refine == -1) {
         if (readback_ok) {
             const double* h = (const double*)ctx->readback + 1;
             for (int64_t b = 0; b < (n_all + IB - 1) / IB - n_old / IB; ++b)
                 if (h[b] > c->max_cest) c->max_cest = h[b];  // (the estimates of the old blocks are in max_cest already)
         } else {
             FR_TRY(fetch_max_cest(c));
+        }
+        if (ctx->world > 1) {
+            // every rank factored the same Schur complement and should hold the same estimates; the decision to repeat the
+            // append is a collective one all the same (a repeat issues the all-gather again), so it is taken on the maximum
+            // over the ranks, not on trust
+            if (!ctx->agree_buf) FR_HIP(ctx, hipMalloc((void**)&ctx->agree_buf, sizeof(int64_t) * 65));
+            double* ab = (double*)ctx->agree_buf;
+            FR_HIP(ctx, hipMemcpyAsync(ab, &c->max_cest, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            FR_TRY(comm_allgather(ctx, ab, ab + 1, 1));
+            if (ctx->world > 64) return set_err(ctx, FR_INVALID_ARGUMENT, "more than 64 ranks");
+            double hm[64];
+            FR_HIP(ctx, hipMemcpyAsync(hm, ab + 1, sizeof(double) * (size_t)ctx->world, hipMemcpyDeviceToHost, ctx->stream));
+            FR_TRY(comm_stream_sync(ctx, ctx->stream, "add_rows: agreement on the conditioning estimate"));
+            for (int r = 0; r < ctx->world; ++r)
+                if (hm[r] > c->max_cest) c->max_cest = hm[r];
         }
         if (!c->refine && c->max_cest > ctx->refine_threshold) {
             c->refine = true;  // an ill-conditioned appended block: once more with the refinement step behind every inverse product
@@ -1725,8 +1825,15 @@ static int solve_in_place(fr_chol* c, double* B, int64_t m, int64_t ldb, bool bo
 {
     fr_ctx* ctx = c->ctx;
     FR_HIP(ctx, hipSetDevice(ctx->device));
-    const bool persistent = ctx->trsv && !c->refine && c->n > 0 && m > 0 && (m == 1 || use_column_groups(ctx, c, c->n, m)) &&
-                            !(m > 1 && use_big_leaves(ctx, c, c->n, m, false) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max));
+    // The path is decided HERE, once: when the 2048-row leaves are predicted their inverse caches are built now (n / 2048 x 32 MiB per
+    // factor -- 512 MiB at N = 32768; option bigleaf_max = 0 switches the path off); if they cannot be, trsm_lower_fwd / bwd will fall
+    // through to a persistent kernel and the backup is taken (round-4 advisor finding: the fall-through used to run without one).
+    bool big = m > 1 && c->n > 0 && use_big_leaves(ctx, c, c->n, m, false) && !(ctx->narrow_batched_max > 0 && m <= ctx->narrow_batched_max);
+    if (big && !(ensure_inv512(ctx, c, FR_PROF_GEMM_SOLVE) == FR_OK && ensure_invbig(ctx, c, FR_PROF_GEMM_SOLVE) == FR_OK)) {
+        (void)hipGetLastError();
+        big = false;
+    }
+    const bool persistent = ctx->trsv && !c->refine && c->n > 0 && m > 0 && (m == 1 || use_column_groups(ctx, c, c->n, m)) && !big;
     WsGuard bk(ctx);
     double* backup = nullptr;
     if (persistent && is_device_ptr(B) && ldb >= c->n) {

@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -78,11 +79,16 @@ static int rccl_load(fr_ctx* ctx)
             return set_err((ctx), FR_RCCL_ERROR, "%s failed: %s", #call, g_rccl.GetErrorString(r__)); \
     } while (0)
 
-// inside a CallGuard named `guard`: no call on handles the watchdog has taken over
+// inside a CallGuard named `guard`: ownership of the handles passes to the RCCL call and back PER CALL (enter / leave are
+// compare-and-swaps on the watchdog's state word), so the watchdog can only abort while this thread is inside RCCL and this
+// thread never enters RCCL on handles the watchdog has taken
 #define FR_NCCL_G(ctx, call)                                                                                   \
     do {                                                                                                       \
-        if (guard.taken_over()) return set_err((ctx), FR_RCCL_ERROR, "communicators aborted by the watchdog"); \
-        FR_NCCL(ctx, call);                                                                                    \
+        if (!guard.enter()) return set_err((ctx), FR_RCCL_ERROR, "communicators aborted by the watchdog");     \
+        ncclResult_t r__ = (call);                                                                             \
+        if (!guard.leave()) return set_err((ctx), FR_RCCL_ERROR, "communicators aborted by the watchdog");     \
+        if (r__ != ncclSuccess)                                                                                \
+            return set_err((ctx), FR_RCCL_ERROR, "%s failed: %s", #call, g_rccl.GetErrorString(r__));          \
     } while (0)
 
 static inline int64_t now_ms()
@@ -97,12 +103,18 @@ static inline int64_t now_ms()
 //     (option "comm_timeout_ms"), aborts both communicators itself -- ncclCommAbort makes the pending kernels exit -- and
 //     returns FR_RCCL_ERROR.
 //   * on the HOST: a call into RCCL blocks (connection set-up with a peer that never calls).  The thread that is stuck
-//     cannot help itself, so every context with a communicator has a watchdog thread.  The host thread brackets each RCCL
-//     call with a sequence number (CallGuard); a call in progress for longer than the deadline is aborted from the
-//     watchdog -- the documented use of ncclCommAbort from a second thread.  Ownership of the communicators passes by a
-//     compare-and-swap on that sequence number: either the host thread leaves the call first (the watchdog's swap fails, it
-//     does nothing), or the watchdog wins and the host thread, when its call returns, waits for the abort to finish and never
-//     touches the handles again.
+//     cannot help itself, so every context with a communicator has a watchdog thread.  The state word `call` says who owns
+//     the handles:
+//         0                 no guarded sequence
+//         2 * seq           the host thread is inside a guarded sequence, BETWEEN two RCCL calls: it runs, the watchdog keeps off
+//         2 * seq + 1       the host thread is INSIDE an RCCL call (since call_t0)
+//         kWatchAborting    the watchdog has taken the handles
+//     The host thread moves 2 seq -> 2 seq + 1 (CallGuard::enter) and back (leave) with compare-and-swaps around EVERY single
+//     RCCL call; the watchdog moves 2 seq + 1 -> kWatchAborting, and only that: it aborts a call that has been in progress
+//     for longer than the deadline -- the documented use of ncclCommAbort from a second thread -- and nothing else, so a
+//     check-then-call window does not exist (round-4 advisor finding: the former single check in front of a call was not atomic
+//     with it).  The watchdog only READS ctx->comm / comm2 (they cannot change while the host thread is inside a call); the
+//     host thread, once its call returns and its leave() fails, waits for `aborted` and nulls them itself.
 // After either, the context is "lost" (every collective fails at once) until the host calls fr_ctx_comm_finalize and attaches
 // a new communicator; bench.py then falls back to a more conservative schedule (friedrich_amd/sharding.py: guarded_schedule).
 constexpr uint64_t kWatchAborting = ~uint64_t(0);
@@ -112,12 +124,13 @@ struct CommWatch {
     std::mutex m;
     std::condition_variable cv;
     bool stop = false;
-    std::atomic<uint64_t> call{0};  // sequence number of the RCCL host call in progress; 0: none; kWatchAborting: the watchdog took over
+    std::atomic<uint64_t> call{0};  // see above
     std::atomic<int64_t> call_t0{0};
     std::atomic<int> aborted{0};    // the watchdog has torn the communicators down
     uint64_t seq = 0;
 };
 
+// host thread only (never the watchdog): abort and forget both handles
 static void abort_handles(fr_ctx* ctx)
 {
     if (ctx->comm2 && g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)ctx->comm2);
@@ -134,11 +147,16 @@ static void watch_main(fr_ctx* ctx, CommWatch* w)
         if (w->stop) break;
         const uint64_t c = w->call.load();
         const int64_t T = ctx->comm_timeout_ms;
-        if (c == 0 || c == kWatchAborting || T <= 0) continue;
+        if (c == 0 || c == kWatchAborting || (c & 1) == 0 || T <= 0) continue;  // (only a call IN PROGRESS can be stuck)
         if (now_ms() - w->call_t0.load() < T) continue;
         uint64_t expect = c;
         if (!w->call.compare_exchange_strong(expect, kWatchAborting)) continue;  // the call returned in the meantime
-        abort_handles(ctx);  // (the host thread is inside RCCL and touches the handles no more: see CallGuard)
+        // the host thread is inside RCCL and, when it comes back, will find its leave() refused: the handles are ours to abort
+        // (read only: the host thread nulls them after `aborted`)
+        void* c2 = ctx->comm2;
+        void* c1 = ctx->comm;
+        if (c2 && g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)c2);
+        if (c1 && g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)c1);
         __atomic_fetch_add(&ctx->comm_timeouts, (int64_t)1, __ATOMIC_RELAXED);
         w->aborted.store(1);
     }
@@ -166,34 +184,123 @@ static void watch_stop(fr_ctx* ctx)
     ctx->watch = nullptr;
 }
 
-// Brackets the RCCL host calls of one collective.
+// Brackets the RCCL host calls of one collective (a grouped send / receive is several calls).
 struct CallGuard {
     fr_ctx* ctx;
     CommWatch* w;
-    uint64_t mine = 0;
+    uint64_t mine = 0;  // 2 * seq
+    bool lost = false;
     explicit CallGuard(fr_ctx* c) : ctx(c), w((CommWatch*)c->watch)
     {
         if (!w) return;
-        mine = ++w->seq;
-        w->call_t0.store(now_ms());
+        mine = 2 * ++w->seq;
         w->call.store(mine);
     }
-    // true once the watchdog has taken the communicators over: the handles must not be used any more (checked in front of
-    // every RCCL call of a guarded sequence -- a grouped send / receive is several calls)
-    bool taken_over() const { return w && w->call.load() == kWatchAborting; }
-    ~CallGuard()
+    // in front of one RCCL call; false: the watchdog has the handles, do not call
+    bool enter()
     {
-        if (!w) return;
+        if (!w) return true;
+        if (lost) return false;
+        w->call_t0.store(now_ms());
         uint64_t expect = mine;
-        if (w->call.compare_exchange_strong(expect, 0)) return;
-        // the watchdog decided this call was stuck and is tearing the communicators down (or has): wait for it, then mark
-        // the context; the handles are gone
+        if (w->call.compare_exchange_strong(expect, mine | 1)) return true;
+        take_note();
+        return false;
+    }
+    // behind it; false: the watchdog took the handles over while the call was in progress
+    bool leave()
+    {
+        if (!w) return true;
+        uint64_t expect = mine | 1;
+        if (w->call.compare_exchange_strong(expect, mine)) return true;
+        take_note();
+        return false;
+    }
+    bool taken_over() const { return lost; }
+    // the watchdog decided a call was stuck and is tearing the communicators down (or has): wait for it, then forget the
+    // handles (this thread is the only one that writes them) and mark the context
+    void take_note()
+    {
+        if (lost) return;
+        lost = true;
         while (!w->aborted.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        ctx->comm = ctx->comm2 = nullptr;
         ctx->comm_lost = true;
         set_err(ctx, FR_RCCL_ERROR, "an RCCL call did not return within %lld ms (dist_schedule %lld): communicators aborted by the watchdog",
                 (long long)ctx->comm_timeout_ms, (long long)ctx->dist_schedule);
     }
+    ~CallGuard()
+    {
+        if (!w || lost) return;
+        uint64_t expect = mine;
+        if (!w->call.compare_exchange_strong(expect, 0)) take_note();  // (cannot happen: the watchdog only takes 2 seq + 1)
+    }
 };
+
+// An RCCL group opened on this thread is closed on EVERY way out of the sequence (an error of one of the grouped calls used to
+// leave the thread's group depth above zero: the communicator created by the recovery path would then have been initialised
+// inside an open group).  After a take-over the handles are gone and ncclGroupEnd would walk operations queued on a freed
+// communicator, so it is skipped -- that needs a send / receive *enqueue* to block for the whole deadline first.
+struct GroupGuard {
+    CallGuard& guard;
+    bool open = false;
+    explicit GroupGuard(CallGuard& g) : guard(g) {}
+    ~GroupGuard()
+    {
+        if (!open || guard.taken_over()) return;
+        if (!guard.enter()) return;
+        (void)g_rccl.GroupEnd();
+        (void)guard.leave();
+    }
+};
+
+// ncclCommInitRank with a deadline.  The call is a rendezvous of all ranks and blocks until the last one arrives; the
+// communicator it is about to create does not exist yet, so no ncclCommAbort can reach it (round-4 advisor finding: the
+// watchdog could only abort the OTHER, healthy communicator).  It therefore runs on a helper thread and this thread waits for
+// it with the deadline (option "comm_timeout_ms"; 0: for ever).  Past the deadline the job is abandoned: the caller gets
+// ncclSystemError at once, and the helper, if RCCL ever lets it go, aborts the communicator it was handed and frees the job.
+struct InitJob {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    ncclComm_t comm = nullptr;
+    ncclResult_t res = ncclSystemError;
+};
+
+static ncclResult_t init_rank_bounded(fr_ctx* ctx, ncclComm_t* out, int world, const ncclUniqueId& id, int rank, bool* timed_out)
+{
+    *out = nullptr;
+    *timed_out = false;
+    auto job = std::make_shared<InitJob>();
+    const int device = ctx->device;
+    std::thread([job, device, world, id, rank] {
+        ncclComm_t c = nullptr;
+        ncclResult_t r = hipSetDevice(device) == hipSuccess ? g_rccl.CommInitRank(&c, world, id, rank) : ncclUnhandledCudaError;
+        std::lock_guard<std::mutex> lk(job->m);
+        if (job->abandoned) {
+            if (r == ncclSuccess && c && g_rccl.CommAbort) (void)g_rccl.CommAbort(c);
+            return;
+        }
+        job->comm = r == ncclSuccess ? c : nullptr;
+        job->res = r;
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->m);
+    const int64_t T = ctx->comm_timeout_ms;
+    if (T > 0) {
+        if (!job->cv.wait_for(lk, std::chrono::milliseconds(T), [&] { return job->done; })) {
+            job->abandoned = true;
+            *timed_out = true;
+            __atomic_fetch_add(&ctx->comm_timeouts, (int64_t)1, __ATOMIC_RELAXED);
+            return ncclSystemError;
+        }
+    } else {
+        job->cv.wait(lk, [&] { return job->done; });
+    }
+    *out = job->comm;
+    return job->res;
+}
 
 // ---- test hook: one rank goes missing ------------------------------------------------------------------------
 // FRIEDRICH_AMD_TEST_COMM_HANG = "schedule,rank,nth": while the context runs dist_schedule `schedule`, rank `rank` does not take
@@ -381,7 +488,9 @@ int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root, int 
     if (ctx->local) return local_scatter(ctx, (char*)buf, 8 * count_per_rank, root);
     ncclComm_t comm = pick_comm(ctx, which);
     CallGuard guard(ctx);
+    GroupGuard group(guard);
     FR_NCCL_G(ctx, g_rccl.GroupStart());
+    group.open = true;
     if (ctx->rank == root) {
         for (int r = 0; r < ctx->world; ++r)
             if (r != root)
@@ -389,6 +498,7 @@ int comm_scatter(fr_ctx* ctx, double* buf, size_t count_per_rank, int root, int 
     } else {
         FR_NCCL_G(ctx, g_rccl.Recv(buf + (size_t)ctx->rank * count_per_rank, count_per_rank, ncclDouble, root, comm, ctx->ls));
     }
+    group.open = false;  // (ncclGroupEnd closes the group whatever it returns)
     FR_NCCL_G(ctx, g_rccl.GroupEnd());
     return FR_OK;
 }
@@ -404,13 +514,16 @@ int comm_fanout(fr_ctx* ctx, double* buf, size_t count, int root, int which)
     if (ctx->local) return local_bcast(ctx, buf, 8 * count, root);
     ncclComm_t comm = pick_comm(ctx, which);
     CallGuard guard(ctx);
+    GroupGuard group(guard);
     FR_NCCL_G(ctx, g_rccl.GroupStart());
+    group.open = true;
     if (ctx->rank == root) {
         for (int r = 0; r < ctx->world; ++r)
             if (r != root) FR_NCCL_G(ctx, g_rccl.Send(buf, count, ncclDouble, r, comm, ctx->ls));
     } else {
         FR_NCCL_G(ctx, g_rccl.Recv(buf, count, ncclDouble, root, comm, ctx->ls));
     }
+    group.open = false;  // (ncclGroupEnd closes the group whatever it returns)
     FR_NCCL_G(ctx, g_rccl.GroupEnd());
     return FR_OK;
 }
@@ -422,7 +535,7 @@ int comm_bcast(fr_ctx* ctx, double* buf, size_t count, int root)
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count);
     if (ctx->local) return local_bcast(ctx, buf, 8 * count, root);
     CallGuard guard(ctx);
-    FR_NCCL(ctx, g_rccl.Broadcast(buf, buf, count, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->ls));
+    FR_NCCL_G(ctx, g_rccl.Broadcast(buf, buf, count, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
 
@@ -436,7 +549,7 @@ int comm_allgather_i64(fr_ctx* ctx, const int64_t* send, int64_t* recv, size_t c
     COMM_ENTER(ctx);
     if (ctx->local) return local_allgather(ctx, send, recv, 8 * count_per_rank);
     CallGuard guard(ctx);
-    FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclInt64, (ncclComm_t)ctx->comm, ctx->ls));
+    FR_NCCL_G(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclInt64, (ncclComm_t)ctx->comm, ctx->ls));
     return FR_OK;
 }
 
@@ -451,7 +564,8 @@ int comm_allgather(fr_ctx* ctx, const double* send, double* recv, size_t count_p
     ProfScope ps(ctx, FR_PROF_COMM, 0.0, 8.0 * (double)count_per_rank * ctx->world);
     if (ctx->local) return local_allgather(ctx, send, recv, 8 * count_per_rank);
     CallGuard guard(ctx);
-    FR_NCCL(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, pick_comm(ctx, which), ctx->ls));
+    ncclComm_t comm = pick_comm(ctx, which);
+    FR_NCCL_G(ctx, g_rccl.AllGather(send, recv, count_per_rank, ncclDouble, comm, ctx->ls));
     return FR_OK;
 }
 
@@ -550,9 +664,11 @@ void comm_abort(fr_ctx* ctx)
 
 // Second communicator over the same ranks (bulk stream of the chain-first schedule), created on first use: its id is drawn
 // by rank 0 and travels over the first communicator.  Collective: every rank of the first communicator calls it at the same
-// point of its host program (the start of a schedule-2 factorisation / the self-test), and every rank takes part in the
-// broadcast and the CommInitRank whatever happened locally before -- a zeroed id tells the peers that rank 0 could not draw
-// one -- so that no rank is left waiting; the ranks then agree on the outcome.
+// point of its host program (the start of a schedule-2 factorisation / the self-test).  A zeroed id tells the peers that rank
+// 0 could not draw one; a rank whose hand-over fails locally (RCCL error, time-out: its context is lost and its first
+// communicator aborted) leaves, and its peers' ncclCommInitRank -- which has a deadline of its own, init_rank_bounded -- or
+// their status agreement on the first communicator ends in FR_RCCL_ERROR instead of waiting for it.  No way out of this
+// function leaves a half-made communicator behind.
 int ensure_comm2(fr_ctx* ctx)
 {
     if (ctx->world <= 1 || ctx->local || ctx->comm2) return FR_OK;
@@ -567,27 +683,30 @@ int ensure_comm2(fr_ctx* ctx)
     FR_HIP(ctx, hipMemcpyAsync(d, &id2, sizeof(id2), hipMemcpyHostToDevice, s));
     {
         CallGuard guard(ctx);
-        FR_NCCL(ctx, g_rccl.Broadcast(d, d, sizeof(id2), ncclChar, 0, (ncclComm_t)ctx->comm, s));
+        FR_NCCL_G(ctx, g_rccl.Broadcast(d, d, sizeof(id2), ncclChar, 0, (ncclComm_t)ctx->comm, s));
     }
     FR_HIP(ctx, hipMemcpyAsync(&id2, d, sizeof(id2), hipMemcpyDeviceToHost, s));
     FR_TRY(comm_stream_sync(ctx, s, "hand-over of the second communicator's id"));
     bool id_ok = false;
     for (size_t i = 0; i < sizeof(id2); ++i) id_ok = id_ok || ((const char*)&id2)[i] != 0;
     ncclComm_t comm2 = nullptr;
-    bool ok = id_ok;
-    if (id_ok) {
-        CallGuard guard(ctx);
-        ok = g_rccl.CommInitRank(&comm2, ctx->world, id2, ctx->rank) == ncclSuccess;
+    bool ok = id_ok, timed_out = false;
+    if (id_ok) ok = init_rank_bounded(ctx, &comm2, ctx->world, id2, ctx->rank, &timed_out) == ncclSuccess;
+    if (timed_out) {
+        // a peer never arrived: the first communicator may be healthy, but the ranks no longer agree on what comes next
+        comm_abort(ctx);
+        return set_err(ctx, FR_RCCL_ERROR, "creation of the second communicator did not finish within %lld ms (rank %d of %d): communicators aborted",
+                       (long long)ctx->comm_timeout_ms, ctx->rank, ctx->world);
     }
-    if (ctx->comm_lost) return FR_RCCL_ERROR;
     bool all_ok = false;
     hipStream_t saved = ctx->ls;
     ctx->ls = s;
     const int st = comm_agree(ctx, ok, &all_ok);
     ctx->ls = saved;
-    if (st != FR_OK || !all_ok) {
+    if (st != FR_OK || !all_ok || ctx->comm_lost) {
         if (comm2) (void)g_rccl.CommAbort(comm2);
         if (st != FR_OK) return st;
+        if (ctx->comm_lost) return FR_RCCL_ERROR;
         return set_err(ctx, FR_RCCL_ERROR, id_ok ? "a rank could not create the second communicator" : "rank 0 could not draw an id for the second communicator");
     }
     ctx->comm2 = comm2;
@@ -687,7 +806,12 @@ int fr_ctx_comm_init(fr_ctx* ctx, int rank, int world_size, const void* unique_i
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclComm_t comm = nullptr;
-    FR_NCCL(ctx, g_rccl.CommInitRank(&comm, world_size, id, rank));
+    bool timed_out = false;
+    const ncclResult_t ir = init_rank_bounded(ctx, &comm, world_size, id, rank, &timed_out);
+    if (timed_out)
+        return set_err(ctx, FR_RCCL_ERROR, "ncclCommInitRank did not finish within %lld ms (rank %d of %d): a peer never arrived", (long long)ctx->comm_timeout_ms,
+                       rank, world_size);
+    if (ir != ncclSuccess) return set_err(ctx, FR_RCCL_ERROR, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(ir));
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->world = world_size;

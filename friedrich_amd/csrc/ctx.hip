@@ -537,6 +537,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->xcd_reserve = value;
         return FR_OK;
     }
+    if (!strcmp(name, "k4_flat")) {
+        if (value < -1 || value > 1) return set_err(ctx, FR_INVALID_ARGUMENT, "k4_flat must be -1 (automatic), 0 or 1");
+        ctx->k4_flat = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "dist_schedule")) {
         if (value < 0 || value > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "dist_schedule must be 0 (broadcast), 1 (split) or 2 (diagonal chain first)");
         ctx->dist_schedule = value;
@@ -577,6 +582,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     }
     if (!strcmp(name, "trsv")) {
         ctx->trsv = value != 0;
+        return FR_OK;
+    }
+    if (!strcmp(name, "grad_shard_min")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "grad_shard_min must be >= 0");
+        ctx->grad_shard_min = value;
         return FR_OK;
     }
     if (!strcmp(name, "tri_inverse")) {

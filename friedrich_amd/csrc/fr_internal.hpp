@@ -86,6 +86,7 @@ struct fr_ctx {
     int64_t bigleaf_max = -1;   // solves with at most this many right-hand sides (and >= 4096 rows) run left-looking over 2048-row blocks
                                 // with explicit 2048-block inverses (chol.hip: trsm_big); -1: 4096; 0: never
     int64_t trsv = 1;           // solves with few right-hand sides as one persistent launch per direction (trsv.hip, trsm_narrow.hip)
+    int64_t grad_shard_min = 4096;  // sharded contexts: gradient terms of factors with at least this many rows are split over the ranks (grad.hip)
     int64_t tri_inverse = 1;    // gradient terms: L^-1 and W^T W skip the structural zeros (chol_tri_inverse); 0: dense products
     int64_t predict_assoc = 0;  // 0: (K^-1 K*)^T y as the reference, 1: K*^T (K^-1 y)
     // Products with explicit inverse blocks lose a factor cond(L_bb) of backward accuracy against substitution.  refine:
@@ -109,6 +110,7 @@ struct fr_ctx {
     int64_t prof_launches[FR_PROF_COUNT] = {0};
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
+    int64_t k4_flat = -1;          // diagonal-block kernel: -1 = flat variant wherever the kernel has its CU to itself (potf2.hip), 0 = never, 1 = every full block
     bool k4_alone = false;         // the running factorisation has no second stream: nothing shares the diagonal-block kernel's CU
     int reserve_now = 0;           // XCDs reserved right now (set by the factorisation around the launches it applies to)
     unsigned panel_epoch = 0;      // number of the panel being factored on the panel stream (see claim_item)
@@ -449,6 +451,8 @@ int trsm_lower_fwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t 
 int trsm_lower_bwd(fr_ctx* ctx, const fr_chol* c, int64_t n, double* B, int64_t m, int64_t ldb, int prof_cls);
 // W (n x n, leading dimension ldw) <- L^-1, strict upper triangle exactly zero; T: scratch of at least (n / 2 + 512)^2 doubles
 int chol_tri_inverse(fr_ctx* ctx, const fr_chol* c, double* W, int64_t ldw, double* T, int prof_cls);
+// B (k1 x m) <- L11^-T B with L11 the LEADING k1 x k1 block of the factor (k1 a multiple of 512, or the whole factor); stream-ordered paths only
+int trsm_lower_bwd_leading(fr_ctx* ctx, const fr_chol* c, int64_t k1, double* B, int64_t m, int64_t ldb, int prof_cls);
 int chol_alloc(fr_ctx* ctx, int64_t n, int64_t capacity, int64_t d, fr_chol** out);
 int chol_fetch_info(fr_chol* c);
 

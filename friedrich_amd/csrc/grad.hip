@@ -13,6 +13,7 @@
 //     `gradient` bodies (file:line at each case), including the reference's quirks (Matern2 grad_ls as written,
 //     Multiquadric declaring 2 parameters but yielding 1 gradient).
 #include "fr_internal.hpp"
+#include <vector>
 #include "kprog_device.hpp"
 
 namespace fr {
@@ -137,6 +138,7 @@ struct GradArgs {
     const double* Kinv;
     int64_t ldk;
     double inv_scale;  // 1/scale (scaled variant) or 1
+    double alpha_w;    // weight of the alpha_i alpha_j term: 1; sharded: 1 on rank 0, 0 elsewhere (Kinv is then a rank's PARTIAL of K^-1)
     int ng;
     double* partials;  // [nblocks][ng]
 };
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void grad_reduce_kernel(const GradArgs a)
                 (void)leaf_grad_k<LEAF>(a.prog.ops[0], s[h][b], u[h][b], gv);
                 const double kinv = in ? a.Kinv[gi + gj * a.ldk] : 0.0;
                 const double w = (gi == gj) ? 1.0 : 2.0;
-                const double coef = w * (ai[h] * aj * a.inv_scale - kinv);
+                const double coef = w * (ai[h] * aj * a.inv_scale * a.alpha_w - kinv);
 #pragma unroll
                 for (int q = 0; q < NG; ++q)
                     if (in) acc[q] += coef * gv[q];
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void grad_reduce_kernel(const GradArgs a)
                     double gv[MAXG];
                     const int ng = kprog_grad(a.prog, s[h][0], u[h][0], gv);
                     const double w = (gi == gj) ? 1.0 : 2.0;
-                    const double coef = w * (ai[h] * a.alpha[gj] * a.inv_scale - a.Kinv[gi + gj * a.ldk]);
+                    const double coef = w * (ai[h] * a.alpha[gj] * a.inv_scale * a.alpha_w - a.Kinv[gi + gj * a.ldk]);
 #pragma unroll
                     for (int q = 0; q < MAXG; ++q)
                         if (q < ng) acc[q] += coef * gv[q];
@@ -346,13 +348,48 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
     }
     if (!y) return set_err(ctx, FR_INVALID_ARGUMENT, "null training-output vector (y)");
     const int64_t ld = round_up(n, kAlign);
+    // Sharded: K^-1 = W^T W = sum over the ROWS k of W = L^-1 of the outer products w_k w_k^T, and every
+    // term of the gradient that involves K^-1 -- tr(K^-1 G_q), tr(K^-1) -- is linear in it.  So the rows of W are dealt to the
+    // ranks in chunks; a rank forms the rows of its chunks (W(K, :)^T = the backward solve  L11^T X = [0; I]  on the leading
+    // block that ends with chunk K: the rows of W are zero to the right of their diagonal), accumulates its PARTIAL
+    // K^-1 = sum_K X X^T, runs the fused reductions on it (the alpha alpha^T term is counted on rank 0 only), and one all-gather
+    // of ng + 2 scalars per rank, summed in rank order on every rank, finishes the job: no matrix ever travels.  Chunks are dealt
+    // in a snake over DESCENDING row ranges (the cost of a chunk grows with the square of where it ends).  Ill-conditioned
+    // (refined) handles and small factors: every rank computes the whole, no collective.
+    const int Wn = ctx->world, me = ctx->rank;
+    const bool sharded = Wn > 1 && n >= ctx->grad_shard_min && n >= 1024 && !c->refine;
+    const int64_t cs = n >= 8192 ? 2048 : 512;  // rows per chunk
     WsGuard wg(ctx), kg(ctx), vg(ctx), pg(ctx);
-    double* W = wg.get(sizeof(double) * (size_t)ld * (size_t)n);
+    double* W = wg.get(sizeof(double) * (size_t)ld * (size_t)(sharded ? cs : n));
     double* Kinv = kg.get(sizeof(double) * (size_t)ld * (size_t)n);
-    double* vec = vg.get(sizeof(double) * (size_t)(ld + MAXG + 8));
+    double* vec = vg.get(sizeof(double) * (size_t)(ld + (MAXG + 8) * 66));
+    if (sharded) {
+        bool all_ok = true;
+        FR_TRY(comm_agree(ctx, W && Kinv && vec, &all_ok));
+        if (W && Kinv && vec && !all_ok) return set_err(ctx, FR_OUT_OF_MEMORY, "a peer rank could not allocate its gradient workspace");
+    }
     if (!W || !Kinv || !vec) return FR_OUT_OF_MEMORY;
     double* alpha = vec;
-    double* outs = vec + ld;  // [ng] gradient halves, trace, alpha.alpha, y.alpha
+    double* outs = vec + ld;  // [ng] gradient halves, trace, alpha.alpha, y.alpha; sharded: followed by every rank's ng + 2
+    if (sharded) {
+        const int64_t nc = (n + cs - 1) / cs;
+        FR_HIP(ctx, hipMemsetAsync(Kinv, 0, sizeof(double) * (size_t)ld * (size_t)n, ctx->ls));
+        for (int64_t t = 0; t < nc; ++t) {  // t-th largest chunk
+            const int owner = (int)(((t / Wn) & 1) ? (Wn - 1 - t % Wn) : (t % Wn));
+            if (owner != me) continue;
+            const int64_t j = nc - 1 - t, k0 = j * cs, k1 = (k0 + cs < n) ? k0 + cs : n, m = k1 - k0;
+            if (k0 > 0) FR_TRY(launch_fill(ctx, W, k0, m, ld, 0.0));
+            FR_TRY(launch_set_identity(ctx, W + k0, m, ld));
+            FR_TRY(trsm_lower_bwd_leading(ctx, c, k1, W, m, ld, FR_PROF_GEMM_SOLVE));
+            GemmDesc g;
+            g.M = k1; g.N = k1; g.K = m;
+            g.A = W; g.lda = ld; g.a_kmajor = false;
+            g.B = W; g.ldb = ld; g.b_kmajor = false;
+            g.Cin = Kinv; g.ldcin = ld; g.D = Kinv; g.ldd = ld;
+            g.alpha = 1.0; g.beta = 1.0; g.lower = true; g.prof_cls = FR_PROF_GEMM_SOLVE;
+            FR_TRY(launch_gemm(ctx, g));
+        }
+    } else {
     // K8: W = L^-1 (strict upper triangle of W is exactly zero), Kinv = W^T W (lower triangle)
     FR_TRY(chol_tri_inverse(ctx, c, W, ld, Kinv, FR_PROF_GEMM_SOLVE));  // (Kinv's buffer is the scratch: it is written next)
     {
@@ -366,6 +403,7 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
         g.Cin = Kinv; g.ldcin = ld; g.D = Kinv; g.ldd = ld;
         g.alpha = 1.0; g.beta = 0.0; g.lower = true; g.prof_cls = FR_PROF_GEMM_SOLVE;
         FR_TRY(launch_gemm(ctx, g));
+    }
     }
     // alpha = K^-1 y (optimizer.rs:33, 171)
     {
@@ -397,6 +435,7 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
     a.X = c->X; a.n = n; a.ldx = c->ld_x; a.d = c->d;
     a.alpha = alpha; a.Kinv = Kinv; a.ldk = ld;
     a.inv_scale = scaled ? 1.0 / scale : 1.0;
+    a.alpha_w = (sharded && me != 0) ? 0.0 : 1.0;
     a.ng = ng;
     a.partials = partials;
     {
@@ -431,8 +470,24 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
         FR_HIP(ctx, hipGetLastError());
     }
     double h[MAXG + 2];
-    FR_HIP(ctx, hipMemcpyAsync(h, outs, sizeof(double) * (size_t)(ng + 2), hipMemcpyDeviceToHost, ctx->stream));
-    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (sharded) {
+        // every rank's partials, summed in rank order (the same bits on every rank); alpha . alpha is rank 0's
+        if (Wn > 64) return set_err(ctx, FR_INVALID_ARGUMENT, "more than 64 ranks");
+        const size_t cnt = (size_t)(ng + 2);
+        double* all = outs + (MAXG + 8);
+        FR_TRY(comm_allgather(ctx, outs, all, cnt));
+        std::vector<double> hh(cnt * (size_t)Wn);
+        FR_HIP(ctx, hipMemcpyAsync(hh.data(), all, sizeof(double) * hh.size(), hipMemcpyDeviceToHost, ctx->stream));
+        FR_TRY(comm_stream_sync(ctx, ctx->stream, "the all-gather of the gradient partials"));
+        for (size_t q = 0; q < cnt; ++q) {
+            h[q] = 0.0;
+            for (int r = 0; r < Wn; ++r) h[q] += hh[(size_t)r * cnt + q];
+        }
+        h[ng + 1] = hh[(size_t)ng + 1];
+    } else {
+        FR_HIP(ctx, hipMemcpyAsync(h, outs, sizeof(double) * (size_t)(ng + 2), hipMemcpyDeviceToHost, ctx->stream));
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // one entry per DECLARED parameter: the reference allocates nb_parameters() matrices and zips them POSITIONALLY with
     // the gradient vector (algebra/mod.rs:135-151), so trailing entries without a value stay NaN (Multiquadric)
     for (int q = 0; q < np; ++q) out_grad[q] = (q < ng) ? h[q] : std::nan("");

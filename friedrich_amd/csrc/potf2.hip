@@ -1496,7 +1496,7 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
     const bool uncapped = force >= 0 ? force == 1 : (ctx->reserve_now > 0 || ctx->world > 1 || ctx->k4_alone);
     // the flat kernel: full blocks with their inverse, wherever the diagonal-block kernel has its CU to itself
     const bool flat_ok = nbk == PB && mode != 3 && inv != nullptr;
-    const bool use_flat = flat_ok && (force_flat >= 0 ? force_flat == 1 : uncapped);
+    const bool use_flat = flat_ok && (force_flat >= 0 ? force_flat == 1 : (ctx->k4_flat >= 0 ? ctx->k4_flat == 1 : uncapped));
     ProfScope ps(ctx, FR_PROF_POTF2, (double)nbk * nbk * nbk * (2.0 / 3.0), (double)nbk * nbk * 8.0 * 3.0);
     if (use_flat)
         hipLaunchKernelGGL(potf2_flat_kernel, dim3(1), dim3(PT), flat::LDS_BYTES, ctx->ls, A, lda, (int)nbk, col0, mode, sub, inv, ldinv, info,

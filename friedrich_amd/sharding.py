@@ -126,7 +126,11 @@ class ThreadLink:
         return out
 
     def barrier(self):
-        self.shared.barrier.wait(timeout=900)
+        self.gather(None)  # (every rendezvous of the control plane is the SAME primitive: see agree)
+
+    def abort(self):
+        """this rank is about to die of an exception: peers waiting in a rendezvous fail at once instead of timing out"""
+        self.shared.barrier.abort()
 
     def attach(self, ctx):
         """collective: a fresh communicator on every rank's context"""
@@ -147,7 +151,10 @@ class TorchLink:
         return out
 
     def barrier(self):
-        self.dist.barrier(group=self.ctl)
+        self.gather(None)  # (every rendezvous of the control plane is the SAME primitive: see agree)
+
+    def abort(self):
+        pass  # (a process-rank that dies takes the job down: torch.distributed.run ends its peers)
 
     def attach(self, ctx):
         ids = [ctx.comm_unique_id() if self.rank == 0 else None]
@@ -164,6 +171,9 @@ class SoloLink:
         return [obj]
 
     def barrier(self):
+        pass
+
+    def abort(self):
         pass
 
     def attach(self, ctx):
@@ -195,13 +205,29 @@ def preflight_fit(ctx, ref_ctx, n=4096, d=8, tol=1e-11):
     return None
 
 
+class PeerFailure(RuntimeError):
+    """raised by sync_point on a healthy rank: a peer reported a failure in the same rendezvous"""
+
+
 def agree(link, ok, why=None):
-    """-> (every rank ok?, the first failing rank's reason)"""
+    """-> (every rank ok?, the first failing rank's reason).  EVERY rendezvous of the control plane -- this one, sync_point,
+    link.barrier -- is one link.gather, so a rank that fails early and reports it here meets its peers wherever they are (in a
+    sync_point of the measurement, in their own agree behind it): the ranks can never sit in two different collectives of
+    the out-of-band link (round-4 advisor finding: barrier against all_gather_object).  A plain barrier contributes None = ok."""
     flags = link.gather((bool(ok), why))
-    bad = [(r, w) for r, (o, w) in enumerate(flags) if not o]
+    bad = [(r, f[1]) for r, f in enumerate(flags) if f is not None and not f[0]]
     if not bad:
         return True, None
     return False, f"rank {bad[0][0]}: {bad[0][1]}"
+
+
+def sync_point(link):
+    """rendezvous inside a guarded measurement: returns when every rank is here, raises PeerFailure when one of them reported
+    a failure instead (it is in `agree` after catching its error) -- the caller then goes to the fall-back WITHOUT another
+    agree: this rendezvous was it"""
+    ok, why = agree(link, True)
+    if not ok:
+        raise PeerFailure(why)
 
 
 def reattach(ctx, link):
@@ -238,6 +264,9 @@ def guarded_schedule(ctx, link, preflight, schedules=(2, 1, 0), timeout_ms=20000
             ok = why is None
         except FriedrichError as e:
             ok, why = False, str(e)
+        except BaseException:
+            link.abort()  # (not a library error: this rank is going down; do not leave the peers in a 10-minute wait)
+            raise
         took[s] = 1e3 * (time.perf_counter() - t0)
         ok, why = agree(link, ok, why)
         if ok:

@@ -96,13 +96,18 @@ void fr_ctx_destroy(fr_ctx* ctx);
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
-/* Tunables (17 names; everything else the library decides from the problem size):
+/* Tunables (19 names; everything else the library decides from the problem size):
  *   "nb"             outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
  *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
  *   "xcd_reserve"    -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
  *                    the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, 4 below 4096, nb <= 512 only: DESIGN.md
  *                    section 5); 0: never; 1..4: that many XCDs for the whole factorisation
+ *   "k4_flat"        -1 (default): full 128 x 128 diagonal blocks are factored by the flat variant of the diagonal-block kernel
+ *                    (one row per lane, rank-4 MFMA updates: potf2.hip) wherever that kernel has its CU to itself -- XCDs set aside,
+ *                    no second stream, sharded chain -- and by the staged variant that fits beside a GEMM workgroup elsewhere; 0 / 1:
+ *                    one variant throughout.  The two round differently (both within the parity tolerance): a factor is a
+ *                    function of the input AND of the options that select kernels
  *   "dist_schedule"  sharded (multi-GPU) factorisation, how a panel step travels: 0 = the owner solves the whole panel, one
  *                    broadcast; 1 (default) = diagonal block broadcast, rows below scattered / solved per rank / all-gathered;
  *                    2 = as 1 with the chain of diagonal blocks running ahead of the bulk rows on a second communicator
@@ -123,6 +128,9 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "trsv"           1 (default): solves with few right-hand sides run as one persistent launch per direction; 0: the
  *                    recursive GEMM / matrix-vector path (what a solve falls back to after a timed-out hand-off)
  *   "tri_inverse"    1 (default): the gradient terms form L^-1 and K^-1 = W^T W skipping the structural zeros
+ *   "grad_shard_min" 4096 (default): with a communicator attached, fr_grad_terms of a factor with at least this many rows is split
+ *                    over the ranks (row blocks of L^-1 per rank, partial K^-1 and partial reductions, one all-gather of p + 2
+ *                    scalars); below, every rank computes the whole.  Every rank must use the same value.
  *   "refine"         -1 (default): automatic -- see fr_chol_conditioning; 0: never; 1: always.  "refine_threshold": 30
  *   "predict_assoc"  0 (default): predict as the reference associates it, prior + (K^-1 K*)^T y  (mod.rs:234-241,
  *                    two n x m triangular solves);  1: prior + K*^T (K^-1 y), the same value up to rounding with two
@@ -228,7 +236,8 @@ int fr_chol_add_rows(fr_chol* chol, const fr_kprog* kernel, const double* Xall, 
 int fr_chol_info(const fr_chol* chol, int64_t* n, int64_t* capacity, int64_t* d, int64_t* n_subst,
                  int64_t* fail_col);
 /* Conditioning report of the factor as it stands (refreshed by every way a factor comes into being or changes: from_inputs,
- * refactor, from_matrix, upload_l, add_rows; not available -- 0 -- for sharded factors): *max_estimate = the largest estimate max|W_ij| * max L_jj over the
+ * refactor, from_matrix, upload_l, add_rows; sharded factors: the maximum over every rank's blocks, the same on every rank, so the
+ * ranks take the same refinement decision): *max_estimate = the largest estimate max|W_ij| * max L_jj over the
  * 128 x 128 diagonal blocks (W = explicit inverse of the block), *refined = 1 when the handle applies a step of iterative
  * refinement behind every product with an inverse block (option "refine": -1 automatic, the default: on when an estimate
  * exceeds "refine_threshold", 30).  No reference counterpart: nalgebra substitutes, which needs no such step. */

@@ -1,0 +1,228 @@
+"""SURVEY.md section 8e, the sub-bullets the round-4 verdict listed as missing -- exercised with thread-ranks on ONE GPU over the
+in-process transport (same sharded code as over RCCL):
+
+  * the refinement decision of an ill-conditioned fit is taken on the maximum conditioning estimate over EVERY rank's diagonal
+    blocks (it rides on the all-gather that merges the substitution logs), so a sharded fit returns the oracle's pivot list where
+    an unrefined one substituted hundreds of pivots (reference: src/algebra/mod.rs:81-86);
+  * add_samples: the new rows are dealt to the ranks, each solves its slice of L21^T, one all-gather (src/algebra/mod.rs:97-126);
+  * the gradient terms: row blocks of L^-1 per rank, partial K^-1, partial reductions, one all-gather of p + 2 scalars
+    (src/gaussian_process/optimizer.rs:32, 169).
+"""
+import numpy as np
+import pytest
+
+from conftest import rand_inputs, rel_err
+from oracle import oracle as O
+from test_gpu_dist import run_ranks
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+# ---- (a) the ranks agree on the refinement decision -------------------------------------------------------------------------
+@pytest.mark.parametrize("schedule", [0, 1, 2], ids=["bcast", "split", "chain"])
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("noise", [1e-5, 1e-6])
+def test_sharded_ill_conditioned_fit_returns_the_oracles_pivots(world, noise, schedule):
+    """The fixture of test_conditioning_sweep_rbf_d1 (RBF, d = 1, length scale 0.05, 1024 sorted points): at noise 1e-6 the
+    unrefined explicit-inverse products drove a Schur complement negative -- 896 substituted pivots where the oracle has none
+     -- which is what a sharded fit returned while refinement was switched off for it."""
+    n, d = 1024, 1
+    rng = np.random.default_rng(7)
+    X = np.asfortranarray(np.sort(rng.random((n, d)), axis=0))
+    k = ("squared_exp", 0.05, 1.0)
+    eps = 1e-2 * noise * noise
+    st, L_o, idx_o = O.make_cholesky_cov_matrix(k, X, noise, eps)
+    assert st == 0 and len(idx_o) == 0
+    L_o = np.tril(L_o)
+    K = O.make_covariance_matrix(k, X, X) + noise * noise * np.eye(n)
+    ku = np.linalg.cond(K) * 2.2e-16
+    B = np.asfortranarray(rng.standard_normal((n, 3)))
+    Z_o = O.chol_solve(L_o, B)
+
+    def fn(ctx, rank):
+        ctx.set_option("nb", 128)  # eight panels: every rank owns diagonal blocks, none owns all of them
+        ctx.set_option("dist_schedule", schedule)
+        chol = ctx.cholesky_from_inputs(k, X, noise, eps=eps, allow_failure=True)
+        out = [chol.info(), chol.conditioning(), chol.substitutions().tolist(), chol.l(), chol.solve(B)]
+        chol.refactor(k, noise, eps=eps, allow_failure=True)  # (the handle keeps refining: one factorisation this time)
+        out += [chol.info(), chol.conditioning(), chol.l()]
+        chol.free()
+        return out
+
+    res = run_ranks(world, fn)
+    est0 = res[0][1][0]
+    for info, (est, refined), idx, L, Z, info2, (est2, refined2), L2 in res:
+        assert info["fail_col"] == -1 and info["n_subst"] == 0 and idx == idx_o.tolist(), (info, est)
+        assert refined and est > 30.0 and est == est0  # the same estimate on every rank -> the same decision
+        assert rel_err(L, L_o) < max(1e-9, 0.1 * ku)
+        assert rel_err(Z, Z_o) < max(1e-9, 2.0 * ku)
+        assert info2["fail_col"] == -1 and info2["n_subst"] == 0 and refined2
+        assert rel_err(L2, L_o) < max(1e-9, 0.1 * ku)
+    for r in res[1:]:
+        assert np.array_equal(r[3], res[0][3])  # every rank holds the same factor, bit for bit
+
+
+def test_sharded_well_conditioned_fit_reports_the_single_rank_estimate():
+    n = 1500
+    X = rand_inputs(n, 4, 11)
+    k = ("matern2", 0.7, 1.2)
+    from friedrich_amd.device import Context
+
+    ctx1 = Context()
+    ctx1.set_option("nb", 128)
+    c1 = ctx1.cholesky_from_inputs(k, X, 0.1)
+    est1, ref1 = c1.conditioning()
+    c1.free()
+    ctx1.close()
+    assert not ref1 and 1.0 < est1 < 30.0
+
+    def fn(ctx, rank):
+        ctx.set_option("nb", 128)
+        chol = ctx.cholesky_from_inputs(k, X, 0.1)
+        out = chol.conditioning()
+        chol.free()
+        return out
+
+    for est, ref in run_ranks(3, fn):
+        assert not ref and abs(est / est1 - 1.0) < 1e-6  # (the staged and the flat diagonal-block kernel round differently)
+
+
+# ---- (b) add_samples with the new rows dealt to the ranks -------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_add_rows_matches_oracle_and_ranks_agree_bitwise(world):
+    n0, d = 1100, 3
+    steps = [300, 128, 1, 2, 515]  # unaligned, aligned to nothing in particular, fewer rows than ranks, wider than a panel
+    ntot = n0 + sum(steps)
+    X = rand_inputs(ntot, d, 21)
+    y = np.cos(X.sum(axis=1))
+    Xq = rand_inputs(40, d, 22)
+    k = ("squared_exp", 0.8, 1.3)
+    noise = 0.2
+    refs = []
+    n = n0
+    for s in steps:
+        n += s
+        st, L_o, _ = O.make_cholesky_cov_matrix(k, X[:n], noise)  # add_samples == refit (tests/test_oracle.py)
+        assert st == 0
+        refs.append(np.tril(L_o))
+    gp = O.OracleGP(O.ZeroPrior(), k, noise, None, X, y)
+    want = gp.predict(Xq)
+
+    def fn(ctx, rank):
+        ctx.set_option("nb", 128)
+        chol = ctx.cholesky_from_inputs(k, np.asfortranarray(X[:n0]), noise, capacity_hint=n0 + 10)
+        outs = []
+        n = n0
+        for s in steps:
+            n += s
+            chol.add_rows(k, np.asfortranarray(X[:n]), s, noise)
+            outs.append(chol.l())
+        mean = chol.predict_mean(k, y, Xq)
+        var = chol.predict_variance(k, Xq)
+        calls = ctx.counter("solve_retries")
+        chol.free()
+        return outs, mean, var, calls
+
+    res = run_ranks(world, fn)
+    for outs, mean, var, retries in res:
+        for L, L_ref in zip(outs, refs):
+            assert L.shape == L_ref.shape and rel_err(L, L_ref) < TOL
+        assert rel_err(mean, want) < TOL
+        assert rel_err(var, gp.predict_variance(Xq)) < 1e-8
+        assert retries == 0
+    for outs, mean, var, _ in res[1:]:
+        for L, L0 in zip(outs, res[0][0]):
+            assert np.array_equal(L, L0)  # the replicated part is deterministic: no broadcast of the Schur factor is needed
+        assert np.array_equal(mean, res[0][1])
+
+
+def test_sharded_add_rows_configs4_shape():
+    """BASELINE configs[4] at its own sizes over 4 ranks: 4096 rows grown to 8192 in 512-row appends (the 2048-row leaves and their
+    cache extension on every rank's slice solve), against a single-rank run of the same appends on the same GPU."""
+    from friedrich_amd import synth
+    from friedrich_amd.device import Context
+
+    n0, n1, step, d = 4096, 8192, 512, 8
+    X, y, Xq = synth.make_problem(n1, d, cfg=4, m=32)
+    k = ("squared_exp", 1.1, 1.0)
+    noise = 0.1
+
+    def grow(ctx):
+        chol = ctx.cholesky_from_inputs(k, np.asfortranarray(X[:n0]), noise, capacity_hint=n1)
+        for n in range(n0 + step, n1 + 1, step):
+            chol.add_rows(k, np.asfortranarray(X[:n]), step, noise)
+        out = (chol.l(), chol.predict_mean(k, y, Xq))
+        chol.free()
+        return out
+
+    ctx1 = Context()
+    L1, m1 = grow(ctx1)
+    ctx1.close()
+    for L, m in run_ranks(4, lambda ctx, rank: grow(ctx)):
+        assert rel_err(L, L1) < 1e-12
+        assert rel_err(m, m1) < 1e-10
+
+
+# ---- (c) gradient terms split over the ranks ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("kernel", [("squared_exp", 0.6, 1.4), ("sum", ("matern2", 0.9, 1.1), ("linear", 0.3))], ids=["rbf", "sum"])
+def test_sharded_grad_terms_match_oracle(world, kernel):
+    n, d = 1300, 3  # 512-row chunks: three of them, the last one ragged
+    X = rand_inputs(n, d, 31)
+    y = np.sin(X.sum(axis=1))
+    noise = 0.3
+    gp = O.OracleGP(O.ZeroPrior(), kernel, noise, None, X, y)
+    npar = O.nb_parameters(kernel)
+    g_o = gp.gradient()
+    scale_o, gs_o = gp.scaled_gradient()
+
+    def fn(ctx, rank):
+        ctx.set_option("nb", 128)
+        ctx.set_option("grad_shard_min", 1024)
+        chol = ctx.cholesky_from_inputs(kernel, X, noise)
+        g, _ = chol.grad_terms(kernel, y, noise, scaled=False, nb_parameters=npar)
+        gs, scale = chol.grad_terms(kernel, y, noise, scaled=True, nb_parameters=npar)
+        chol.free()
+        return g, gs, scale
+
+    res = run_ranks(world, fn)
+    for g, gs, scale in res:
+        assert g.shape == g_o.shape
+        assert np.max(np.abs(g - g_o)) < 1e-8 * (np.max(np.abs(g_o)) + 1.0)
+        assert abs(scale / scale_o - 1.0) < 1e-9
+        assert np.max(np.abs(gs - gs_o)) < 1e-8 * (np.max(np.abs(gs_o)) + 1.0)
+    for g, gs, scale in res[1:]:
+        assert np.array_equal(g, res[0][0]) and np.array_equal(gs, res[0][1])  # summed in rank order on every rank
+
+
+@pytest.mark.parametrize("n", [8192 + 640, 12288])
+def test_sharded_grad_terms_large_against_single_rank(n):
+    """2048-row chunks (n >= 8192): leading-block backward solves on the 2048-row leaves, ragged last chunk, 3 ranks (the snake
+    deal leaves ranks with different chunk counts) -- against the single-rank recursion (triangular inverse + W^T W), which the
+    tests above and test_gpu_parity hold to the oracle."""
+    from friedrich_amd.device import Context
+
+    d = 6
+    X = rand_inputs(n, d, 41)
+    y = np.sin(X.sum(axis=1))
+    k = ("squared_exp", 1.2, 1.1)
+    noise = 0.2
+    ctx1 = Context()
+    c1 = ctx1.cholesky_from_inputs(k, X, noise)
+    g1, _ = c1.grad_terms(k, y, noise, scaled=False, nb_parameters=2)
+    gs1, s1 = c1.grad_terms(k, y, noise, scaled=True, nb_parameters=2)
+    c1.free()
+    ctx1.close()
+
+    def fn(ctx, rank):
+        chol = ctx.cholesky_from_inputs(k, X, noise)
+        g, _ = chol.grad_terms(k, y, noise, scaled=False, nb_parameters=2)
+        gs, s = chol.grad_terms(k, y, noise, scaled=True, nb_parameters=2)
+        chol.free()
+        return g, gs, s
+
+    for g, gs, s in run_ranks(3, fn):
+        assert np.max(np.abs(g - g1)) < 1e-9 * (np.max(np.abs(g1)) + 1.0)
+        assert np.max(np.abs(gs - gs1)) < 1e-9 * (np.max(np.abs(gs1)) + 1.0)
+        assert abs(s / s1 - 1.0) < 1e-12

@@ -839,8 +839,10 @@ def test_schedule_options_keep_the_factor(ctx, opt, val):
 @pytest.mark.parametrize("n", [1536, 2500, 3200])
 def test_xcd_reservation(ctx, n):
     """The look-ahead pipeline with XCDs set aside for the panel chain (gemm_f64.hip: trailing-update tiles CLAIMED by the
-    workgroups that do not sit on the panel stream's XCDs, panel launches on the b % 8 < R workgroups): every setting gives
-    bit for bit the factor of the default (automatic reservation) -- same arithmetic, only placed differently."""
+    workgroups that do not sit on the panel stream's XCDs, panel launches on the b % 8 < R workgroups): with the
+    diagonal-block kernel held fixed (option k4_flat = 0 / 1: round 5's flat variant and the staged one round differently),
+    every reservation setting gives bit for bit the same factor -- same arithmetic, only placed differently -- and the
+    automatic choice (flat where the kernel has its CU to itself) is a function of the input: two fits agree bit for bit."""
     k = PD_KERNELS[0]
     X = rand_inputs(n, 3, 77 + n)
     st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
@@ -848,14 +850,23 @@ def test_xcd_reservation(ctx, n):
     chol = ctx.cholesky_from_inputs(k, X, 0.1)
     L_auto = chol.l()
     assert rel_err(L_auto, L_o) < TOL
+    chol.refactor(k, 0.1)
+    assert np.array_equal(chol.l(), L_auto)
     try:
-        for r1 in (0, 1, 2, 3, 4):
-            ctx.set_option("xcd_reserve", r1)
-            for rep in range(2):  # (twice: the claim counters are recycled, the published XCD is known the second time)
-                chol.refactor(k, 0.1)
-                assert np.array_equal(chol.l(), L_auto), r1
+        for flat in (0, 1):
+            ctx.set_option("k4_flat", flat)
+            ctx.set_option("xcd_reserve", -1)
+            chol.refactor(k, 0.1)
+            L_ref = chol.l()
+            assert rel_err(L_ref, L_o) < TOL
+            for r1 in (0, 1, 2, 3, 4):
+                ctx.set_option("xcd_reserve", r1)
+                for rep in range(2):  # (twice: the claim counters are recycled, the published XCD is known the second time)
+                    chol.refactor(k, 0.1)
+                    assert np.array_equal(chol.l(), L_ref), (flat, r1)
     finally:
         ctx.set_option("xcd_reserve", -1)
+        ctx.set_option("k4_flat", -1)
     chol.free()
 
 
