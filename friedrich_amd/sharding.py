@@ -79,6 +79,38 @@ def chain_rounds(n, nb, world):
         }
 
 
+# ---- add_samples and the gradient terms (fr_chol_add_rows in chol.hip, grad_terms_impl in grad.hip) -------
+def add_rows_slices(nb_new, world):
+    """fr_chol_add_rows: the nb_new right-hand sides of  L21^T = L11^-1 K12  in `world` equal slices
+    -> (slice width, [(first new row, rows) per rank]); one all-gather of slice x n_old doubles per rank returns L21^T"""
+    width = -(-nb_new // world)
+    out = []
+    for r in range(world):
+        lo = min(nb_new, r * width)
+        out.append((lo, min(nb_new, lo + width) - lo))
+    return width, out
+
+
+def grad_chunk_rows(n):
+    """rows per chunk of the sharded gradient terms"""
+    return 2048 if n >= 8192 else 512
+
+
+def grad_chunks(n, world):
+    """fr_grad_terms: the rows of W = L^-1 in chunks, dealt in a snake over DESCENDING row ranges (the cost of a chunk -- a backward
+    solve on the leading block that ends with it and that block's share of W^T W -- grows with the square of where it ends)
+    -> [(k0, k1, owner)], largest first.  A rank accumulates  sum over its chunks of  W[k0:k1, :k1]^T W[k0:k1, :k1]  into the
+    leading k1 x k1 corner of its PARTIAL K^-1; the reductions are linear in K^-1, so the ranks' p + 2 scalars just add up."""
+    cs = grad_chunk_rows(n)
+    nc = -(-n // cs)
+    out = []
+    for t in range(nc):
+        owner = (world - 1 - t % world) if (t // world) & 1 else t % world
+        j = nc - 1 - t
+        out.append((j * cs, min(n, (j + 1) * cs), owner))
+    return out
+
+
 # ---- guarded start of a sharded run: preflight, watchdog, schedule fall-back (bench.py, tests/test_gpu_dist_guard.py) ---------
 # The library bounds every wait for a collective (option "comm_timeout_ms": comm.hip) and reports FR_RCCL_ERROR instead of
 # hanging; what to do then is the host's decision.  These helpers are that decision for bench.py and the tests: try the

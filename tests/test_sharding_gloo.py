@@ -402,3 +402,99 @@ def test_guarded_schedule_over_gloo(tmp_path, scenario):
         assert res[0]["schedule"] == -1 and any("attaching a fresh communicator failed" in x for x in res[0]["reasons"])
         for r in res:
             assert r["log"][-1] == ["finalize", True]
+
+
+# ---- add_samples and the gradient terms as they are dealt to the ranks ---------------------------------
+def _worker_8e(rank, world, port, n0, nb_new, out_dir):
+    """numpy replay of the two deals over a gloo group: a rank solves ITS slice of L21^T and one all-gather returns the whole;
+    a rank forms the rows of L^-1 of ITS chunks (backward solve on the leading block), accumulates its partial K^-1 and reduces
+    it -- tr(K^-1 G), tr(K^-1) are linear in K^-1, so the partial scalars add up"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scipy.linalg as sl
+    import torch
+    import torch.distributed as dist
+
+    from friedrich_amd import sharding
+    from oracle import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k = ("squared_exp", 0.8, 1.3)
+    n = n0 + nb_new
+    X = rand_inputs(n, 3, 42)
+    K = O.make_covariance_matrix(k, X, X) + 0.04 * np.eye(n)
+    L11 = sl.cholesky(K[:n0, :n0], lower=True)
+    # (b) add_rows: slices of the right-hand sides
+    width, slices = sharding.add_rows_slices(nb_new, world)
+    lo, rows = slices[rank]
+    mine = np.zeros((width, n0))
+    if rows > 0:
+        mine[:rows] = sl.solve_triangular(L11, K[:n0, n0 + lo:n0 + lo + rows], lower=True).T
+    gathered = [torch.zeros((width, n0), dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(mine))
+    L21 = np.concatenate([g.numpy() for g in gathered])[:nb_new]
+    S = K[n0:, n0:] - L21 @ L21.T  # replicated on every rank
+    L = np.zeros((n, n))
+    L[:n0, :n0], L[n0:, :n0], L[n0:, n0:] = L11, L21, sl.cholesky(S, lower=True)
+    np.save(os.path.join(out_dir, f"L{rank}.npy"), L)
+    # (c) gradient terms: rows of W = L^-1 in chunks
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((n, n))
+    G = G + G.T
+    Kinv_part = np.zeros((n, n))
+    for k0, k1, owner in sharding.grad_chunks(n, world):
+        if owner != rank:
+            continue
+        E = np.zeros((k1, k1 - k0))
+        E[k0:, :] = np.eye(k1 - k0)
+        Xc = sl.solve_triangular(L[:k1, :k1], E, lower=True, trans="T")  # = W[k0:k1, :k1]^T
+        Kinv_part[:k1, :k1] += Xc @ Xc.T
+    part = torch.tensor([float(np.sum(Kinv_part * G)), float(np.trace(Kinv_part))], dtype=torch.float64)
+    allp = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(allp, part)
+    tot = sum(p.numpy() for p in allp)  # (rank order)
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), np.array([tot[0], tot[1], float(np.sum(np.linalg.inv(K) * G)), float(np.trace(np.linalg.inv(K)))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n0,nb_new", [(700, 300), (1100, 1)])
+def test_two_rank_add_rows_and_grad_chunks(tmp_path, n0, nb_new):
+    import torch.multiprocessing as tmp_mp
+
+    from oracle import oracle as O
+
+    world = 2
+    port = 35100 + (os.getpid() % 2000) + nb_new % 7
+    tmp_mp.spawn(_worker_8e, args=(world, port, n0, nb_new, str(tmp_path)), nprocs=world, join=True)
+    n = n0 + nb_new
+    X = rand_inputs(n, 3, 42)
+    st, L_o, _ = O.make_cholesky_cov_matrix(("squared_exp", 0.8, 1.3), X, 0.2)
+    for r in range(world):
+        assert rel_err(np.load(tmp_path / f"L{r}.npy"), np.tril(L_o)) < 1e-10
+        g = np.load(tmp_path / f"g{r}.npy")
+        assert abs(g[0] - g[2]) < 1e-9 * (abs(g[2]) + 1.0) and abs(g[1] / g[3] - 1.0) < 1e-10
+
+
+def test_grad_chunks_and_add_rows_slices_cover_everything_once():
+    from friedrich_amd import sharding
+
+    for n in (1024, 1300, 8192, 8192 + 640, 32768):
+        for world in (2, 3, 4, 8):
+            ch = sharding.grad_chunks(n, world)
+            rows = sorted((k0, k1) for k0, k1, _ in ch)
+            assert rows[0][0] == 0 and rows[-1][1] == n and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            assert all(k0 % sharding.grad_chunk_rows(n) == 0 for k0, _, _ in ch)
+            # the snake keeps the ranks' work level: cost of a chunk ~ (where it ends)^2 x its rows
+            cost = [0.0] * world
+            for k0, k1, o in ch:
+                cost[o] += float(k1) ** 2 * (k1 - k0)
+            if len(ch) >= 2 * world:
+                assert max(cost) < 1.6 * (sum(cost) / world), (n, world, cost)
+    for nb_new in (1, 2, 7, 512, 515):
+        for world in (2, 3, 8):
+            width, sl_ = sharding.add_rows_slices(nb_new, world)
+            got = [r for lo, rows in sl_ for r in range(lo, lo + rows)]
+            assert got == list(range(nb_new)) and all(rows <= width for _, rows in sl_)
