@@ -36,8 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_NB = 1024  # block size of the run profiles/r04/fit32k_counters.json was collected with
-PMC_FILE = os.path.join("profiles", "r04", "fit32k_counters.json")
+PMC_NB = 1024  # block size of the run profiles/r05/fit32k_counters.json was collected with
+PMC_FILE = os.path.join("profiles", "r05", "fit32k_counters.json")
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; scripts/mfma_f64_peak measures 77.0-77.6 on the box
 
 
@@ -382,7 +382,7 @@ def run_rank(args, link, device_index, emit, mode):
         pmc_path = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc_path) and (n, d, nb_eff, world) == (32768, 16, PMC_NB, 1):
             with open(pmc_path) as f:
-                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: regenerate (scripts/profile_r04.sh) whenever gemm_f64.hip / gemm_tile.hpp change
+                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: tests/test_profiles_fresh.py fails when gemm_f64.hip / gemm_tile.hpp changed after the passes (scripts/profile_r05.sh)
             traffic_src = PMC_FILE
         if not sharded:
             parallelism = "1 GPU"

@@ -549,6 +549,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
                 // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
                 // own products are too large for one or two XCDs and every setting is neutral or worse
                 if (kb2 <= 512) ctx->reserve_now = rest <= 4096 ? 4 : (rest <= 8192 ? 2 : (rest <= 16384 ? 1 : 0));  // (12288 .. 16384: the same to 1 %)
+                else if (rest <= ctx->xcd_reserve_big_rows) ctx->reserve_now = 1;  // (experiment, off by default: DESIGN.md section 5, round 5)
             } else {
                 ctx->reserve_now = (int)ctx->xcd_reserve;  // explicit: that many XCDs for the whole factorisation
             }

@@ -537,6 +537,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->xcd_reserve = value;
         return FR_OK;
     }
+    if (!strcmp(name, "xcd_reserve_big_rows")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve_big_rows must be >= 0");
+        ctx->xcd_reserve_big_rows = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "k4_flat")) {
         if (value < -1 || value > 1) return set_err(ctx, FR_INVALID_ARGUMENT, "k4_flat must be -1 (automatic), 0 or 1");
         ctx->k4_flat = value;

@@ -110,6 +110,7 @@ struct fr_ctx {
     int64_t prof_launches[FR_PROF_COUNT] = {0};
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
+    int64_t xcd_reserve_big_rows = 0;  // experiment (scripts/headline_ab.py): with panels wider than 512 columns, one XCD is set aside while at most this many rows remain (0: never -- the measured default)
     int64_t k4_flat = -1;          // diagonal-block kernel: -1 = flat variant wherever the kernel has its CU to itself (potf2.hip), 0 = never, 1 = every full block
     bool k4_alone = false;         // the running factorisation has no second stream: nothing shares the diagonal-block kernel's CU
     int reserve_now = 0;           // XCDs reserved right now (set by the factorisation around the launches it applies to)

@@ -96,13 +96,15 @@ void fr_ctx_destroy(fr_ctx* ctx);
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
-/* Tunables (19 names; everything else the library decides from the problem size):
+/* Tunables (20 names; everything else the library decides from the problem size):
  *   "nb"             outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
  *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
  *   "xcd_reserve"    -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
  *                    the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, 4 below 4096, nb <= 512 only: DESIGN.md
  *                    section 5); 0: never; 1..4: that many XCDs for the whole factorisation
+ *   "xcd_reserve_big_rows" 0 (default: never): with panels wider than 512 columns, one XCD is set aside while at most this many
+ *                    rows remain (measured and left off: DESIGN.md section 5, round 5)
  *   "k4_flat"        -1 (default): full 128 x 128 diagonal blocks are factored by the flat variant of the diagonal-block kernel
  *                    (one row per lane, rank-4 MFMA updates: potf2.hip) wherever that kernel has its CU to itself -- XCDs set aside,
  *                    no second stream, sharded chain -- and by the staged variant that fits beside a GEMM workgroup elsewhere; 0 / 1:

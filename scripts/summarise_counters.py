@@ -59,6 +59,10 @@ for k, a in agg.items():
         e["mfma_TFLOP_per_s"] = round(fl / (tot / 1e9) / 1e12, 2)
         e["mfma_frac_of_78.6"] = round(e["mfma_TFLOP_per_s"] / 78.6, 3)
     out["kernels"][k] = e
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import source_hashes  # noqa: E402
+
+out["sources"] = source_hashes()  # the device sources these passes ran (tests/test_profiles_fresh.py)
 json.dump(out, open(out_path, "w"), indent=1)
 for k, e in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["total_ms"]):
     print(k[:44], e)
