@@ -25,8 +25,8 @@ STATUS_NAMES = {
     5: "FR_INVALID_ARGUMENT", 6: "FR_OUT_OF_MEMORY", 7: "FR_HIP_ERROR", 8: "FR_RCCL_ERROR", 9: "FR_NO_DEVICE",
 }
 
-FR_PROF_GRAM, FR_PROF_POTF2, FR_PROF_GEMM_PANEL, FR_PROF_SYRK, FR_PROF_GEMM_SOLVE, FR_PROF_REDUCE, FR_PROF_COMM = range(7)
-PROF_NAMES = ["gram", "potf2", "gemm_panel", "syrk", "gemm_solve", "reduce", "comm"]
+FR_PROF_GRAM, FR_PROF_POTF2, FR_PROF_GEMM_PANEL, FR_PROF_SYRK, FR_PROF_GEMM_SOLVE, FR_PROF_REDUCE, FR_PROF_COMM, FR_PROF_SYRK_CHAIN = range(8)
+PROF_NAMES = ["gram", "potf2", "gemm_panel", "syrk", "gemm_solve", "reduce", "comm", "syrk_chain"]
 
 FR_KPROG_MAX_OPS = 15
 FR_COMM_ID_BYTES = 128

@@ -466,6 +466,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     }
     hipStream_t S0 = ctx->stream, S1 = ctx->stream2;
     int st = FR_OK;
+    const bool cu_ok = ctx->cu_reserve != 0 && ctx->xcd_reserve != 0 && cu_table_ready(ctx);  // (builds the CU rank table on first use: one small launch + a synchronisation, here rather than between two panels)
     if (world == 1 && ctx->xcd_reserve != 0 && ctx->claim_ring) {
         // claim counters of the launches that keep off the panel stream's XCD (gemm_f64.hip): one pair per launch
         FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 2 * kClaimSlots, S0));
@@ -474,6 +475,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     auto fail = [&](int code) {
         ctx->ls = S0;
         ctx->reserve_now = 0;
+        ctx->reserve_by_cu_now = false;
         ctx->cols_final_at = -1;
         if (world > 1) {
             comm_abort(ctx);  // a host-side failure past this point: the peers must not wait for this rank
@@ -548,11 +550,18 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             if (ctx->xcd_reserve < 0) {
                 // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
                 // own products are too large for one or two XCDs and every setting is neutral or worse
-                if (kb2 <= 512) ctx->reserve_now = rest <= 4096 ? 4 : (rest <= 8192 ? 2 : (rest <= 16384 ? 1 : 0));  // (12288 .. 16384: the same to 1 %)
+                if (kb2 <= 512) {
+                    // (defaults 4096 / 8192 / 16384; 12288 .. 16384: the same to 1 %.  By CUs -- above cu_reserve_min_rows -- the
+                    // two-unit tier ends at 6144 rows: the panel's products no longer carry idle workgroups, and the trailing
+                    // update, which then bounds the step as often as the chain does, gets the CUs)
+                    const int64_t rows2 = (cu_ok && rest > ctx->cu_reserve_min_rows && ctx->reserve_rows2_cu < ctx->reserve_rows2) ? ctx->reserve_rows2_cu : ctx->reserve_rows2;
+                    ctx->reserve_now = rest <= ctx->reserve_rows4 ? 4 : (rest <= rows2 ? 2 : (rest <= ctx->reserve_rows1 ? 1 : 0));
+                }
                 else if (rest <= ctx->xcd_reserve_big_rows) ctx->reserve_now = 1;  // (experiment, off by default: DESIGN.md section 5, round 5)
             } else {
                 ctx->reserve_now = (int)ctx->xcd_reserve;  // explicit: that many XCDs for the whole factorisation
             }
+            ctx->reserve_by_cu_now = cu_ok && ctx->reserve_now > 0 && rest > ctx->cu_reserve_min_rows;
         }
         const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
@@ -576,7 +585,12 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             la_hook(k + kb, kb2);
             if (own_next) st = factor_panel(ctx, A, ld, n, k + kb, kb2, col0, mode, sub, dinv, info, T);
             ctx->cols_final_at = -1;
-            if (st == FR_OK && ctx->reserve_now) st = launch_release_xcds(ctx, ctx->panel_epoch);  // (on the panel stream)
+            // (on the panel stream.  By CUs there is nothing to hand back: a launch keeps off for as long as it runs.  With four
+            // XCDs set aside -- at most 4096 trailing rows -- the trailing update is at most 528 tiles on half the chip, ~120 us
+            // against a chain of >= 260: it is long done, and the launch with its dispatch bubble, 11 us between the panel's
+            // last solve and the look-ahead remainder, hands back nothing)
+            if (st == FR_OK && ctx->reserve_now && !cu_reserve_active(ctx) && !(ctx->xcd_reserve < 0 && ctx->reserve_now == 4))
+                st = launch_release_xcds(ctx, ctx->panel_epoch);
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, k + kb, kb2, dinv, pbuf, owner_of(k + kb, nb, world));
         }
         if (st != FR_OK) return fail(st);
@@ -627,6 +641,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     }
     ctx->ls = S0;
     ctx->reserve_now = 0;
+    ctx->reserve_by_cu_now = false;
     ctx->cols_final_at = -1;
     return FR_OK;
 }

@@ -469,6 +469,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->readback) (void)hipHostFree(ctx->readback);
     if (ctx->xcc_word) (void)hipFree(ctx->xcc_word);
+    if (ctx->cu_rank) (void)hipFree(ctx->cu_rank);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->claim_ring) (void)hipFree(ctx->claim_ring);
     if (ctx->dyn_ring) (void)hipFree(ctx->dyn_ring);
@@ -540,6 +541,26 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "xcd_reserve_big_rows")) {
         if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "xcd_reserve_big_rows must be >= 0");
         ctx->xcd_reserve_big_rows = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "reserve_rows2_cu")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "reserve_rows2_cu must be >= 0");
+        ctx->reserve_rows2_cu = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "reserve_rows1") || !strcmp(name, "reserve_rows2") || !strcmp(name, "reserve_rows4")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "reserve_rows* must be >= 0");
+        (name[12] == '1' ? ctx->reserve_rows1 : (name[12] == '2' ? ctx->reserve_rows2 : ctx->reserve_rows4)) = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "cu_reserve_min_rows")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "cu_reserve_min_rows must be >= 0");
+        ctx->cu_reserve_min_rows = value;
+        return FR_OK;
+    }
+    if (!strcmp(name, "cu_reserve")) {
+        if (value != 0 && value != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "cu_reserve must be 0 or 1");
+        ctx->cu_reserve = value;
         return FR_OK;
     }
     if (!strcmp(name, "k4_flat")) {

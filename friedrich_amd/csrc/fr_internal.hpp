@@ -111,6 +111,13 @@ struct fr_ctx {
     double prof_flops[FR_PROF_COUNT] = {0};
     double prof_bytes[FR_PROF_COUNT] = {0};
     int64_t xcd_reserve_big_rows = 0;  // experiment (scripts/headline_ab.py): with panels wider than 512 columns, one XCD is set aside while at most this many rows remain (0: never -- the measured default)
+    int64_t reserve_rows1 = 16384, reserve_rows2 = 8192, reserve_rows4 = 4096;  // automatic reservation tiers (nb <= 512): 1 / 2 / 4 units while at most this many rows remain
+    int64_t reserve_rows2_cu = 6144;     // ... the two-unit tier when the reservation is by CUs (measured: scripts/optset_ab.py)
+    int64_t cu_reserve_min_rows = 4096;  // ... while more than this many rows remain (below, the chain's products are too small to saturate anything and gain more from staying inside one or two XCDs' L2)
+    bool reserve_by_cu_now = false;  // state: the reservation in force is carried out by CUs
+    int64_t cu_reserve = 1;        // reservation by CUs (R of every shader engine) instead of by XCDs: resident trailing-update workgroups, no idle panel workgroups (gemm_f64.hip)
+    unsigned char* cu_rank = nullptr;  // device: [xcc][se][cu_id] -> rank of that CU among the active CUs of its shader engine (255: absent); built on first use
+    int cu_rank_state = 0;         // 0: not built, 1: usable, -1: the probe did not see a regular chip (CU-level reservation off)
     int64_t k4_flat = -1;          // diagonal-block kernel: -1 = flat variant wherever the kernel has its CU to itself (potf2.hip), 0 = never, 1 = every full block
     bool k4_alone = false;         // the running factorisation has no second stream: nothing shares the diagonal-block kernel's CU
     int reserve_now = 0;           // XCDs reserved right now (set by the factorisation around the launches it applies to)
@@ -360,7 +367,9 @@ struct GemmDesc {
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 // S (rows x kb, ld lds_) <- S L^-T against a factored kb x kb diagonal block and its 128-block inverses: one launch (gemm_f64.hip)
 int launch_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const double* L, int64_t ldl, int64_t kb, const double* dinv);
-int launch_release_xcds(fr_ctx* ctx, unsigned epoch);  // on ctx->ls: the chain of panel `epoch` is finished
+int launch_release_xcds(fr_ctx* ctx, unsigned epoch);
+bool cu_table_ready(fr_ctx* ctx);     // option cu_reserve is set and the chip looks as expected (builds the CU rank table on first use)
+bool cu_reserve_active(fr_ctx* ctx);  // the reservation in force is carried out by CUs  // on ctx->ls: the chain of panel `epoch` is finished
 
 // K4: factor one diagonal block (nbk <= 128) and emit its explicit inverse (inv may be NULL).
 //   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows),

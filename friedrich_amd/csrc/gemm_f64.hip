@@ -22,6 +22,7 @@
 // instruction moves four 128-byte segments.
 #include "fr_internal.hpp"
 #include "gemm_tile.hpp"
+#include <vector>
 
 namespace fr {
 
@@ -170,6 +171,87 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g
     gemm_f64_body<false, false>(g, lds);
 }
 
+// ---- resident workgroups that claim tiles (GemmArgs::place == 3) ---------------------------------------------------------------
+// While CUs are set aside for the panel chain (fr_ctx::cu_reserve), the main stream's products run as ONE round of resident
+// workgroups: a workgroup that finds itself on a reserved CU -- one of the ncu_res lowest-ranked CUs of its shader engine, on
+// every XCD -- leaves at once, everybody else takes tiles from the list until it is empty.  Nothing of the launch is dispatched
+// after its first microseconds, so the reserved CUs stay empty for as long as it runs: the diagonal-block kernel and the panel
+// stream's products find them without any placement logic of their own, and no launch of the panel stream carries idle
+// workgroups (which have to wait for a slot on the busy XCDs before they can exit: scripts/dispatch_probe.hip).  Every tile is
+// computed whole by one workgroup with the arithmetic of the one-tile-per-workgroup launch: the same bits.
+// Own kernel symbols: the loop around the tile function costs registers the one-tile kernels must not pay (see MIRROR above).
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double* lds)
+{
+    __shared__ long long item;
+    if (threadIdx.x == 0) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));  // cu_id[11:8] sh_id[12] se_id[15:13]
+        const unsigned rank = g.cu_rank[(((xcc & 7u) * 8u + ((hwid >> 13) & 7u)) << 4) + ((hwid >> 8) & 15u)];
+        bool leave = false;
+        if (rank < (unsigned)g.ncu_res) leave = __hip_atomic_fetch_add(g.claim + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.max_exit;
+        item = leave ? -2 : 0;
+    }
+    __syncthreads();
+    if (item == -2) return;
+    for (;;) {
+        __syncthreads();  // (everybody has read `item`, the tile before is out of the LDS stages)
+        if (threadIdx.x == 0) {
+            const unsigned i = __hip_atomic_fetch_add(g.claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            item = (int64_t)i < g.ntiles ? (long long)i : -1;
+        }
+        __syncthreads();
+        const long long tlin = item;
+        if (tlin < 0) return;
+        int64_t tm, tn;
+        if (g.lower) {
+            int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
+            while (row * (row + 1) / 2 > tlin) --row;
+            while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
+            tm = row;
+            tn = tlin - row * (row + 1) / 2;
+        } else {
+            tm = tlin % g.tiles_m;
+            tn = tlin / g.tiles_m;
+        }
+        const int64_t n0 = tn * BN;
+        if (g.own_world > 1 && (int)(((g.own_col0 + n0) / g.own_nb) % g.own_world) != g.own_rank) continue;
+        // (the leading dimensions and base pointers pass through an empty asm in every round: what the tile function derives
+        // from them per lane would otherwise be hoisted out of the loop and kept alive across it -- 255 registers and 260 B of
+        // scratch per lane where the one-tile kernel needs 237 and none)
+        GemmArgs gt = g;
+        asm volatile("" : "+s"(gt.lda), "+s"(gt.ldb), "+s"(gt.ldd), "+s"(gt.ldcin));
+        asm volatile("" : "+s"(gt.A), "+s"(gt.B), "+s"(gt.D), "+s"(gt.Cin));
+        gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, tm * BM, n0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void syrk_lower_persist_f64_kernel(const GemmArgs g)
+{
+    __shared__ double lds[4 * TILE_ELEMS];
+    gemm_f64_persist_body<false, false>(g, lds);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f64_persist_kernel(const GemmArgs g)
+{
+    __shared__ double lds[4 * TILE_ELEMS];
+    gemm_f64_persist_body<false, false>(g, lds);
+}
+
+// which (shader engine, CU id) pairs exist on each XCD: one workgroup per slot of the chip, each notes where it ran
+__global__ __launch_bounds__(256) void cu_probe_kernel(unsigned* seen)
+{
+    if (threadIdx.x == 0) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        atomicAdd(seen + ((((xcc & 7u) * 8u + ((hwid >> 13) & 7u)) << 4) + ((hwid >> 8) & 15u)), 1u);
+    }
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 3000) __builtin_amdgcn_s_sleep(8);  // 30 us: the launch spreads over every CU
+}
+
 // ---- rows of a panel solved against its factored diagonal block, ONE launch ------------------------------------------------
 // S (rows x kb) <- S L_kk^-T, left-looking over the 128-column sub-panels:  S_s <- (S_s - S_{<s} L[s, <s]^T) W_s^T.  The rows are
 // independent, so a workgroup takes 32 of them through all 2 nblk - 1 tile products by itself -- no hand-off between
@@ -263,6 +345,52 @@ int launch_release_xcds(fr_ctx* ctx, unsigned epoch)
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }
+
+// The rank table of the CU-level reservation: [xcc][se][cu_id] -> position of that CU among the CUs of its shader engine that
+// exist on this chip (harvested CUs leave holes in the ids, different ones per engine: scripts/hwid_probe.hip), 255 where there
+// is none.  Built once per context from a launch that puts a workgroup on every CU; usable only if every one of 8 x 4 engines
+// shows at least four CUs (otherwise the CU-level reservation stays off and the XCD-level one is used).
+static int ensure_cu_table(fr_ctx* ctx)
+{
+    if (ctx->cu_rank_state != 0) return ctx->cu_rank_state;
+    ctx->cu_rank_state = -1;
+    unsigned* seen = nullptr;
+    if (hipMalloc((void**)&seen, sizeof(unsigned) * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    std::vector<unsigned> h(1024, 0u);
+    std::vector<unsigned char> rank(1024, 255);
+    bool ok = hipMemsetAsync(seen, 0, sizeof(unsigned) * 1024, ctx->stream) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(cu_probe_kernel, dim3(4096), dim3(256), 0, ctx->stream, seen);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h.data(), seen, sizeof(unsigned) * 1024, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    (void)hipFree(seen);
+    if (!ok) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    int engines = 0;
+    for (int e = 0; e < 64; ++e) {
+        int r = 0;
+        for (int c = 0; c < 16; ++c)
+            if (h[(size_t)e * 16 + c]) rank[(size_t)e * 16 + c] = (unsigned char)r++;
+        if (r >= 4) ++engines;
+        else if (r > 0) return -1;  // an engine with fewer CUs than may be set aside
+    }
+    if (engines != 32) return -1;  // not the 8 XCDs x 4 engines this scheme is written for
+    if (hipMalloc((void**)&ctx->cu_rank, 1024) != hipSuccess || hipMemcpy(ctx->cu_rank, rank.data(), 1024, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    ctx->cu_rank_state = 1;
+    return 1;
+}
+
+bool cu_table_ready(fr_ctx* ctx) { return ctx->cu_reserve != 0 && ensure_cu_table(ctx) == 1; }
+bool cu_reserve_active(fr_ctx* ctx) { return ctx->reserve_by_cu_now && ctx->cu_reserve != 0 && ctx->cu_rank_state == 1; }
 
 // Host side of claim_item (gemm_tile.hpp): a counter pair from the factorisation's ring for one launch that keeps off the
 // panel stream's XCDs.  Returns the placement to use (0: launch plainly) and the grid size.
@@ -419,7 +547,34 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.nres = ctx->reserve_now;
     g.epoch = ctx->panel_epoch;
     g.tri = d.tri;
-    if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip) {
+    g.cu_rank = nullptr;
+    g.ncu_res = 0;
+    int64_t persist_grid = 0;
+    const bool by_cu = ctx->reserve_now && cu_reserve_active(ctx);
+    if (by_cu) {
+        // CU-level reservation: the panel stream's launches go wherever there is room -- the reserved CUs, which everybody else
+        // vacates; the other streams' products on 128 x 128 tiles run as resident workgroups that claim their tiles
+        if (d.batch <= 1 && !d.whole_chip && ctx->ls != ctx->stream2 && !small && !d.a_kmajor && !d.b_kmajor && !d.tri && g.mirror_tiles == 0 &&
+            g.kslice == 0 && ctx->claim_ring && ctx->claim_next < kClaimSlots) {
+            g.place = 3;
+            g.claim = ctx->claim_ring + 2 * ctx->claim_next++;
+            g.cu_rank = ctx->cu_rank;
+            g.ncu_res = ctx->reserve_now;
+            // As many workgroups as are needed for `ntiles` of them to end up on CUs that are not set aside (the dispatcher spreads
+            // a launch of up to 256 workgroups one to a CU: a product with fewer tiles than CUs keeps a CU's matrix cores to each of
+            // its tiles), at most one per slot of the chip (two per CU).  A shortfall only means that some workgroups take a second tile.
+            const int64_t rcus = (int64_t)ctx->reserve_now * 32;  // CUs set aside
+            int64_t G = (ntiles * 256 + (256 - rcus) - 1) / (256 - rcus) + 8;
+            if (G > 512) G = 512;
+            int64_t me = G * rcus / 256 + G * rcus / 512 + 16;  // 1.5 x the expected share of the reserved CUs ...
+            const int64_t want = ntiles < G ? ntiles : G;
+            const int64_t keep = want / 2 > 1 ? want / 2 : 1;  // ... but this many workgroups stay whatever the dispatcher does
+            if (me > G - keep) me = G - keep;
+            g.max_exit = (unsigned)(me > 0 ? me : 0);
+            persist_grid = G;
+            use_super = false;
+        }
+    } else if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip) {
         if (ctx->ls == ctx->stream2) {
             if (!d.lower) g.place = 2;
         } else {
@@ -445,6 +600,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     }
     if (g.place == 2) ntiles = 8 * ((g.ntiles + g.nres - 1) / g.nres);
     if (g.place == 1) ntiles = g.ntiles + g.max_exit;
+    if (g.place == 3) ntiles = persist_grid;
     if (ntiles > 0x7fffffffLL) return set_err(ctx, FR_INVALID_ARGUMENT, "GEMM grid too large");
     double bytes = 8.0 * ((double)d.M * g.K + (double)d.N * g.K + (d.lower ? 1.0 : 2.0) * (double)d.M * d.N);
     if (d.own_world > 1) {
@@ -464,7 +620,7 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     }
     if (d.tri) flops *= (d.tri == 1 && d.lower) ? (2.0 / 3.0) : 0.5;  // average length of the restricted contraction
     const double nbatch = d.batch > 1 ? (double)d.batch : 1.0;
-    ProfScope ps(ctx, d.prof_cls, flops * nbatch, bytes * nbatch);
+    ProfScope ps(ctx, (g.place == 3 && d.prof_cls == FR_PROF_SYRK) ? (int)FR_PROF_SYRK_CHAIN : d.prof_cls, flops * nbatch, bytes * nbatch);
     g.batch_a = d.batch_a;
     g.batch_b = d.batch_b;
     g.batch_c = d.batch_c;
@@ -483,6 +639,10 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         hipLaunchKernelGGL((gemm_f64_m32_kernel<true, true>), grid, block, 0, ctx->ls, g);
     else if (small)
         hipLaunchKernelGGL((gemm_f64_m32_kernel<true, false>), grid, block, 0, ctx->ls, g);
+    else if (g.place == 3 && d.lower)
+        hipLaunchKernelGGL(syrk_lower_persist_f64_kernel, grid, block, 0, ctx->ls, g);
+    else if (g.place == 3)
+        hipLaunchKernelGGL(gemm_f64_persist_kernel, grid, block, 0, ctx->ls, g);
     else if (d.lower && !d.a_kmajor && !d.b_kmajor)
         hipLaunchKernelGGL(syrk_lower_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (!d.a_kmajor && !d.b_kmajor)

@@ -42,6 +42,11 @@ struct GemmArgs {
     const unsigned* xcc_word;  // 1 + XCC_ID of the XCD the diagonal-block kernels run on (0: not known yet)
     unsigned* claim;
     unsigned max_exit;
+    // place 3 (gemm_f64.hip: gemm_f64_persist_body): resident workgroups claim tiles from claim[0] until none is left; a workgroup
+    // that finds itself on one of the ncu_res lowest-ranked CUs of its shader engine (cu_rank: [xcc][se][cu_id] -> rank) leaves at
+    // once, at most max_exit of them (claim[1])
+    const unsigned char* cu_rank;
+    int ncu_res;
     // triangular operands: the contraction of a tile runs over [kbeg, kend) only (multiples of 128, from the tile's offsets)
     //   1: kbeg = m0  (op(A)(m, k) = 0 for k < m: the transpose of a lower-triangular matrix)
     //   2: kbeg = n0  (op(B)(k, n) = 0 for k < n: a lower-triangular matrix as the right operand)

@@ -80,6 +80,12 @@ class _Mat:
                 a = np.asarray(obj, dtype=np.float64)
                 if a.ndim == 1:
                     a = a.reshape(-1, 1)
+                # the leading rows of a column-major matrix are a column-major matrix with a leading dimension -- what the ABI
+                # takes (EMatrix::as_matrix has ld = capacity too): no copy
+                if a.ndim == 2 and a.shape[0] > 0 and a.shape[1] > 1 and a.strides[0] == 8 and a.strides[1] % 8 == 0 and a.strides[1] // 8 >= a.shape[0]:
+                    self.rows, self.cols, self.ld = a.shape[0], a.shape[1], a.strides[1] // 8
+                    self.keep, self.ptr, self.host = a, a.ctypes.data, a
+                    return
                 arr = np.asfortranarray(a)
             self.rows, self.cols = arr.shape
             self.ld = max(self.rows, 1)

@@ -96,13 +96,18 @@ void fr_ctx_destroy(fr_ctx* ctx);
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
-/* Tunables (20 names; everything else the library decides from the problem size):
+/* Tunables (21 names; everything else the library decides from the problem size):
  *   "nb"             outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
  *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
  *   "xcd_reserve"    -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
  *                    the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, 4 below 4096, nb <= 512 only: DESIGN.md
  *                    section 5); 0: never; 1..4: that many XCDs for the whole factorisation
+ *   "cu_reserve"     how the reservation above is carried out.  0: whole XCDs -- the trailing update's workgroups retire on
+ *                    the reserved XCDs, the panel stream's launches carry 8 / R times the workgroups and only those dealt to the
+ *                    reserved XCDs work;  1: R CUs of every shader engine of every XCD (the same number of CUs) -- the trailing
+ *                    update runs as resident workgroups that claim tiles and vacate those CUs, the panel stream's launches need
+ *                    no idle workgroups (which otherwise wait for a slot on the busy XCDs: DESIGN.md section 5, round 5)
  *   "xcd_reserve_big_rows" 0 (default: never): with panels wider than 512 columns, one XCD is set aside while at most this many
  *                    rows remain (measured and left off: DESIGN.md section 5, round 5)
  *   "k4_flat"        -1 (default): full 128 x 128 diagonal blocks are factored by the flat variant of the diagonal-block kernel
@@ -162,7 +167,9 @@ typedef enum {
     FR_PROF_GEMM_SOLVE = 4,/* K5/K6 GEMMs issued by the triangular solves */
     FR_PROF_REDUCE = 5,    /* K7 epilogue reductions */
     FR_PROF_COMM = 6,      /* RCCL collectives */
-    FR_PROF_COUNT = 7
+    FR_PROF_SYRK_CHAIN = 7,/* K6 as launched while CUs are set aside for the panel chain: resident workgroups that claim tiles
+                              (own kernel symbol syrk_lower_persist_f64_kernel, so that class 3 stays the launches of syrk_lower_f64_kernel) */
+    FR_PROF_COUNT = 8
 } fr_prof_class;
 /* enable: 0 = off, 1 = every class, otherwise a mask with bit (class + 1) set for each class to time */
 int fr_ctx_profile_enable(fr_ctx* ctx, int enable);

@@ -55,12 +55,13 @@ for n in sizes:
     chol.free()
     if n == 8192:  # configs[4]: 4096 -> 8192 in 512-row chunks
         t_best = 1e30
+        Xf = np.asfortranarray(X)  # the caller's matrix as the reference holds it (EMatrix: column-major with a capacity): its leading rows go by pointer + ld
         for _ in range(2):
-            g = ctx.cholesky_from_inputs(k, X[:4096], hp["noise"], capacity_hint=n)
+            g = ctx.cholesky_from_inputs(k, Xf[:4096], hp["noise"], capacity_hint=n)
             ctx.synchronize()
             t0 = time.perf_counter()
             for hi in range(4096 + 512, n + 1, 512):
-                g.add_rows(k, X[:hi], 512, hp["noise"])
+                g.add_rows(k, Xf[:hi], 512, hp["noise"])
             ctx.synchronize()
             t_best = min(t_best, time.perf_counter() - t0)
             g.free()

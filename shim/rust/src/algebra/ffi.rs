@@ -55,6 +55,7 @@ pub const FR_PROF_SYRK: c_int = 3;
 pub const FR_PROF_GEMM_SOLVE: c_int = 4;
 pub const FR_PROF_REDUCE: c_int = 5;
 pub const FR_PROF_COMM: c_int = 6;
+pub const FR_PROF_SYRK_CHAIN: c_int = 7;
 
 pub const FR_COMM_ID_BYTES: usize = 128;
 

@@ -870,6 +870,33 @@ def test_xcd_reservation(ctx, n):
     chol.free()
 
 
+@pytest.mark.parametrize("n", [5300, 6700])
+def test_cu_level_reservation_same_bits(ctx, n):
+    """Above 4096 trailing rows the reservation is carried out by CUs (option cu_reserve, the default): the trailing update and the
+    early look-ahead update run as RESIDENT workgroups that claim their tiles and vacate R CUs of every shader engine
+    (syrk_lower_persist_f64_kernel / gemm_f64_persist_kernel), the panel stream's launches carry no idle workgroups.  Every
+    tile is still computed whole by one workgroup: the factor is bit for bit the one of the XCD-level reservation, for every
+    tier setting, twice in a row (the claim counters are recycled) -- and both agree with the oracle."""
+    k = PD_KERNELS[0]
+    X = rand_inputs(n, 3, 99 + n)
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    chol = ctx.cholesky_from_inputs(k, X, 0.1)
+    L_cu = chol.l()
+    assert rel_err(L_cu, np.tril(L_o)) < TOL
+    try:
+        for opts in ({"cu_reserve": 0}, {"cu_reserve": 1, "reserve_rows2_cu": 8192}, {"cu_reserve": 1, "cu_reserve_min_rows": 1024},
+                     {"cu_reserve": 1, "xcd_reserve": 1}, {"cu_reserve": 1, "xcd_reserve": 4}, {"cu_reserve": 1}):
+            for o, v in {"cu_reserve": 1, "reserve_rows2_cu": 6144, "cu_reserve_min_rows": 4096, "xcd_reserve": -1, **opts}.items():
+                ctx.set_option(o, v)
+            for rep in range(2):
+                chol.refactor(k, 0.1)
+                assert np.array_equal(chol.l(), L_cu), opts
+    finally:
+        for o, v in {"cu_reserve": 1, "reserve_rows2_cu": 6144, "cu_reserve_min_rows": 4096, "xcd_reserve": -1}.items():
+            ctx.set_option(o, v)
+    chol.free()
+
+
 @pytest.mark.parametrize("n,m", [(2, 2), (127, 3), (128, 16), (129, 7), (300, 2), (1000, 16), (2049, 5), (700, 17), (1300, 100), (900, 300)])
 def test_narrow_persistent_solves_2_to_16_columns(ctx, n, m):
     """2 .. 16 right-hand sides (and more, in column groups of 16): one persistent matrix-core launch per direction (trsm_narrow.hip), the backward sweep on
