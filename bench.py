@@ -187,6 +187,11 @@ def run_rank(args, link, device_index, emit, mode):
     y_d = torch.from_numpy(y - hp["prior"]).to(dev)
     prior_d = torch.full((m_loc,), hp["prior"], dtype=torch.float64, device=dev)
     mean_d = torch.empty((m_loc,), dtype=torch.float64, device=dev)
+    # (--verify's reference output is allocated HERE, with everything else and before anything is freed: a block that torch's
+    # caching allocator hands out again is only safe in the order of TORCH's stream, and the library writes on streams of its
+    # own -- with thread-ranks sharing one allocator, a buffer allocated late could be a block whose previous owner, a
+    # temporary of another thread, still had a kernel pending: one rank in six runs "deviated" by 0.6 that way in round 5)
+    want_d = torch.empty((m_loc,), dtype=torch.float64, device=dev) if args.verify else None
     X_d = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev).t()
 
     def sync():
@@ -218,7 +223,7 @@ def run_rank(args, link, device_index, emit, mode):
             for _ in range(args.warmup):
                 step(False)
             ctx.profile_reset()
-            ctx.profile_enable(True, classes=["syrk"])
+            ctx.profile_enable(True, classes=["syrk", "syrk_chain"])
             sync()
             t_start = time.perf_counter()
             for _ in range(args.steps):
@@ -353,12 +358,12 @@ def run_rank(args, link, device_index, emit, mode):
     if args.verify and m_loc > 0:
         ref_ctx = Context(device_index)
         ref = ref_ctx.cholesky_from_inputs(kernel, X_d, noise)
-        want = torch.empty((m_loc,), dtype=torch.float64, device=dev)
-        ref.predict_mean(kernel, y_d, Xq_d, prior_d, out=want)
+        ref.predict_mean(kernel, y_d, Xq_d, prior_d, out=want_d)
         chol.predict_mean(kernel, y_d, Xq_d, prior_d, out=mean_d)
         ref_ctx.synchronize()
         ctx.synchronize()
-        verify_err = float((mean_d - want).abs().max() / want.abs().max())
+        got_h, want_h = mean_d.cpu().numpy(), want_d.cpu().numpy()  # (compared on the host: no device temporaries)
+        verify_err = float(np.max(np.abs(got_h - want_h)) / np.max(np.abs(want_h)))
         ref.free()
         ref_ctx.close()
 
@@ -376,6 +381,12 @@ def run_rank(args, link, device_index, emit, mode):
         total_flops = flops_fit(n, d) + flops_predict(n, m, d)
         syrk = prof["syrk"]
         achieved = syrk["flops"] / max(syrk["ms"], 1e-9) / 1e9  # TFLOP/s
+        # the trailing updates of the chain-bound tail of a fit (at most 16384 trailing rows, CUs set aside for the panel chain) are
+        # launches of another kernel symbol -- resident workgroups that claim tiles, syrk_lower_persist_f64_kernel -- and a profile
+        # class of their own, so that `roofline` stays "the launches of syrk_lower_f64_kernel" (what rocprofv3's per-kernel
+        # average counts); they are reported next to it, and so is the rate over ALL trailing-update launches of a fit
+        chain = prof.get("syrk_chain", {"flops": 0.0, "ms": 0.0, "launches": 0})
+        all_ms, all_flops = syrk["ms"] + chain["ms"], syrk["flops"] + chain["flops"]
         # PMC counters cannot be read from inside the process: the figure is the committed rocprofv3 --pmc summary of the
         # same workload (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction); null for any other size
         traffic, traffic_src = None, None
@@ -430,6 +441,14 @@ def run_rank(args, link, device_index, emit, mode):
                 "launches": syrk["launches"],
                 "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
                 "flops_per_launch": syrk["flops"] / max(syrk["launches"], 1),
+                "chain_phase_launches": {
+                    "kernel": "syrk_lower_persist_f64_kernel (the same tile code as resident workgroups; chain-bound tail of the fit)",
+                    "launches": chain["launches"], "avg_launch_ms": chain["ms"] / max(chain["launches"], 1),
+                    "achieved": chain["flops"] / max(chain["ms"], 1e-9) / 1e9,
+                    "frac": chain["flops"] / max(chain["ms"], 1e-9) / 1e9 / PEAK_F64_MFMA_TFLOPS,
+                },
+                "all_trailing_updates": {"launches": syrk["launches"] + chain["launches"], "achieved": all_flops / max(all_ms, 1e-9) / 1e9,
+                                         "frac": all_flops / max(all_ms, 1e-9) / 1e9 / PEAK_F64_MFMA_TFLOPS},
             },
         }
         if sharded:
