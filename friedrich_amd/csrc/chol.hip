@@ -520,6 +520,34 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         la_split = true;
         return FR_OK;
     };
+    // once the panel chain is longer than the trailing update, the update's launches leave XCDs / CUs to the panel stream
+    // (gemm_f64.hip / gemm_tile.hpp: claim_item, gemm_f64_persist_body); `remaining` = rows from the panel about to be factored on
+    auto set_reservation = [&](int64_t remaining, int64_t kbw) {
+        ctx->reserve_now = 0;
+        ctx->reserve_by_cu_now = false;
+        ++ctx->panel_epoch;
+        if (world == 1 && ctx->claim_ring) {
+            if (ctx->xcd_reserve < 0) {
+                // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
+                // own products are too large for one or two XCDs and every setting is neutral or worse
+                if (kbw <= 512) {
+                    // (defaults 4096 / 8192 / 16384; 12288 .. 16384: the same to 1 %.  By CUs -- above cu_reserve_min_rows -- the
+                    // two-unit tier ends at 6144 rows: the panel's products no longer carry idle workgroups, and the trailing
+                    // update, which then bounds the step as often as the chain does, gets the CUs)
+                    const int64_t rows2 = (cu_ok && remaining > ctx->cu_reserve_min_rows && ctx->reserve_rows2_cu < ctx->reserve_rows2) ? ctx->reserve_rows2_cu : ctx->reserve_rows2;
+                    ctx->reserve_now = remaining <= ctx->reserve_rows4 ? 4 : (remaining <= rows2 ? 2 : (remaining <= ctx->reserve_rows1 ? 1 : 0));
+                }
+                else if (remaining <= ctx->xcd_reserve_big_rows) ctx->reserve_now = 1;  // (experiment, off by default: DESIGN.md section 5, round 5)
+            } else {
+                ctx->reserve_now = (int)ctx->xcd_reserve;  // explicit: that many XCDs for the whole factorisation
+            }
+            ctx->reserve_by_cu_now = cu_ok && ctx->reserve_now > 0 && remaining > ctx->cu_reserve_min_rows;
+        }
+    };
+    // The FIRST panel too (round 5): nothing runs next to it but the early look-ahead update, which then keeps off like every
+    // later one -- and the panel's diagonal blocks get the flat kernel (31 us) instead of the staged one that fits beside a GEMM
+    // workgroup (48 us): 4 x 17 us of a fit of 2.3 ms at N = 4096
+    set_reservation(n, kb0);
     {
         if (split) {
             st = split_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T, pbuf, split_rows, owner_of(0, nb, world));
@@ -527,6 +555,8 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             la_hook(0, kb0);
             if (world == 1 || rank == owner_of(0, nb, world)) st = factor_panel(ctx, A, ld, n, 0, kb0, col0, mode, sub, dinv, info, T);
             ctx->cols_final_at = -1;
+            if (st == FR_OK && ctx->reserve_now && !cu_reserve_active(ctx) && !(ctx->xcd_reserve < 0 && ctx->reserve_now == 4))
+                st = launch_release_xcds(ctx, ctx->panel_epoch);
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
         }
         if (st != FR_OK) return fail(st);
@@ -544,25 +574,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         const double* P = A + (k + kb) + k * ld;
         // once the panel chain is longer than the trailing update, the update's launches leave the panel stream's XCD(s) to it
         // (gemm_f64.hip / gemm_tile.hpp: claim_item)
-        ctx->reserve_now = 0;
-        ++ctx->panel_epoch;
-        if (world == 1 && ctx->claim_ring) {
-            if (ctx->xcd_reserve < 0) {
-                // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
-                // own products are too large for one or two XCDs and every setting is neutral or worse
-                if (kb2 <= 512) {
-                    // (defaults 4096 / 8192 / 16384; 12288 .. 16384: the same to 1 %.  By CUs -- above cu_reserve_min_rows -- the
-                    // two-unit tier ends at 6144 rows: the panel's products no longer carry idle workgroups, and the trailing
-                    // update, which then bounds the step as often as the chain does, gets the CUs)
-                    const int64_t rows2 = (cu_ok && rest > ctx->cu_reserve_min_rows && ctx->reserve_rows2_cu < ctx->reserve_rows2) ? ctx->reserve_rows2_cu : ctx->reserve_rows2;
-                    ctx->reserve_now = rest <= ctx->reserve_rows4 ? 4 : (rest <= rows2 ? 2 : (rest <= ctx->reserve_rows1 ? 1 : 0));
-                }
-                else if (rest <= ctx->xcd_reserve_big_rows) ctx->reserve_now = 1;  // (experiment, off by default: DESIGN.md section 5, round 5)
-            } else {
-                ctx->reserve_now = (int)ctx->xcd_reserve;  // explicit: that many XCDs for the whole factorisation
-            }
-            ctx->reserve_by_cu_now = cu_ok && ctx->reserve_now > 0 && rest > ctx->cu_reserve_min_rows;
-        }
+        set_reservation(rest, kb2);
         const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
         if (own_next && !la_on_panel) {
@@ -1649,6 +1661,7 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
     // append whose new diagonal blocks turn out ill-conditioned is repeated with iterative refinement (the policy of
     // assemble_and_factor; the estimates come from the re-aligned inverse blocks).
     bool readback_ok = false;
+    int64_t ext_inv512_before = -1, ext_invbig_before = -1;  // what the caches covered before an append extended them (-1: it did not)
     if (!ctx->readback && hipHostMalloc(&ctx->readback, 4096, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         ctx->readback = nullptr;  // (falls back to separate read-backs)
@@ -1660,6 +1673,11 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
         } scope{ctx};
         ctx->refine_now = c->refine;
         c->n = n_old;
+        if (ext_inv512_before >= 0) {  // a repeat: what the first attempt added to the caches described blocks that are rewritten now
+            c->inv512_rows = ext_inv512_before < c->inv512_rows ? ext_inv512_before : c->inv512_rows;
+            c->invbig_rows = ext_invbig_before < c->invbig_rows ? ext_invbig_before : c->invbig_rows;
+            ext_inv512_before = ext_invbig_before = -1;
+        }
         const int64_t ld = c->ld_a;
         double* A21 = c->A + n_old;               // nb_new x n_old
         double* A22 = c->A + n_old + n_old * ld;  // nb_new x nb_new
@@ -1746,11 +1764,19 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
         // upload of the new inputs -- ~250 us of idle GPU per add_samples(512), measured on a kernel trace.)
         const int64_t b_lo = n_old / IB, b_hi = (n_all + IB - 1) / IB;
         readback_ok = ctx->readback && (size_t)(b_hi - b_lo + 1) * sizeof(double) <= 4096;
-        if (readback_ok) {
-            FR_HIP(ctx, hipMemsetAsync(c->info + 2, 0, sizeof(int64_t), ctx->stream));
-            FR_TRY(launch_diag_check_zero(ctx, c->A + n_old + n_old * ld, nb_new, ld, c->info + 2));
-            FR_HIP(ctx, hipMemcpyAsync(ctx->readback, c->info + 2, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-            FR_HIP(ctx, hipMemcpyAsync((double*)ctx->readback + 1, c->cest + b_lo, sizeof(double) * (size_t)(b_hi - b_lo), hipMemcpyDeviceToHost, ctx->stream));
+        if (readback_ok) FR_TRY(launch_append_status(ctx, c->A + n_old + n_old * ld, nb_new, ld, c->cest + b_lo, b_hi - b_lo, (double*)ctx->readback));
+        // The inverse-block caches, when they are in use (the append's own L21 solve took them), are extended over the new rows
+        // IN FRONT of the synchronisation: the few small launches queue behind the Schur block's factorisation while the host
+        // still has its hands free, instead of one by one behind the synchronisation with the GPU idle between them (66 us of
+        // gaps per add_samples(512) on round 5's kernel trace).  They only read what the append has written; should the append
+        // be repeated (a timed-out hand-off, an ill-conditioned block) the caches are cut back to the old rows first.
+        if (!c->refine && c->inv512_rows > 0) {
+            const int64_t inv512_before = c->inv512_rows, invbig_before = c->invbig_rows;
+            const int st2 = ensure_inv512(ctx, c, FR_PROF_GEMM_PANEL);
+            if (st2 == FR_OK && invbig_before > 0) (void)ensure_invbig(ctx, c, FR_PROF_GEMM_PANEL);
+            ext_inv512_before = inv512_before;
+            ext_invbig_before = invbig_before;
+            (void)hipGetLastError();
         }
         FR_TRY(comm_stream_sync(ctx, ctx->stream, "add_rows"));  // (sharded: the stream holds an all-gather -- bounded wait)
         return check_status_word(ctx);
@@ -1794,13 +1820,9 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
             if (st != FR_OK) c->n = n_old;
         }
     }
-    if (st == FR_OK && !c->refine && c->inv512_rows > 0) {
-        // The inverse-block caches are in use (the append's own L21 solve took them): extend them over the new rows NOW, behind
-        // the synchronisation -- the few small launches run while the host is on its way back to the caller and into the next
-        // call (~80 us of idle GPU per append on the trace) instead of in front of the next solve.  Best effort: a failure
-        // here only leaves the extension to that solve.
-        const int st2 = ensure_inv512(ctx, c, FR_PROF_GEMM_PANEL);
-        if (st2 == FR_OK && c->invbig_rows > 0) (void)ensure_invbig(ctx, c, FR_PROF_GEMM_PANEL);
+    if (st != FR_OK && ext_inv512_before >= 0) {  // (a failed append leaves the old factor: so do its caches)
+        c->inv512_rows = ext_inv512_before < c->inv512_rows ? ext_inv512_before : c->inv512_rows;
+        c->invbig_rows = ext_invbig_before < c->invbig_rows ? ext_invbig_before : c->invbig_rows;
     }
     return st;
 }

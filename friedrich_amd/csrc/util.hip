@@ -302,6 +302,23 @@ __global__ void diag_zero_kernel(const double* A, int64_t n, int64_t lda, int64_
     if (i < n && A[i + i * lda] == 0.0) flag[0] = 1;
 }
 
+// What fr_chol_add_rows reads back after an append, in ONE launch that writes pinned host memory directly: out[0] (as int64) = is
+// any diagonal entry of the n new rows zero, out[1 ..] = the conditioning estimates of the nb diagonal blocks that changed (round
+// 4: a memset, this check, two device-to-host copies -- 25 us of launches on the tail of every append)
+__global__ __launch_bounds__(256) void append_status_kernel(const double* A, int64_t n, int64_t lda, const double* cest, int64_t nb, double* out)
+{
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (A[i + i * lda] == 0.0) mine = 1;
+    if (mine) any = 1;  // (benign race: every writer writes 1)
+    __syncthreads();
+    if (threadIdx.x == 0) reinterpret_cast<int64_t*>(out)[0] = any;
+    for (int64_t b = threadIdx.x; b < nb; b += blockDim.x) out[1 + b] = cest[b];
+}
+
 __global__ __launch_bounds__(256) void sum_log_abs_kernel(const double* v, int64_t n, double* out)
 {
     __shared__ double red[4];
@@ -456,6 +473,13 @@ int launch_diag_check_zero(fr_ctx* ctx, const double* A, int64_t n, int64_t lda,
 {
     if (n <= 0) return FR_OK;
     hipLaunchKernelGGL(diag_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->ls, A, n, lda, flag);
+    FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int launch_append_status(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, const double* cest, int64_t nb, double* host_out)
+{
+    hipLaunchKernelGGL(append_status_kernel, dim3(1), dim3(256), 0, ctx->ls, A, n, lda, cest, nb, host_out);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
 }

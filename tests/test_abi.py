@@ -79,3 +79,23 @@ def test_synth_generator_is_deterministic():
     X2, y2, Xq2 = synth.make_problem(64, 3, cfg=2, m=5)
     assert np.array_equal(X, X2) and np.array_equal(y, y2) and np.array_equal(Xq, Xq2)
     assert X.flags.f_contiguous and X.shape == (64, 3) and Xq.shape == (5, 3)
+
+
+def test_binding_passes_leading_rows_of_a_column_major_matrix_without_a_copy():
+    """The ABI takes pointer + leading dimension (EMatrix::as_matrix has ld = capacity, extendable_matrix.rs:52-55): the ctypes
+    binding hands the leading rows of a column-major matrix over as they lie (fr_chol_add_rows gets the caller's whole matrix
+    on every call; a host copy per call was 45 us of configs[4]'s 1.1 ms per append), and still copies what is not column-major."""
+    import numpy as np
+
+    from friedrich_amd.device import _Mat
+
+    X = np.asfortranarray(np.arange(40.0).reshape(8, 5))
+    v = _Mat(X[:6])
+    assert (v.rows, v.cols, v.ld) == (6, 5, 8) and v.ptr == X.ctypes.data
+    full = _Mat(X)
+    assert (full.rows, full.cols, full.ld) == (8, 5, 8) and full.ptr == X.ctypes.data
+    c = _Mat(np.ascontiguousarray(X)[:6])  # row-major rows: copied into column-major
+    assert (c.rows, c.cols, c.ld) == (6, 5, 6) and c.ptr != X.ctypes.data
+    assert np.array_equal(c.keep, X[:6])
+    one = _Mat(X[:6, :1])  # a single column: ld is irrelevant, any layout
+    assert (one.rows, one.cols) == (6, 1)
