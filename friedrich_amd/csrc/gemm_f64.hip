@@ -497,7 +497,13 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     // workgroups pay while the large tiles would not fill those CUs either -- with 1 XCD and small tiles for up to 64 large
     // ones the fit at N = 8192 went from 9.1 to 10.2 ms)
     int64_t small_max = ctx->small_tiles;
-    if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip && ctx->ls == ctx->stream2 && small_max > 32 * ctx->reserve_now) small_max = 32 * ctx->reserve_now;
+    {
+        // (by CUs the panel stream's workgroups go to the reserved CUs of ALL XCDs, two or three to a CU: 32-row tiles pay for up to
+        // 64 large tiles per reserved unit -- N = 8192 6.56 -> 6.43 ms, in-process A/B of 32 / 64 / 128)
+        static const int cu_cap = getenv("FRIEDRICH_AMD_CU_SMALL_CAP") ? atoi(getenv("FRIEDRICH_AMD_CU_SMALL_CAP")) : 64;
+        const int64_t cap = (cu_reserve_active(ctx) ? (int64_t)cu_cap : 32) * ctx->reserve_now;
+        if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip && ctx->ls == ctx->stream2 && small_max > cap) small_max = cap;
+    }
     const bool small = (small_max > 0 && !d.lower && !d.tri && d.M > BMS && d.D != d.B /* in place over op(B) needs ONE tile row */ &&
                         g.tiles_m * g.tiles_n * (d.batch > 1 ? d.batch : 1) <= small_max) ||
                        (d.force_small && !d.lower && d.M > BMS && d.D != d.B);
