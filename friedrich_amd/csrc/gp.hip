@@ -278,11 +278,13 @@ static int fr_posterior_impl(fr_chol* c, const fr_kprog* kernel, const double* y
     // mean = prior + W^T y   (mod.rs:387-388)
     FR_TRY(init_with_prior(ctx, mean.dev, prior_q, m));
     FR_TRY(launch_gemv_t(ctx, W, c->n, m, q.ldk, ys.dev, 1.0, 1.0, mean.dev));
+    // (the covariance goes to its own device image here and travels to the host at the END, with the mean and the factor: a
+    // commit in this place -- a device-to-host copy and a synchronisation -- left the GPU idle for ~110 us in front of the
+    // factorisation of every sample_at(256), round 5's kernel trace of configs[4])
+    Staged cov(ctx);
     if (out_cov) {
-        Staged cov(ctx);
         FR_TRY(cov.out(out_cov, m, m, ldc));
         FR_TRY(launch_copy(ctx, covl.dev, covl.ld, cov.dev, cov.ld, m, m));
-        FR_TRY(cov.commit());
     }
     // MultivariateNormal::new: covariance.cholesky().expect(..).unpack()   (multivariate_normal.rs:56-57)
     int64_t fail_col = -1;
@@ -292,6 +294,7 @@ static int fr_posterior_impl(fr_chol* c, const fr_kprog* kernel, const double* y
     FR_TRY(pst);
     FR_TRY(launch_tri_fill(ctx, covl.dev, m, covl.ld, 0.0));
     FR_TRY(mean.commit());
+    if (out_cov) FR_TRY(cov.commit());
     FR_TRY(covl.commit());
     if (fail_col >= 0)
         return set_err(ctx, FR_NOT_POSITIVE_DEFINITE, "MultivariateNormal: Cholesky decomposition failed! (column %lld)",
