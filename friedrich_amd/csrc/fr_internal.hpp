@@ -101,6 +101,7 @@ struct fr_ctx {
     bool trsv_lds_set = false;
     bool trsmn_lds_set = false;
     bool prior_lds_set = false;
+    bool rs16_lds_set = false;
     // profiling
     bool prof = false;
     unsigned prof_mask = ~0u;

@@ -306,12 +306,141 @@ __global__ __launch_bounds__(256, 2) void rows_solve_kernel(const RowsSolveArgs 
     }
 }
 
+// The same sweep with the workgroup's rows RESIDENT in LDS (round 5): 16 rows x kb <= 512 columns (64 KiB) are loaded once, every
+// product of the sweep reads its left operand from there and its right operand -- a 128 x K block of the factor or an inverse
+// block, shared by all workgroups and L2-resident -- as matrix-core fragments straight from memory, eight k-groups ahead; the
+// strip goes back to memory once, at the end.  The generic kernel above pays a store -> drain -> reload round trip through L2
+// between any two of its 2 nblk - 1 dependent products (~17 us each); here a product is its matrix-core time (64 instructions per
+// wave and 128 of contraction: 1.7 us) plus one load latency.  Same arithmetic up to the order of summation (even and odd k-groups go to two accumulators: agreement
+// with the generic kernel to round-off, 4e-16 against numpy in scripts/rows_solve_probe.py).  kb a multiple of 128, at most 512.
+constexpr int RS16_STRIDE = 516;  // doubles per row of the strip (516 mod 32 = 4: rows 0..7 x four k's hit 32 distinct 8-byte banks)
+
+__global__ __launch_bounds__(256) void rows_solve16_kernel(const RowsSolveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double strip[];  // [16][RS16_STRIDE]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int nblk = (int)(a.kb / 128);
+    // load: 16 rows x kb columns (a column is 128 contiguous bytes)
+    {
+        // (eight loads in flight per thread: a loop of one load and one LDS store per trip is a chain of kb / 16 memory latencies)
+        const int r = t & 15;
+        const bool rok = m0 + r < a.rows;
+        const double* src = a.S + (m0 + r) + (int64_t)(t >> 4) * a.lds_;
+        double* dst = strip + r * RS16_STRIDE + (t >> 4);
+        for (int64_t cb = 0; cb < a.kb; cb += 128) {  // 16 columns per trip of the 256 threads, eight trips per block of 128
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = rok ? src[(cb + 16 * i) * a.lds_] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[cb + 16 * i] = v[i];
+        }
+    }
+    __syncthreads();
+    const double* srow = strip + l15 * RS16_STRIDE + lq;  // this lane's left-operand element of k-group j: srow[4 j]
+    // The sweep as ONE sequence of batches of D = 32 k-groups (128 of contraction): sub-panel s has s batches of its update
+    // (acc = S[:, 0 .. c0) L[c0 + n, 0 .. c0)^T, then S_s -= acc) and one batch of its solve (acc = S_s W_s^T, then S_s = acc).
+    // The right-operand fragments of batch i + 1 are requested slot by slot right behind the use of batch i's -- across the
+    // boundaries between products too, where the strip is written back and the waves synchronise: the sweep is bound by the
+    // latency of those loads (~2 us from a remote L2 / the Infinity Cache), not by the matrix core (17 us for the whole sweep).
+    constexpr int D = 32;
+    const int nbatch = nblk * (nblk + 1) / 2;
+    auto batch_ptr = [&](int it, int& sub, int& upd_batch) -> const double* {  // -> this lane's first fragment element of batch `it`
+        int sb = 0;
+        while ((sb + 1) * (sb + 2) / 2 <= it) ++sb;
+        const int r = it - sb * (sb + 1) / 2;
+        sub = sb;
+        upd_batch = r < sb ? r : -1;  // -1: the solve
+        if (r < sb) return a.L + (128 * sb + 32 * wave + l15) + (int64_t)(128 * r + lq) * a.ldl;
+        return a.dinv + (int64_t)sb * (128 * 128) + (32 * wave + l15) + (int64_t)lq * 128;
+    };
+    double rb0[D], rb1[D];
+    {
+        int sb, ub;
+        const double* p = batch_ptr(0, sb, ub);
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            rb0[u] = p[(int64_t)(4 * u) * 128];
+            rb1[u] = p[16 + (int64_t)(4 * u) * 128];
+        }
+    }
+    // (FOUR accumulator chains -- even and odd k-groups of the two tiles, added at the end of a product: a matrix-core instruction
+    // that depends on the one before it on the same accumulator cannot issue back to back)
+    d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0}, acc0b = {0.0, 0.0, 0.0, 0.0}, acc1b = {0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < nbatch; ++it) {
+        int sb, ub, nsb = 0, nub = 0;
+        (void)batch_ptr(it, sb, ub);
+        const bool more = it + 1 < nbatch;
+        const double* np = more ? batch_ptr(it + 1, nsb, nub) : a.dinv;
+        const int64_t nld = (more && nub >= 0) ? a.ldl : 128;
+        const int c0 = 128 * sb;
+        const double* left = ub >= 0 ? srow + 128 * ub : srow + c0;
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const double av = left[4 * u];
+            if (u & 1) {
+                acc0b = __builtin_amdgcn_mfma_f64_16x16x4f64(rb0[u], av, acc0b, 0, 0, 0);
+                acc1b = __builtin_amdgcn_mfma_f64_16x16x4f64(rb1[u], av, acc1b, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(rb0[u], av, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(rb1[u], av, acc1, 0, 0, 0);
+            }
+            if (more) {
+                rb0[u] = np[(int64_t)(4 * u) * nld];
+                rb1[u] = np[16 + (int64_t)(4 * u) * nld];
+            }
+        }
+        const bool upd_done = ub >= 0 && ub == sb - 1, solve_done = ub < 0;
+        if (upd_done || solve_done) {
+            __syncthreads();  // every wave has read what it needs of sub-panel sb before anybody overwrites it
+            acc0 += acc0b;
+            acc1 += acc1b;
+            acc0b = d4_t{0.0, 0.0, 0.0, 0.0};
+            acc1b = d4_t{0.0, 0.0, 0.0, 0.0};
+            double* out = strip + l15 * RS16_STRIDE + c0 + 32 * wave + lq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (upd_done) {
+                    out[4 * r] = out[4 * r] - acc0[r];
+                    out[16 + 4 * r] = out[16 + 4 * r] - acc1[r];
+                } else {
+                    out[4 * r] = acc0[r];
+                    out[16 + 4 * r] = acc1[r];
+                }
+            }
+            acc0 = d4_t{0.0, 0.0, 0.0, 0.0};
+            acc1 = d4_t{0.0, 0.0, 0.0, 0.0};
+            __syncthreads();
+        }
+    }
+    {
+        const int r = t & 15;
+        if (m0 + r < a.rows) {
+            double* dst = a.S + (m0 + r) + (int64_t)(t >> 4) * a.lds_;
+            const double* src = strip + r * RS16_STRIDE + (t >> 4);
+            for (int64_t c = 0; c < a.kb; c += 16) dst[c * a.lds_] = src[c];
+        }
+    }
+}
+
 int launch_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const double* L, int64_t ldl, int64_t kb, const double* dinv)
 {
     if (rows <= 0 || kb <= 0) return FR_OK;
     RowsSolveArgs a;
     a.S = S; a.lds_ = lds_; a.rows = rows; a.L = L; a.ldl = ldl; a.kb = kb; a.dinv = dinv;
     ProfScope ps(ctx, FR_PROF_GEMM_PANEL, (double)rows * (double)kb * (double)kb, 8.0 * 2.0 * (double)rows * (double)kb);
+    static const int rs16 = getenv("FRIEDRICH_AMD_ROWS_SOLVE16") ? atoi(getenv("FRIEDRICH_AMD_ROWS_SOLVE16")) : 1;
+    if (rs16 && kb % 128 == 0 && kb <= 512) {
+        const size_t lds_bytes = sizeof(double) * 16 * RS16_STRIDE;
+        if (!ctx->rs16_lds_set) {  // (66 KB: above the default dynamic-LDS limit)
+            FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rows_solve16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            ctx->rs16_lds_set = true;
+        }
+        hipLaunchKernelGGL(rows_solve16_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), lds_bytes, ctx->ls, a);
+        FR_HIP(ctx, hipGetLastError());
+        return FR_OK;
+    }
     hipLaunchKernelGGL(rows_solve_kernel, dim3((unsigned)((rows + BMS - 1) / BMS)), dim3(256), 0, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
     return FR_OK;
@@ -664,3 +793,13 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
 }
 
 }  // namespace fr
+
+// Developer hook (not part of the ABI, not declared in friedrich_amd.h): the one-launch panel-row solve by itself, for
+// scripts/rows_solve_probe.py.  S (rows x kb, device) <- S L^-T against a factored kb x kb block L and its 128-block inverses.
+extern "C" int fr_debug_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const double* L, int64_t ldl, int64_t kb, const double* dinv)
+{
+    if (!ctx) return FR_INVALID_ARGUMENT;
+    FR_LOCK(ctx);
+    FR_HIP(ctx, hipSetDevice(ctx->device));
+    return fr::launch_rows_solve(ctx, S, lds_, rows, L, ldl, kb, dinv);
+}

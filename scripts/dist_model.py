@@ -54,14 +54,16 @@ print(f"   kernel time per factorisation: potf2 {1e3 * p['potf2']['ms'] / 10:.0f
 A512, B512, C512 = cm(nb, nb), cm(nb, nb), cm(nb, nb)
 print(f"u1 / LA1 (512 x 512 x 512 product): {best(lambda: ctx.gemm(A512, B512, C512, trans_b=True, alpha=-1.0, beta=1.0)):.0f} us")
 # R1 / slice solves: 4 sub-panels, S_s <- (S_s - S_<s L^T) W_s^T
+import ctypes
+ctx.lib.fr_debug_rows_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_void_p]
 def solve_rows(rows):
-    Sx, L, Wi = cm(rows, nb), cm(nb, nb), cm(128, 128)
+    """the library's own one-launch kernel (round 5: through the developer hook fr_debug_rows_solve; rounds 3 and 4 priced this
+    term with seven separate products).  Timings of random operands: the kernel's time does not depend on the values"""
+    Sx, L, Wi = cm(rows, nb), cm(nb, nb), cm(128, 4 * 128)
     def run():
-        for s in range(4):
-            c0 = 128 * s
-            if s:
-                ctx.gemm(Sx[:, :c0], L[c0:c0 + 128, :c0], Sx[:, c0:c0 + 128], trans_b=True, alpha=-1.0, beta=1.0)
-            ctx.gemm(Sx[:, c0:c0 + 128], Wi, Sx[:, c0:c0 + 128], trans_b=True)  # (out of place here; in place in the library)
+        st = ctx.lib.fr_debug_rows_solve(ctx.h, Sx.data_ptr(), rows, rows, L.data_ptr(), nb, nb, Wi.data_ptr())
+        assert st == 0
     return best(run)
 print(f"R1 (512 rows against D): {solve_rows(512):.0f} us")
 for k in (0, 8192, 16384, 24576):
