@@ -535,7 +535,10 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
                     // two-unit tier ends at 6144 rows: the panel's products no longer carry idle workgroups, and the trailing
                     // update, which then bounds the step as often as the chain does, gets the CUs)
                     const int64_t rows2 = (cu_ok && remaining > ctx->cu_reserve_min_rows && ctx->reserve_rows2_cu < ctx->reserve_rows2) ? ctx->reserve_rows2_cu : ctx->reserve_rows2;
-                    ctx->reserve_now = remaining <= ctx->reserve_rows4 ? 4 : (remaining <= rows2 ? 2 : (remaining <= ctx->reserve_rows1 ? 1 : 0));
+                    // (... and the one-unit tier at 12288: between 12288 and 16384 rows the trailing update bounds the step, and it
+                    // is faster on the whole chip than on 7 / 8 of it even with the staged diagonal-block kernel next to it)
+                    const int64_t rows1 = (cu_ok && ctx->reserve_rows1_cu < ctx->reserve_rows1) ? ctx->reserve_rows1_cu : ctx->reserve_rows1;
+                    ctx->reserve_now = remaining <= ctx->reserve_rows4 ? 4 : (remaining <= rows2 ? 2 : (remaining <= rows1 ? 1 : 0));
                 }
                 else if (remaining <= ctx->xcd_reserve_big_rows) ctx->reserve_now = 1;  // (experiment, off by default: DESIGN.md section 5, round 5)
             } else {

@@ -548,6 +548,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->reserve_rows2_cu = value;
         return FR_OK;
     }
+    if (!strcmp(name, "reserve_rows1_cu")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "reserve_rows1_cu must be >= 0");
+        ctx->reserve_rows1_cu = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "reserve_rows1") || !strcmp(name, "reserve_rows2") || !strcmp(name, "reserve_rows4")) {
         if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "reserve_rows* must be >= 0");
         (name[12] == '1' ? ctx->reserve_rows1 : (name[12] == '2' ? ctx->reserve_rows2 : ctx->reserve_rows4)) = value;

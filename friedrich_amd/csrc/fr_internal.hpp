@@ -113,6 +113,7 @@ struct fr_ctx {
     double prof_bytes[FR_PROF_COUNT] = {0};
     int64_t xcd_reserve_big_rows = 0;  // experiment (scripts/headline_ab.py): with panels wider than 512 columns, one XCD is set aside while at most this many rows remain (0: never -- the measured default)
     int64_t reserve_rows1 = 16384, reserve_rows2 = 8192, reserve_rows4 = 4096;  // automatic reservation tiers (nb <= 512): 1 / 2 / 4 units while at most this many rows remain
+    int64_t reserve_rows1_cu = 12288;    // ... the one-unit tier when the reservation is by CUs (N = 16384 / 20480 / 32768: -1.2 / -2.0 / -0.8 % against 16384)
     int64_t reserve_rows2_cu = 6144;     // ... the two-unit tier when the reservation is by CUs (measured: scripts/optset_ab.py)
     int64_t cu_reserve_min_rows = 4096;  // ... while more than this many rows remain (below, the chain's products are too small to saturate anything and gain more from staying inside one or two XCDs' L2)
     bool reserve_by_cu_now = false;  // state: the reservation in force is carried out by CUs

@@ -886,7 +886,7 @@ def test_cu_level_reservation_same_bits(ctx, n):
     try:
         for opts in ({"cu_reserve": 0}, {"cu_reserve": 1, "reserve_rows2_cu": 8192}, {"cu_reserve": 1, "cu_reserve_min_rows": 1024},
                      {"cu_reserve": 1, "xcd_reserve": 1}, {"cu_reserve": 1, "xcd_reserve": 4}, {"cu_reserve": 1}):
-            for o, v in {"cu_reserve": 1, "reserve_rows2_cu": 6144, "cu_reserve_min_rows": 4096, "xcd_reserve": -1, **opts}.items():
+            for o, v in {"cu_reserve": 1, "reserve_rows2_cu": 6144, "reserve_rows1_cu": 12288, "cu_reserve_min_rows": 4096, "xcd_reserve": -1, **opts}.items():
                 ctx.set_option(o, v)
             for rep in range(2):
                 chol.refactor(k, 0.1)
