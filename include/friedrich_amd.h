@@ -96,11 +96,13 @@ void fr_ctx_destroy(fr_ctx* ctx);
 int fr_ctx_set_stream(fr_ctx* ctx, void* hip_stream);
 int fr_ctx_synchronize(fr_ctx* ctx);
 const char* fr_last_error(const fr_ctx* ctx);
-/* Tunables (21 names; everything else the library decides from the problem size):
+/* Tunables (everything else the library decides from the problem size; the tier / threshold knobs of the reservation --
+ *   "reserve_rows1" / "reserve_rows2" / "reserve_rows4" (16384 / 8192 / 4096), "reserve_rows1_cu" / "reserve_rows2_cu" (12288 / 6144),
+ *   "cu_reserve_min_rows" (4096) -- exist for the in-process sweeps of scripts/optset_ab.py):
  *   "nb"             outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
  *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
- *   "xcd_reserve"    -1 (default): while the panel chain bounds a single-GPU factorisation, the trailing update keeps off
+ *   "xcd_reserve"    -1 (default): while the panel chain bounds a single-GPU factorisation (from the first panel on), the trailing update keeps off
  *                    the panel stream's XCDs (1 XCD below 16384 trailing rows, 2 below 8192, 4 below 4096, nb <= 512 only: DESIGN.md
  *                    section 5); 0: never; 1..4: that many XCDs for the whole factorisation
  *   "cu_reserve"     how the reservation above is carried out.  0: whole XCDs -- the trailing update's workgroups retire on
