@@ -107,7 +107,8 @@ const char* fr_last_error(const fr_ctx* ctx);
  *                    section 5); 0: never; 1..4: that many XCDs for the whole factorisation
  *   "cu_reserve"     how the reservation above is carried out.  0: whole XCDs -- the trailing update's workgroups retire on
  *                    the reserved XCDs, the panel stream's launches carry 8 / R times the workgroups and only those dealt to the
- *                    reserved XCDs work;  1: R CUs of every shader engine of every XCD (the same number of CUs) -- the trailing
+ *                    reserved XCDs work;  1 (default; above 4096 trailing rows, with the tiers at 12288 / 6144 rows): R CUs of every shader
+ *                    engine of every XCD (the same number of CUs) -- the trailing
  *                    update runs as resident workgroups that claim tiles and vacate those CUs, the panel stream's launches need
  *                    no idle workgroups (which otherwise wait for a slot on the busy XCDs: DESIGN.md section 5, round 5)
  *   "xcd_reserve_big_rows" 0 (default: never): with panels wider than 512 columns, one XCD is set aside while at most this many
