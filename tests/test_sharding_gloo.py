@@ -498,3 +498,57 @@ def test_grad_chunks_and_add_rows_slices_cover_everything_once():
             width, sl_ = sharding.add_rows_slices(nb_new, world)
             got = [r for lo, rows in sl_ for r in range(lo, lo + rows)]
             assert got == list(range(nb_new)) and all(rows <= width for _, rows in sl_)
+
+
+# ---- one rendezvous primitive on the control plane (round-4 advisor finding: barrier against all_gather_object) ----------------
+def _worker_rendezvous(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import datetime
+    import json
+
+    import torch.distributed as dist
+
+    from friedrich_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
+    link = sharding.TorchLink(dist, rank, world, ctl)
+    log = []
+    # round 1: rank 0's step fails before the rendezvous of the timed region; rank 1 is already waiting in it
+    if rank == 0:
+        log.append(list(sharding.agree(link, False, "step failed")))
+    else:
+        try:
+            sharding.sync_point(link)
+            log.append("passed")
+        except sharding.PeerFailure as e:
+            log.append(["peer", str(e)])
+    # round 2: both healthy -- a plain barrier on one side meets a sync_point on the other (same primitive underneath)
+    if rank == 0:
+        link.barrier()
+        log.append("barrier")
+    else:
+        sharding.sync_point(link)
+        log.append("sync")
+    # round 3: both report, one of them a failure
+    log.append(list(sharding.agree(link, rank == 0, None if rank == 0 else "late failure")))
+    with open(os.path.join(out_dir, f"r{rank}.json"), "w") as f:
+        json.dump(log, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_control_plane_rendezvous_is_one_primitive(tmp_path):
+    import json
+
+    import torch.multiprocessing as tmp_mp
+
+    world = 2
+    port = 36100 + (os.getpid() % 2000)
+    tmp_mp.spawn(_worker_rendezvous, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (json.load(open(tmp_path / f"r{r}.json")) for r in range(world))
+    assert r0[0] == [False, "rank 0: step failed"] and r1[0] == ["peer", "rank 0: step failed"]
+    assert r0[1] == "barrier" and r1[1] == "sync"
+    assert r0[2] == [False, "rank 1: late failure"] and r1[2] == [False, "rank 1: late failure"]
