@@ -137,7 +137,10 @@ struct GradArgs {
     const double* alpha;
     const double* Kinv;
     int64_t ldk;
-    double inv_scale;  // 1/scale (scaled variant) or 1
+    const double* ya;  // device: y . alpha -- the scaled variant divides the alpha alpha^T term by scale = y . alpha / n (optimizer.rs:174); formed
+                       // per thread from this word, so that the host does not have to read it back (a synchronisation) in front of the launch
+    double nd;         // n as a double
+    int scaled;
     double alpha_w;    // weight of the alpha_i alpha_j term: 1; sharded: 1 on rank 0, 0 elsewhere (Kinv is then a rank's PARTIAL of K^-1)
     int ng;
     double* partials;  // [nblocks][ng]
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void grad_reduce_kernel(const GradArgs a)
         __syncthreads();
     }
     constexpr int NG = LEAF >= 0 ? leaf_ng(LEAF) : MAXG;
+    const double inv_scale = a.scaled ? 1.0 / (a.ya[0] / a.nd) : 1.0;  // (the host's two divisions, in the same order)
     double acc[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) acc[q] = 0.0;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void grad_reduce_kernel(const GradArgs a)
                 (void)leaf_grad_k<LEAF>(a.prog.ops[0], s[h][b], u[h][b], gv);
                 const double kinv = in ? a.Kinv[gi + gj * a.ldk] : 0.0;
                 const double w = (gi == gj) ? 1.0 : 2.0;
-                const double coef = w * (ai[h] * aj * a.inv_scale * a.alpha_w - kinv);
+                const double coef = w * (ai[h] * aj * inv_scale * a.alpha_w - kinv);
 #pragma unroll
                 for (int q = 0; q < NG; ++q)
                     if (in) acc[q] += coef * gv[q];
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void grad_reduce_kernel(const GradArgs a)
                     double gv[MAXG];
                     const int ng = kprog_grad(a.prog, s[h][0], u[h][0], gv);
                     const double w = (gi == gj) ? 1.0 : 2.0;
-                    const double coef = w * (ai[h] * a.alpha[gj] * a.inv_scale * a.alpha_w - a.Kinv[gi + gj * a.ldk]);
+                    const double coef = w * (ai[h] * a.alpha[gj] * inv_scale * a.alpha_w - a.Kinv[gi + gj * a.ldk]);
 #pragma unroll
                     for (int q = 0; q < MAXG; ++q)
                         if (q < ng) acc[q] += coef * gv[q];
@@ -418,13 +422,9 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
     FR_HIP(ctx, hipMemcpyAsync(ydev, alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     FR_TRY(trsm_lower_fwd(ctx, c, n, alpha, 1, ld, FR_PROF_GEMM_SOLVE));
     FR_TRY(trsm_lower_bwd(ctx, c, n, alpha, 1, ld, FR_PROF_GEMM_SOLVE));
-    // scale = y . alpha / n (optimizer.rs:174)
+    // scale = y . alpha / n (optimizer.rs:174): y . alpha stays on the device until the end (round 5: reading it back here was a
+    // synchronisation in the middle of every optimizer iteration)
     FR_TRY(launch_col_dot(ctx, ydev, ld, alpha, ld, n, 1, outs + ng + 2));
-    double h_ya = 0.0;
-    FR_HIP(ctx, hipMemcpyAsync(&h_ya, outs + ng + 2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    FR_TRY(check_status_word(ctx));  // (the alpha solves are persistent kernels)
-    const double scale = h_ya / (double)n;
     // K2: fused reductions over the lower triangle
     const int64_t nbk = (n + GR_M - 1) / GR_M;
     const int64_t nblocks = nbk * (nbk + 1);
@@ -434,7 +434,9 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
     a.prog = *kernel;
     a.X = c->X; a.n = n; a.ldx = c->ld_x; a.d = c->d;
     a.alpha = alpha; a.Kinv = Kinv; a.ldk = ld;
-    a.inv_scale = scaled ? 1.0 / scale : 1.0;
+    a.ya = outs + ng + 2;
+    a.nd = (double)n;
+    a.scaled = scaled ? 1 : 0;
     a.alpha_w = (sharded && me != 0) ? 0.0 : 1.0;
     a.ng = ng;
     a.partials = partials;
@@ -469,7 +471,8 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
                            (const double*)Kinv, ld, (const double*)alpha, n, outs);
         FR_HIP(ctx, hipGetLastError());
     }
-    double h[MAXG + 2];
+    double h[MAXG + 3];
+    double h_ya = 0.0;
     if (sharded) {
         // every rank's partials, summed in rank order (the same bits on every rank); alpha . alpha is rank 0's
         if (Wn > 64) return set_err(ctx, FR_INVALID_ARGUMENT, "more than 64 ranks");
@@ -484,10 +487,14 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
             for (int r = 0; r < Wn; ++r) h[q] += hh[(size_t)r * cnt + q];
         }
         h[ng + 1] = hh[(size_t)ng + 1];
+        FR_HIP(ctx, hipMemcpy(&h_ya, outs + ng + 2, sizeof(double), hipMemcpyDeviceToHost));
     } else {
-        FR_HIP(ctx, hipMemcpyAsync(h, outs, sizeof(double) * (size_t)(ng + 2), hipMemcpyDeviceToHost, ctx->stream));
+        FR_HIP(ctx, hipMemcpyAsync(h, outs, sizeof(double) * (size_t)(ng + 3), hipMemcpyDeviceToHost, ctx->stream));
         FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        h_ya = h[ng + 2];
     }
+    FR_TRY(check_status_word(ctx));  // (the alpha solves are persistent kernels)
+    const double scale = h_ya / (double)n;
     // one entry per DECLARED parameter: the reference allocates nb_parameters() matrices and zips them POSITIONALLY with
     // the gradient vector (algebra/mod.rs:135-151), so trailing entries without a value stay NaN (Multiquadric)
     for (int q = 0; q < np; ++q) out_grad[q] = (q < ng) ? h[q] : std::nan("");
