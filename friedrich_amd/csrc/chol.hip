@@ -1297,13 +1297,26 @@ int chol_alloc(fr_ctx* ctx, int64_t n, int64_t capacity, int64_t d, fr_chol** ou
     return FR_OK;
 }
 
-int chol_fetch_info(fr_chol* c)
+// with_cest: the conditioning estimates of the diagonal blocks come back behind the SAME synchronisation (round 5: they used to be a
+// second read-back with a synchronisation of its own -- ~40 us of idle GPU per factorisation, 8 % of an optimizer iteration at N = 512)
+int chol_fetch_info(fr_chol* c, bool with_cest)
 {
     fr_ctx* ctx = c->ctx;
     int64_t head[3] = {0, 0, 0};
     FR_HIP(ctx, hipMemcpyAsync(head, c->info, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
+    const int64_t nblk = (c->n + IB - 1) / IB;
+    std::vector<double> hc;
+    if (with_cest && nblk > 0 && c->cest) {
+        hc.resize((size_t)nblk);
+        FR_HIP(ctx, hipMemcpyAsync(hc.data(), c->cest, sizeof(double) * (size_t)nblk, hipMemcpyDeviceToHost, ctx->stream));
+    }
     FR_TRY(comm_stream_sync(ctx, ctx->stream, "the sharded factorisation"));  // (single rank: a plain hipStreamSynchronize)
     FR_TRY(check_status_word(ctx));  // a bounded device-side wait of the factorisation (hand-offs, counted tiles) gave up
+    if (with_cest) {
+        c->max_cest = 0.0;
+        for (double v : hc)
+            if (v > c->max_cest) c->max_cest = v;  // (NaN: a failed block, reported through fail_col)
+    }
     c->fail_col = head[0] - 1;
     c->n_subst = head[1];
     if (c->n_subst < 0 || c->n_subst > c->n) {
@@ -1460,12 +1473,8 @@ static int assemble_and_factor_once(fr_chol* c, const fr_kprog* kernel, double n
     FR_HIP(ctx, hipMemsetAsync(c->cest, 0, sizeof(double) * (size_t)((c->capacity + IB - 1) / IB), ctx->stream));
     FR_TRY(launch_gram_sym(ctx, *kernel, c->X, c->n, c->ld_x, c->d, noise * noise, c->A, c->ld_a, ctx->world, ctx->rank, c->nb));
     FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true));
-    FR_TRY(chol_fetch_info(c));
-    if (ctx->world > 1) {
-        FR_TRY(merge_info(c));  // (also the largest conditioning estimate over every rank's blocks)
-    } else {
-        FR_TRY(fetch_max_cest(c));
-    }
+    FR_TRY(chol_fetch_info(c, ctx->world <= 1));
+    if (ctx->world > 1) FR_TRY(merge_info(c));  // (also the largest conditioning estimate over every rank's blocks)
     if (c->fail_col >= 0)
         return set_err(ctx, FR_NOT_POSITIVE_DEFINITE,
                        has_eps ? "Cholesky decomposition failed even though we used `cholesky_epsilon` value of %g (column %lld)"
@@ -1614,8 +1623,7 @@ int fr_chol_from_matrix(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, in
             ctx->refine_now = false;
             ctx->cur_cest = nullptr;
         }
-        if (st == FR_OK) st = chol_fetch_info(c);
-        if (st == FR_OK) st = fetch_max_cest(c);
+        if (st == FR_OK) st = chol_fetch_info(c, true);
         if (st == FR_OK && attempt == 0 && ctx->refine == -1 && !c->refine && c->max_cest > ctx->refine_threshold) {
             c->refine = true;
             continue;

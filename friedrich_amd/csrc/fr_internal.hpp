@@ -467,6 +467,6 @@ int chol_tri_inverse(fr_ctx* ctx, const fr_chol* c, double* W, int64_t ldw, doub
 // B (k1 x m) <- L11^-T B with L11 the LEADING k1 x k1 block of the factor (k1 a multiple of 512, or the whole factor); stream-ordered paths only
 int trsm_lower_bwd_leading(fr_ctx* ctx, const fr_chol* c, int64_t k1, double* B, int64_t m, int64_t ldb, int prof_cls);
 int chol_alloc(fr_ctx* ctx, int64_t n, int64_t capacity, int64_t d, fr_chol** out);
-int chol_fetch_info(fr_chol* c);
+int chol_fetch_info(fr_chol* c, bool with_cest = false);
 
 }  // namespace fr
