@@ -256,3 +256,40 @@ def test_config3_full_size_sharded_over_eight_ranks():
         assert err < 1e-12, err
         assert info["n_subst"] == 0 and info["fail_col"] == -1
     assert rel_err(np.concatenate([r[2] for r in res]), mean_ref) < 1e-10
+
+
+@pytest.mark.parametrize("kb", [128, 256, 384, 512, 200])
+@pytest.mark.parametrize("rows", [16, 100, 512, 1000])
+def test_panel_row_solve_kernels_match_numpy(kb, rows):
+    """The one-launch panel-row solve of the sharded schedules (R1, slice solves): S <- S L^-T against a factored kb x kb block and
+    its 128-block inverses, through the developer hook fr_debug_rows_solve.  kb a multiple of 128: rows_solve16_kernel (the
+    workgroup's 16 rows resident in LDS, round 5), ragged row counts included; otherwise the generic item-loop kernel."""
+    import ctypes
+
+    import torch
+
+    from friedrich_amd.device import Context
+
+    ctx = Context()
+    lib = ctx.lib
+    lib.fr_debug_rows_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_void_p]
+    rng = np.random.default_rng(kb + rows)
+    A = rng.standard_normal((kb, kb))
+    L = np.linalg.cholesky(A @ A.T + kb * np.eye(kb))
+    nblk = (kb + 127) // 128
+    W = np.zeros((128, 128 * nblk))  # block s (ld 128, column-major) = inverse of the s-th diagonal block, zero-padded
+    for s in range(nblk):
+        c0, cs = 128 * s, min(128, kb - 128 * s)
+        W[:cs, c0:c0 + cs] = np.linalg.inv(L[c0:c0 + cs, c0:c0 + cs])
+    S0 = rng.standard_normal((rows, kb))
+    want = np.linalg.solve(L, S0.T).T
+    dev = torch.device("cuda:0")
+    cm = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)  # column-major image: element (i, j) at i + j * rows
+    Sd, Ld, Wd = cm(S0), cm(L), cm(W)
+    st = lib.fr_debug_rows_solve(ctx.h, Sd.data_ptr(), rows, rows, Ld.data_ptr(), kb, kb, Wd.data_ptr())
+    assert st == 0
+    ctx.synchronize()
+    got = Sd.cpu().numpy().T
+    assert rel_err(got, want) < 1e-12
+    ctx.close()
