@@ -42,6 +42,15 @@ def test_throughput_kernels_do_not_spill():
             assert v["Occupancy"] >= 2, (name, v)
             checked += 1
     assert checked == 9, sorted(r)
+    # the resident variants of round 5 (a loop around the tile function): the loop costs per-lane address arithmetic that is hoisted
+    # out of it and reloaded at the start of a tile -- 100 B of scratch per lane, none of it inside the K-loop (ISA inspected);
+    # more than that means the accumulators or the prefetch registers have started to spill.  Two workgroups per CU as well.
+    persist = {n: v for n, v in r.items() if "persist" in n}
+    assert len(persist) == 2, sorted(r)
+    for name, v in persist.items():
+        assert v["ScratchSize"] <= 128 and v["Occupancy"] >= 2, (name, v)
+    rs16 = [v for n, v in r.items() if "rows_solve16" in n]
+    assert rs16 and rs16[0]["ScratchSize"] == 0, rs16  # (the LDS-resident panel-row solve keeps 64 fragment registers in flight)
     g = resources("gram.hip")
     leaf = [v for n, v in g.items() if "gram_kernel" in n and "ILi1ELi2" in n]  # the squared-exponential leaf of the bench
     assert leaf and all(v["ScratchSize"] == 0 for v in leaf), g
