@@ -315,26 +315,28 @@ __global__ __launch_bounds__(256, 2) void rows_solve_kernel(const RowsSolveArgs 
 // with the generic kernel to round-off, 4e-16 against numpy in scripts/rows_solve_probe.py).  kb a multiple of 128, at most 512.
 constexpr int RS16_STRIDE = 516;  // doubles per row of the strip (516 mod 32 = 4: rows 0..7 x four k's hit 32 distinct 8-byte banks)
 
-__global__ __launch_bounds__(256) void rows_solve16_kernel(const RowsSolveArgs a)
+template <int NW>  // waves per workgroup: 4 (two 16-column tiles of a sub-panel per wave) or 8 (one)
+__global__ __launch_bounds__(64 * NW) void rows_solve16_kernel(const RowsSolveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double strip[];  // [16][RS16_STRIDE]
+    constexpr int NT = 64 * NW, CPT = NT / 16, TPW = 8 / NW, CW = 16 * TPW;  // threads, columns per trip of the loaders, tiles / columns per wave
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int64_t m0 = (int64_t)blockIdx.x * 16;
     const int nblk = (int)(a.kb / 128);
     // load: 16 rows x kb columns (a column is 128 contiguous bytes)
     {
-        // (eight loads in flight per thread: a loop of one load and one LDS store per trip is a chain of kb / 16 memory latencies)
+        // (several loads in flight per thread: a loop of one load and one LDS store per trip is a chain of kb / CPT memory latencies)
         const int r = t & 15;
         const bool rok = m0 + r < a.rows;
         const double* src = a.S + (m0 + r) + (int64_t)(t >> 4) * a.lds_;
         double* dst = strip + r * RS16_STRIDE + (t >> 4);
-        for (int64_t cb = 0; cb < a.kb; cb += 128) {  // 16 columns per trip of the 256 threads, eight trips per block of 128
-            double v[8];
+        for (int64_t cb = 0; cb < a.kb; cb += 128) {
+            double v[128 / CPT];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = rok ? src[(cb + 16 * i) * a.lds_] : 0.0;
+            for (int i = 0; i < 128 / CPT; ++i) v[i] = rok ? src[(cb + CPT * i) * a.lds_] : 0.0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dst[cb + 16 * i] = v[i];
+            for (int i = 0; i < 128 / CPT; ++i) dst[cb + CPT * i] = v[i];
         }
     }
     __syncthreads();
@@ -352,20 +354,20 @@ __global__ __launch_bounds__(256) void rows_solve16_kernel(const RowsSolveArgs a
         const int r = it - sb * (sb + 1) / 2;
         sub = sb;
         upd_batch = r < sb ? r : -1;  // -1: the solve
-        if (r < sb) return a.L + (128 * sb + 32 * wave + l15) + (int64_t)(128 * r + lq) * a.ldl;
-        return a.dinv + (int64_t)sb * (128 * 128) + (32 * wave + l15) + (int64_t)lq * 128;
+        if (r < sb) return a.L + (128 * sb + CW * wave + l15) + (int64_t)(128 * r + lq) * a.ldl;
+        return a.dinv + (int64_t)sb * (128 * 128) + (CW * wave + l15) + (int64_t)lq * 128;
     };
-    double rb0[D], rb1[D];
+    double rb0[D], rb1[TPW == 2 ? D : 1];
     {
         int sb, ub;
         const double* p = batch_ptr(0, sb, ub);
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             rb0[u] = p[(int64_t)(4 * u) * 128];
-            rb1[u] = p[16 + (int64_t)(4 * u) * 128];
+            if constexpr (TPW == 2) rb1[u] = p[16 + (int64_t)(4 * u) * 128];
         }
     }
-    // (FOUR accumulator chains -- even and odd k-groups of the two tiles, added at the end of a product: a matrix-core instruction
+    // (even and odd k-groups go to accumulator chains of their own, added at the end of a product: a matrix-core instruction
     // that depends on the one before it on the same accumulator cannot issue back to back)
     d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0}, acc0b = {0.0, 0.0, 0.0, 0.0}, acc1b = {0.0, 0.0, 0.0, 0.0};
     for (int it = 0; it < nbatch; ++it) {
@@ -381,14 +383,14 @@ __global__ __launch_bounds__(256) void rows_solve16_kernel(const RowsSolveArgs a
             const double av = left[4 * u];
             if (u & 1) {
                 acc0b = __builtin_amdgcn_mfma_f64_16x16x4f64(rb0[u], av, acc0b, 0, 0, 0);
-                acc1b = __builtin_amdgcn_mfma_f64_16x16x4f64(rb1[u], av, acc1b, 0, 0, 0);
+                if constexpr (TPW == 2) acc1b = __builtin_amdgcn_mfma_f64_16x16x4f64(rb1[u], av, acc1b, 0, 0, 0);
             } else {
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(rb0[u], av, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(rb1[u], av, acc1, 0, 0, 0);
+                if constexpr (TPW == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(rb1[u], av, acc1, 0, 0, 0);
             }
             if (more) {
                 rb0[u] = np[(int64_t)(4 * u) * nld];
-                rb1[u] = np[16 + (int64_t)(4 * u) * nld];
+                if constexpr (TPW == 2) rb1[u] = np[16 + (int64_t)(4 * u) * nld];
             }
         }
         const bool upd_done = ub >= 0 && ub == sb - 1, solve_done = ub < 0;
@@ -398,15 +400,15 @@ __global__ __launch_bounds__(256) void rows_solve16_kernel(const RowsSolveArgs a
             acc1 += acc1b;
             acc0b = d4_t{0.0, 0.0, 0.0, 0.0};
             acc1b = d4_t{0.0, 0.0, 0.0, 0.0};
-            double* out = strip + l15 * RS16_STRIDE + c0 + 32 * wave + lq;
+            double* out = strip + l15 * RS16_STRIDE + c0 + CW * wave + lq;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (upd_done) {
                     out[4 * r] = out[4 * r] - acc0[r];
-                    out[16 + 4 * r] = out[16 + 4 * r] - acc1[r];
+                    if constexpr (TPW == 2) out[16 + 4 * r] = out[16 + 4 * r] - acc1[r];
                 } else {
                     out[4 * r] = acc0[r];
-                    out[16 + 4 * r] = acc1[r];
+                    if constexpr (TPW == 2) out[16 + 4 * r] = acc1[r];
                 }
             }
             acc0 = d4_t{0.0, 0.0, 0.0, 0.0};
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void rows_solve16_kernel(const RowsSolveArgs a
         if (m0 + r < a.rows) {
             double* dst = a.S + (m0 + r) + (int64_t)(t >> 4) * a.lds_;
             const double* src = strip + r * RS16_STRIDE + (t >> 4);
-            for (int64_t c = 0; c < a.kb; c += 16) dst[c * a.lds_] = src[c];
+            for (int64_t c = 0; c < a.kb; c += CPT) dst[c * a.lds_] = src[c];
         }
     }
 }
@@ -434,10 +436,14 @@ int launch_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const 
     if (rs16 && kb % 128 == 0 && kb <= 512) {
         const size_t lds_bytes = sizeof(double) * 16 * RS16_STRIDE;
         if (!ctx->rs16_lds_set) {  // (66 KB: above the default dynamic-LDS limit)
-            FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rows_solve16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rows_solve16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rows_solve16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             ctx->rs16_lds_set = true;
         }
-        hipLaunchKernelGGL(rows_solve16_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), lds_bytes, ctx->ls, a);
+        if (rs16 == 4)  // (A/B: four waves with two tiles each -- 45.5 us against 42.8 for eight waves with one)
+            hipLaunchKernelGGL(rows_solve16_kernel<4>, dim3((unsigned)((rows + 15) / 16)), dim3(256), lds_bytes, ctx->ls, a);
+        else
+            hipLaunchKernelGGL(rows_solve16_kernel<8>, dim3((unsigned)((rows + 15) / 16)), dim3(512), lds_bytes, ctx->ls, a);
         FR_HIP(ctx, hipGetLastError());
         return FR_OK;
     }
