@@ -363,19 +363,43 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
     const int Wn = ctx->world, me = ctx->rank;
     const bool sharded = Wn > 1 && n >= ctx->grad_shard_min && n >= 1024 && !c->refine;
     const int64_t cs = n >= 8192 ? 2048 : 512;  // rows per chunk
-    WsGuard wg(ctx), kg(ctx), vg(ctx), pg(ctx);
+    WsGuard wg(ctx), kg(ctx), vg(ctx), pg(ctx), yg(ctx);
     double* W = wg.get(sizeof(double) * (size_t)ld * (size_t)(sharded ? cs : n));
     double* Kinv = kg.get(sizeof(double) * (size_t)ld * (size_t)n);
     double* vec = vg.get(sizeof(double) * (size_t)(ld + (MAXG + 8) * 66));
-    if (sharded) {
-        bool all_ok = true;
-        FR_TRY(comm_agree(ctx, W && Kinv && vec, &all_ok));
-        if (W && Kinv && vec && !all_ok) return set_err(ctx, FR_OUT_OF_MEMORY, "a peer rank could not allocate its gradient workspace");
+    double* ydev = yg.get(sizeof(double) * (size_t)ld);
+    const int64_t nbk = (n + GR_M - 1) / GR_M;
+    const int64_t nblocks = nbk * (nbk + 1);
+    double* partials = pg.get(sizeof(double) * (size_t)(nblocks * (ng > 0 ? ng : 1)));
+    const bool have = W && Kinv && vec && ydev && partials;
+    if (!have) {
+        bool all_ok = false;
+        if (sharded) (void)comm_agree(ctx, false, &all_ok);  // (the peers must not wait for this rank's partials)
+        return FR_OUT_OF_MEMORY;
     }
-    if (!W || !Kinv || !vec) return FR_OUT_OF_MEMORY;
     double* alpha = vec;
     double* outs = vec + ld;  // [ng] gradient halves, trace, alpha.alpha, y.alpha; sharded: followed by every rank's ng + 2
+    // alpha = K^-1 y (optimizer.rs:33, 171) -- first: these are the only persistent kernels of the call, and when sharded a
+    // timed-out hand-off must send this rank into its repeat (solve_retry) BEFORE it has taken part in any collective, so that
+    // every rank issues each collective of the call exactly once
+    {
+        const bool dev = is_device_ptr(y);
+        FR_HIP(ctx, hipMemcpyAsync(alpha, y, sizeof(double) * (size_t)n, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                   ctx->stream));
+        if (!dev) FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    FR_HIP(ctx, hipMemcpyAsync(ydev, alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    FR_TRY(trsm_lower_fwd(ctx, c, n, alpha, 1, ld, FR_PROF_GEMM_SOLVE));
+    FR_TRY(trsm_lower_bwd(ctx, c, n, alpha, 1, ld, FR_PROF_GEMM_SOLVE));
+    // scale = y . alpha / n (optimizer.rs:174): y . alpha stays on the device until the end (round 5: reading it back here was a
+    // synchronisation in the middle of every optimizer iteration)
+    FR_TRY(launch_col_dot(ctx, ydev, ld, alpha, ld, n, 1, outs + ng + 2));
     if (sharded) {
+        FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FR_TRY(check_status_word(ctx));
+        bool all_ok = true;
+        FR_TRY(comm_agree(ctx, true, &all_ok));
+        if (!all_ok) return set_err(ctx, FR_OUT_OF_MEMORY, "a peer rank could not allocate its gradient workspace");
         const int64_t nc = (n + cs - 1) / cs;
         FR_HIP(ctx, hipMemsetAsync(Kinv, 0, sizeof(double) * (size_t)ld * (size_t)n, ctx->ls));
         for (int64_t t = 0; t < nc; ++t) {  // t-th largest chunk
@@ -394,9 +418,8 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
             FR_TRY(launch_gemm(ctx, g));
         }
     } else {
-    // K8: W = L^-1 (strict upper triangle of W is exactly zero), Kinv = W^T W (lower triangle)
-    FR_TRY(chol_tri_inverse(ctx, c, W, ld, Kinv, FR_PROF_GEMM_SOLVE));  // (Kinv's buffer is the scratch: it is written next)
-    {
+        // K8: W = L^-1 (strict upper triangle of W is exactly zero), Kinv = W^T W (lower triangle)
+        FR_TRY(chol_tri_inverse(ctx, c, W, ld, Kinv, FR_PROF_GEMM_SOLVE));  // (Kinv's buffer is the scratch: it is written next)
         GemmDesc g;
         const bool tri = ctx->tri_inverse != 0 && n > 2048;  // (small cases: few tiles, cut along K instead -- launch_gemm)
         g.dynamic = tri;  // the tiles' contractions differ in length: claimed, not dealt
@@ -408,28 +431,7 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
         g.alpha = 1.0; g.beta = 0.0; g.lower = true; g.prof_cls = FR_PROF_GEMM_SOLVE;
         FR_TRY(launch_gemm(ctx, g));
     }
-    }
-    // alpha = K^-1 y (optimizer.rs:33, 171)
-    {
-        const bool dev = is_device_ptr(y);
-        FR_HIP(ctx, hipMemcpyAsync(alpha, y, sizeof(double) * (size_t)n, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                   ctx->stream));
-        if (!dev) FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    WsGuard yg(ctx);
-    double* ydev = yg.get(sizeof(double) * (size_t)ld);
-    if (!ydev) return FR_OUT_OF_MEMORY;
-    FR_HIP(ctx, hipMemcpyAsync(ydev, alpha, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
-    FR_TRY(trsm_lower_fwd(ctx, c, n, alpha, 1, ld, FR_PROF_GEMM_SOLVE));
-    FR_TRY(trsm_lower_bwd(ctx, c, n, alpha, 1, ld, FR_PROF_GEMM_SOLVE));
-    // scale = y . alpha / n (optimizer.rs:174): y . alpha stays on the device until the end (round 5: reading it back here was a
-    // synchronisation in the middle of every optimizer iteration)
-    FR_TRY(launch_col_dot(ctx, ydev, ld, alpha, ld, n, 1, outs + ng + 2));
     // K2: fused reductions over the lower triangle
-    const int64_t nbk = (n + GR_M - 1) / GR_M;
-    const int64_t nblocks = nbk * (nbk + 1);
-    double* partials = pg.get(sizeof(double) * (size_t)(nblocks * (ng > 0 ? ng : 1)));
-    if (!partials) return FR_OUT_OF_MEMORY;
     GradArgs a;
     a.prog = *kernel;
     a.X = c->X; a.n = n; a.ldx = c->ld_x; a.d = c->d;
