@@ -418,6 +418,8 @@ def run_rank(args, link, device_index, emit, mode):
             "config": {
                 "workload": f"GP fit (Gram + Cholesky) + predict, N={n} d={d} RBF, m={m} queries, friedrich default hyper-parameters",
                 "n": n, "d": d, "m": m, "kernel": "squared_exp", "nb": nb_eff,
+                "panel_widths": ("2048 while more than 22528 rows remain, 1024 down to 16384, then 512" if (args.nb == 0 and nb_eff == 1024)
+                                 else f"{nb_eff}" + (" down to 16384 rows, then 512" if (nb_eff > 512 and world == 1) else "")),
                 "parallelism": parallelism,
             },
             "fit_ms": float(np.mean(fit_ms)),

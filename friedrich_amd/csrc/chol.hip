@@ -16,7 +16,7 @@
 //        it can safely run in place.
 //   512  leaves of the solves of the predict family: explicit inverses of the 512 x 512 diagonal blocks, assembled on
 //        demand from the 128-block inverses by batched GEMMs (fr_chol::inv512).
-//   nb   outer block (pick_nb: 1024 at N >= 24576 on one GPU, else 512): the trailing update A22 -= P P^T is one
+//   nb   outer block (pick_nb: 1024 at N >= 24576 on one GPU -- 2048 while more than 22528 rows remain -- else 512): the trailing update A22 -= P P^T is one
 //        lower-triangular SYRK launch with K = nb, the dominant FP64-MFMA kernel (n^3/3 of the flops).
 // Solves pick their kernels by the number of right-hand sides: <= 16 memory-bound kernels (L streamed once), otherwise
 // the recursive GEMM formulation.
@@ -492,9 +492,12 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     // Panel width per step.  Fixed (nb) except on a single GPU with nb > 512 (the automatic choice at large n): nb columns while the
     // trailing update dominates (each pass over the trailing matrix costs a read and a write of it whatever its depth), 512
     // once the panel chain does -- from there on the factorisation is the one of an n = nb_switch_rows matrix, XCD
-    // reservation (nb <= 512) included.
+    // reservation (nb <= 512) included.  With the automatic nb = 1024 the first panels are 2048 wide while more than nb_big_rows
+    // rows remain: there one pass over the trailing matrix is > 4 GB of traffic and half as many of them is worth more than
+    // the longer panels cost (in-process A/B, N = 30720 / 32768: 157.0 -> 155.4 / 188.4 -> 185.4 ms; neutral at 24576 / 26624).
     auto width = [&](int64_t remaining) -> int64_t {
         if (world == 1 && nb > 512 && ctx->nb_switch_rows > 0 && remaining <= ctx->nb_switch_rows) return imin(512, remaining);
+        if (world == 1 && ctx->nb == 0 && nb == 1024 && ctx->nb_big_rows > 0 && remaining > ctx->nb_big_rows) return imin(2048, remaining);
         return imin(nb, remaining);
     };
     const int64_t kb0 = width(n);

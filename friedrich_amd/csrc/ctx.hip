@@ -528,6 +528,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->lookahead = value != 0;
         return FR_OK;
     }
+    if (!strcmp(name, "nb_big_rows")) {
+        if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "nb_big_rows must be >= 0");
+        ctx->nb_big_rows = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "nb_switch_rows")) {
         if (value < 0) return set_err(ctx, FR_INVALID_ARGUMENT, "nb_switch_rows must be >= 0");
         ctx->nb_switch_rows = value;

@@ -68,6 +68,7 @@ struct fr_ctx {
     // ---- options (fr_ctx_set_option) ----
     int64_t nb = 0;             // outer Cholesky block; 0 = chosen from the matrix size (pick_nb)
     int64_t lookahead = 1;      // the next panel is factored on the panel stream under the trailing update
+    int64_t nb_big_rows = 22528;     // automatic nb = 1024 only: panels of 2048 columns while more than this many rows remain (0: never)
     int64_t nb_switch_rows = 16384;  // automatic nb = 1024: panels of 512 columns once at most this many rows remain (0: never)
     // XCD reservation (gemm_f64.hip): the main stream's GEMM launches of a factorisation leave the first `reserve_now` XCDs
     // (counted from the one the diagonal-block kernels run on) to the panel stream -- their workgroups there exit at once

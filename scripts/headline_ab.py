@@ -19,9 +19,10 @@ ls = ctx.mean_pairwise_distance(X)
 hp = synth.default_hyperparameters(X, y, ls)
 k = ("squared_exp", hp["ls"], hp["ampl"])
 chol = ctx.cholesky_from_inputs(k, X, hp["noise"], capacity_hint=n)
-DEFAULTS = {"nb": 0, "xcd_reserve_big_rows": 0, "k4_flat": -1, "nb_switch_rows": 16384}
+DEFAULTS = {"nb": 0, "xcd_reserve_big_rows": 0, "k4_flat": -1, "nb_switch_rows": 16384, "nb_big_rows": 22528}
 VARIANTS = [
-    ("default (nb 1024 -> 512 below 16384 rows)", {}),
+    ("default (panels 2048 wide above 22528 rows, 1024 above 16384, then 512)", {}),
+    ("nb 1024 -> 512 below 16384 rows (nb_big_rows = 0: the default before)", {"nb_big_rows": 0}),
     ("nb = 1536", {"nb": 1536}),
     ("nb = 2048", {"nb": 2048}),
     ("nb = 2048, 512 below 8192 rows", {"nb": 2048, "nb_switch_rows": 8192}),

@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 from friedrich_amd import synth
 from friedrich_amd.device import Context
 
-RESET = {"cu_reserve": 1, "reserve_rows2_cu": 6144, "reserve_rows1_cu": 12288, "cu_reserve_min_rows": 4096, "reserve_rows1": 16384, "reserve_rows2": 8192, "reserve_rows4": 4096, "k4_flat": -1, "xcd_reserve": -1, "nb": 0, "xcd_reserve_big_rows": 0, "nb_switch_rows": 16384,
+RESET = {"nb_big_rows": 22528, "cu_reserve": 1, "reserve_rows2_cu": 6144, "reserve_rows1_cu": 12288, "cu_reserve_min_rows": 4096, "reserve_rows1": 16384, "reserve_rows2": 8192, "reserve_rows4": 4096, "k4_flat": -1, "xcd_reserve": -1, "nb": 0, "xcd_reserve_big_rows": 0, "nb_switch_rows": 16384,
          "lookahead": 1, "splitk": 1}
 ctx = Context()
 variants = []

@@ -30,7 +30,7 @@ for W in "fit32k|python scripts/fit_only.py 32768 2" "config2|python scripts/con
   rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/${tag}_sq -o q -- $cmd > /dev/null 2>&1
 done
 cp $(find gpurun_out/fit32k_stats -name "*kernel_stats.csv" | head -1) $O/fit32k_kernel_stats.csv
-python scripts/summarise_counters.py fit32k $O/fit32k_counters.json "two fits (Gram + blocked Cholesky) at N=32768 d=16 RBF nb=1024, scripts/fit_only.py 32768 2, one rocprofv3 --pmc pass per counter group" | head -5
+python scripts/summarise_counters.py fit32k $O/fit32k_counters.json "two fits (Gram + blocked Cholesky) at N=32768 d=16 RBF, automatic panel widths (2048 / 1024 / 512), scripts/fit_only.py 32768 2, one rocprofv3 --pmc pass per counter group" | head -5
 python scripts/summarise_counters.py config2 $O/config2_counters.json "BASELINE configs[2]: N=16384 d=16 Matern-5/2 + cholesky_epsilon, fit x3 + predict(m=1024) x2 + predict_variance x2 (scripts/config_run.py 2), one rocprofv3 --pmc pass per counter group" | head -8
 rm -rf $O/*_stats gpurun_out/fit32k_* gpurun_out/config2_*
 ls $O

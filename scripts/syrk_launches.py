@@ -3,15 +3,15 @@ rate of each (the bench line's roofline fraction is their flop-weighted average)
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kind"] == "KERNEL_DISPATCH" and "syrk_lower" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[-46:]
 n = 32768
-# panel widths: 1024 while more than 16384 rows remain after the panel, then 512
+# the library's rule (chol.hip, width()): 2048-column panels while more than 22528 rows remain, 1024 down to 16384, then 512
 k = 0; out = []
 widths = []
 rem = n
 while rem > 0:
-    w = 512 if rem <= 16384 else 1024  # the library's rule: 512-column panels once at most 16384 rows remain
+    w = 512 if rem <= 16384 else (2048 if rem > 22528 else 1024)
     w = min(w, rem); widths.append(w); rem -= w
+rows = rows[-(len(widths) - 2):]  # one trailing update per panel but the last two (the last one's is part of the look-ahead update)
 # SYRK j uses K = widths[j], result = rows after panel j+1
 pos = 0
 tot_f = tot_t = 0
