@@ -149,7 +149,7 @@ def run_rank(args, link, device_index, emit, mode):
     log = (lambda msg: print(f"bench.py: {msg}", file=sys.stderr, flush=True)) if rank == 0 else (lambda msg: None)
     ctx = Context(device_index)
     ctx.set_option("nb", args.nb)
-    nb_eff = args.nb if args.nb > 0 else (1024 if (world == 1 and args.n >= 24576) else 512)
+    nb_eff = args.nb if args.nb > 0 else (1024 if (world == 1 and args.n >= 18432) else 512)
     sharded = world > 1 or mode == "process_forced"
 
     # ---- N > 1: pick the schedule behind a preflight, under the library's watchdog -------------------------------------

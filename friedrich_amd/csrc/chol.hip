@@ -16,7 +16,7 @@
 //        it can safely run in place.
 //   512  leaves of the solves of the predict family: explicit inverses of the 512 x 512 diagonal blocks, assembled on
 //        demand from the 128-block inverses by batched GEMMs (fr_chol::inv512).
-//   nb   outer block (pick_nb: 1024 at N >= 24576 on one GPU -- 2048 while more than 22528 rows remain -- else 512): the trailing update A22 -= P P^T is one
+//   nb   outer block (pick_nb: 1024 at N >= 18432 on one GPU -- 2048 while more than 22528 rows remain -- else 512): the trailing update A22 -= P P^T is one
 //        lower-triangular SYRK launch with K = nb, the dominant FP64-MFMA kernel (n^3/3 of the flops).
 // Solves pick their kernels by the number of right-hand sides: <= 16 memory-bound kernels (L streamed once), otherwise
 // the recursive GEMM formulation.
@@ -1257,7 +1257,9 @@ static void chol_release(fr_chol* c)
 static int64_t pick_nb(const fr_ctx* ctx, int64_t n)
 {
     if (ctx->nb > 0) return ctx->nb;
-    return (ctx->world <= 1 && n >= 24576) ? 1024 : 512;
+    // (round 5, scripts/optset_ab.py, nb = 1024 with 512 below 16384 rows against 512 throughout: N = 17408 / 18432 / 20480 / 22528
+    // 35.4 / 40.8 / 53.6 / 69.7 -> 35.4 / 40.7 / 53.0 / 68.2 ms -- the threshold was 24576 before)
+    return (ctx->world <= 1 && n >= 18432) ? 1024 : 512;
 }
 
 static int chol_alloc_buffers(fr_ctx* ctx, fr_chol* c, int64_t capacity, int64_t d)

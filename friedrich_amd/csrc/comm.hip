@@ -343,6 +343,11 @@ struct LocalGroup {
     LocalPub pubs[2][64];  // double-buffered by barrier generation parity
     bool broken = false;
     bool async = true;
+    // The ranks' ready / done events are destroyed with the GROUP, by the last rank to detach: a peer that is still on its way
+    // from the second rendezvous of an exchange to its hipStreamWaitEvent calls holds the bare handles (LocalPub), and the rank
+    // they belong to may be through its teardown by then (a rank that was descheduled for the milliseconds its peer needs to
+    // finish -- the one crash of the thread-rank tests in round 5's suite runs is attributed to this window).
+    std::vector<hipEvent_t> retired;
 };
 struct LocalComm {
     LocalGroup* g;
@@ -734,8 +739,6 @@ static void comm_release(fr_ctx* ctx, bool abort)
     }
     if (ctx->local) {
         LocalComm* lc = (LocalComm*)ctx->local;
-        if (lc->ready) (void)hipEventDestroy(lc->ready);
-        if (lc->done) (void)hipEventDestroy(lc->done);
         {
             std::lock_guard<std::mutex> lk(g_local_mutex);
             if (abort) {
@@ -743,7 +746,10 @@ static void comm_release(fr_ctx* ctx, bool abort)
                 lc->g->broken = true;
                 lc->g->cv.notify_all();
             }
+            if (lc->ready) lc->g->retired.push_back(lc->ready);
+            if (lc->done) lc->g->retired.push_back(lc->done);
             if (--lc->g->attached == 0) {
+                for (hipEvent_t e : lc->g->retired) (void)hipEventDestroy(e);
                 g_local_groups.erase(lc->group_id);
                 delete lc->g;
             }

@@ -455,6 +455,9 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    // (every stream that may still hold records of the communicator's events, before those go)
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     extern void fr_comm_destroy_internal(fr_ctx*);
     fr_comm_destroy_internal(ctx);
     for (auto& r : ctx->recs) {

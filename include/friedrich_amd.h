@@ -101,7 +101,7 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "cu_reserve_min_rows" (4096) -- exist for the in-process sweeps of scripts/optset_ab.py):
  *   "nb"             outer Cholesky block: 0 (default) = chosen from the matrix size, else a multiple of 128 in [128, 4096]
  *   "nb_switch_rows" 16384 (default): with nb > 512 on one GPU, panels of 512 columns once at most this many rows remain
- *   "nb_big_rows"    22528 (default): with the automatic nb = 1024 (one GPU, N >= 24576), panels of 2048 columns while more than
+ *   "nb_big_rows"    22528 (default): with the automatic nb = 1024 (one GPU, N >= 18432), panels of 2048 columns while more than
  *                    this many rows remain; 0: never
  *   "lookahead"      1 (default): factor the next panel on a second stream under the trailing update
  *   "xcd_reserve"    -1 (default): while the panel chain bounds a single-GPU factorisation (from the first panel on), the trailing update keeps off

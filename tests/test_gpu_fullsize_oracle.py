@@ -218,7 +218,7 @@ def test_config3_whole_n32768_factor_and_m4096_predict_vs_oracle(ctx):
 
 
 def test_large_n_schedule_on_n8192_vs_oracle(ctx):
-    """The schedule of a fit at N >= 24576 -- 1024-column panels while the trailing update dominates, 512-column panels with
+    """The schedule of a fit at N >= 18432 -- 1024-column panels while the trailing update dominates, 512-column panels with
     XCDs set aside for the panel chain over the last rows -- forced onto a matrix the oracle factors in full (N = 8192:
     nb = 1024, switch to 512 columns below 4096 remaining rows): the same factor as the default schedule's, to TOL of the
     oracle's."""

@@ -120,7 +120,7 @@ def test_cholesky_kernels_and_block_sizes(ctx, kernel):
 
 
 def test_cholesky_large_outer_blocks(ctx):
-    # nb = 768 / 1024 (the automatic choice at N >= 24576) with look-ahead active (n > 2 nb), against the oracle
+    # nb = 768 / 1024 (the automatic choice at N >= 18432) with look-ahead active (n > 2 nb), against the oracle
     n = 2600
     kernel = PD_KERNELS[0]
     X = rand_inputs(n, 4, 17)
