@@ -44,6 +44,8 @@ static RcclApi g_rccl;
 
 static int rccl_load(fr_ctx* ctx)
 {
+    static std::mutex load_mutex;  // (contexts of several host threads may attach at the same time)
+    std::lock_guard<std::mutex> lk(load_mutex);
     if (g_rccl.handle) return FR_OK;
     void* h = nullptr;
     if (const char* p = getenv("FRIEDRICH_AMD_RCCL_PATH")) h = dlopen(p, RTLD_NOW | RTLD_GLOBAL);

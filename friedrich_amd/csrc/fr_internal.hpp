@@ -384,6 +384,9 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
 int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v);
 int launch_blockdiag512(fr_ctx* ctx, const double* dinv128, double* w, int64_t nblocks);
 int launch_copy(fr_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (process, device, kernel), under a lock: the contexts of several host
+// threads (thread-ranks, a host's worker threads) share the device's function objects
+int set_dyn_lds(fr_ctx* ctx, const void* fn, int bytes);
 int launch_append_status(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, const double* cest, int64_t nb, double* host_out);  // zero-diagonal flag + estimates -> pinned host memory
 int launch_set_identity(fr_ctx* ctx, double* p, int64_t n, int64_t ld);
 int launch_tri_fill(fr_ctx* ctx, double* p, int64_t n, int64_t ld, double v);            // strict upper := v

@@ -436,8 +436,8 @@ int launch_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const 
     if (rs16 && kb % 128 == 0 && kb <= 512) {
         const size_t lds_bytes = sizeof(double) * 16 * RS16_STRIDE;
         if (!ctx->rs16_lds_set) {  // (66 KB: above the default dynamic-LDS limit)
-            FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rows_solve16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(rows_solve16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(rows_solve16_kernel<4>), (int)lds_bytes));
+            FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(rows_solve16_kernel<8>), (int)lds_bytes));
             ctx->rs16_lds_set = true;
         }
         if (rs16 == 4)  // (A/B: four waves with two tiles each -- 45.5 us against 42.8 for eight waves with one)

@@ -1483,12 +1483,9 @@ int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0,
     if (nbk <= 0) return FR_OK;
     if (nbk > PB) return set_err(ctx, FR_INVALID_ARGUMENT, "potf2 block too large");
     if (!ctx->potf2_lds_set) {  // per context (= per device): the attribute belongs to the device's copy of the kernel
-        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
-        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_uncapped_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS));
-        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_flat_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)flat::LDS_BYTES));
+        FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(potf2_kernel), (int)POTF2_LDS));
+        FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(potf2_uncapped_kernel), (int)POTF2_LDS));
+        FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(potf2_flat_kernel), (int)flat::LDS_BYTES));
         ctx->potf2_lds_set = true;
     }
     static const int force = getenv("FRIEDRICH_AMD_K4_UNCAPPED") ? atoi(getenv("FRIEDRICH_AMD_K4_UNCAPPED")) : -1;

@@ -145,8 +145,7 @@ extern "C" int fr_linear_prior_fit(fr_ctx* ctx, const double* X, int64_t n, int6
     if (n > 0) {
         const size_t lds = sizeof(double) * (size_t)QLD * (size_t)P;
         if (!ctx->prior_lds_set) {  // per context (= per device): the attribute belongs to the device's copy of the kernel
-            FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tsqr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(sizeof(double) * QLD * QP_MAX)));
+            FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(tsqr_kernel), (int)(sizeof(double) * QLD * QP_MAX)));
             ctx->prior_lds_set = true;
         }
         WsGuard g0(ctx), g1(ctx);

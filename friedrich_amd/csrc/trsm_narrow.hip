@@ -697,7 +697,7 @@ int launch_trsm_narrow(fr_ctx* ctx, const fr_chol* cc, double* B, int64_t m, int
     else
     {
         if (!ctx->trsmn_lds_set) {  // per context (= per device): > 64 KiB of dynamic LDS needs the attribute
-            FR_HIP(ctx, hipFuncSetAttribute((const void*)trsm_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSMN_LDS));
+            FR_TRY(set_dyn_lds(ctx, (const void*)trsm_narrow_kernel, (int)TRSMN_LDS));
             ctx->trsmn_lds_set = true;
         }
         hipLaunchKernelGGL(trsm_narrow_kernel, dim3((unsigned)G, (unsigned)ngroups), dim3(NTH), TRSMN_LDS, ctx->ls, a);

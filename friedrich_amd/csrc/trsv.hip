@@ -449,10 +449,8 @@ int launch_trsv(fr_ctx* ctx, const fr_chol* c, double* b, bool fwd, int prof_cls
     int G = nblk < ctx->num_cus ? nblk : ctx->num_cus;
     if (ctx->test_max_wgs > 0 && G > ctx->test_max_wgs) G = ctx->test_max_wgs;
     if (!ctx->trsv_lds_set) {  // per context (= per device): > 64 KiB of dynamic LDS needs the attribute
-        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_fwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSV_LDS));
-        FR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRSV_BWD_LDS));
+        FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(trsv_fwd_kernel), (int)TRSV_LDS));
+        FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(trsv_bwd_kernel), (int)TRSV_BWD_LDS));
         ctx->trsv_lds_set = true;
     }
     ProfScope ps(ctx, prof_cls, (double)n * (double)n, 4.0 * (double)n * (double)n);

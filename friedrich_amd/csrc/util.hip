@@ -2,6 +2,9 @@
 // predict / predict_variance / predict_mean_variance / likelihood (src/gaussian_process/mod.rs:203-219,
 // 241, 266-270, 313-319) and by the factor download paths.
 #include "fr_internal.hpp"
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace fr {
 
@@ -488,6 +491,17 @@ int launch_sum_log_abs(fr_ctx* ctx, const double* v, int64_t n, double* out)
 {
     hipLaunchKernelGGL(sum_log_abs_kernel, dim3(1), dim3(256), 0, ctx->ls, v, n, out);
     FR_HIP(ctx, hipGetLastError());
+    return FR_OK;
+}
+
+int set_dyn_lds(fr_ctx* ctx, const void* fn, int bytes)
+{
+    static std::mutex m;
+    static std::set<std::pair<int, const void*>> done;
+    std::lock_guard<std::mutex> lk(m);
+    if (done.count({ctx->device, fn})) return FR_OK;
+    FR_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({ctx->device, fn});
     return FR_OK;
 }
 
