@@ -21,6 +21,8 @@ def _empty_cm(torch, n, m, dev):
 @pytest.mark.parametrize("name,n,d,kernel_name,eps", [
     ("config2_matern52_eps", 16384, 16, "matern2", 1e-9),   # BASELINE configs[2]
     ("config3_rbf", 32768, 16, "squared_exp", None),          # BASELINE configs[3] (the bench workload)
+    ("between_the_panel_tiers", 20480, 16, "squared_exp", None),  # 1024-column panels for 4096 rows, then 512 (pick_nb's threshold moved to 18432 in round 5)
+    ("first_size_of_the_2048_tier", 23552, 16, "squared_exp", None),  # one 2048-column panel (23552 > 22528 rows), then 1024, then 512
     ("twice_config3", 65536, 16, "squared_exp", None),         # 32 GiB factor: 64-bit indexing, sized for 288 GB of HBM
 ])
 def test_full_size_fit_properties(ctx, name, n, d, kernel_name, eps):
