@@ -38,7 +38,25 @@ sys.path.insert(0, ROOT)
 
 PMC_NB = 1024  # block size of the run profiles/r05/fit32k_counters.json was collected with
 PMC_FILE = os.path.join("profiles", "r05", "fit32k_counters.json")
-PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; scripts/mfma_f64_peak measures 77.0-77.6 on the box
+PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; measured_mfma_peak() times the instruction loop on the box (77.0-77.6)
+MFMA_PEAK_PROBE = os.path.join(ROOT, "friedrich_amd", "lib", "mfma_f64_peak")  # scripts/mfma_f64_peak.hip, built by friedrich_amd/build.py
+
+
+def measured_mfma_peak():
+    """"measured MFMA-loop TFLOP/s on the box AND datasheet; both reported".  Runs the prebuilt instruction
+    loop (v_mfma_f64_16x16x4_f64 back to back, the chip filled at several occupancies) as a process of its own, before the timed
+    region, and returns the best chip-filling rate in TFLOP/s -- None when the helper is missing or fails (never a guess)."""
+    import re
+    import subprocess
+
+    if not os.path.exists(MFMA_PEAK_PROBE):
+        return None
+    try:
+        r = subprocess.run([MFMA_PEAK_PROBE], capture_output=True, text=True, timeout=60)
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    rates = [float(v) for b, v in re.findall(r"blocks=\s*(\d+) waves/block=\d+:\s*([0-9.]+) TFLOP/s", r.stdout) if int(b) >= 256]
+    return max(rates) if rates else None
 
 
 def flops_fit(n, d):
@@ -99,6 +117,9 @@ def strong_cpu_line(n):
                     f"hardware threads) of a {n} x {n} matrix", "seconds": dt, "GFLOP/s": n ** 3 / 3.0 / dt / 1e9, "threads": threads}
 
 
+BENCH_N, BENCH_M = 32768, 4096  # the workload the line is quoted on (what the CPU sample is extrapolated to)
+
+
 def cpu_baseline(n, d, m, cfg):
     """The reference's CPU path (oracle restatement, one thread) on a bounded sample of the workload."""
     from friedrich_amd import synth
@@ -116,7 +137,16 @@ def cpu_baseline(n, d, m, cfg):
     t2 = time.perf_counter()
     fl = flops_fit(n, d) + flops_predict(n, m, d)
     model, cores = host_description()
+    # "time it fully for N <= 8192 and extrapolate ~ n^3 beyond (label as extrapolated)": the wall time the
+    # same single-thread path would need for the bench's own workload, next to the GPU's step time
+    fit_x = (t1 - t0) * (BENCH_N / n) ** 3
+    pred_x = (t2 - t1) * (BENCH_N / n) ** 2 * (BENCH_M / m)
     return {
+        "extrapolated_s_at_n32768": {
+            "fit": fit_x, "predict": pred_x, "step": fit_x + pred_x, "label": "EXTRAPOLATED, not measured",
+            "method": f"fit time x ({BENCH_N}/{n})^3 (n^3/3 dominates), predict time x ({BENCH_N}/{n})^2 x ({BENCH_M}/{m}) (2 n^2 m dominates), "
+                      f"from the timed N={n}, m={m} sample; the N = {BENCH_N} run itself would take hours on one core",
+        },
         "value": fl / (t2 - t0) / 1e9,
         "unit": "GFLOP/s",
         "cores": 1,
@@ -171,6 +201,7 @@ def run_rank(args, link, device_index, emit, mode):
             ctx.set_option("dist_schedule", schedule)
         ctx.set_option("comm_timeout_ms", args.comm_timeout_ms)
 
+    peak_measured = measured_mfma_peak() if (rank == 0 and mode == "solo") else None
     n, d, m = args.n, args.d, args.m
     cfg = 4
     X, y, Xq = synth.make_problem(n, d, cfg=cfg, m=m)
@@ -435,6 +466,10 @@ def run_rank(args, link, device_index, emit, mode):
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,
+                "peak_source": "datasheet (MI355X FP64 matrix, dense)",
+                "peak_measured": peak_measured,
+                "peak_measured_source": "v_mfma_f64_16x16x4_f64 instruction loop on this box before the timed region (scripts/mfma_f64_peak.hip)",
+                "frac_of_measured_peak": (achieved / peak_measured) if peak_measured else None,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                 "traffic": traffic,

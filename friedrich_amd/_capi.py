@@ -109,6 +109,7 @@ SIGNATURES = {
     "fr_predict_covariance": (_int, [_vp, _kp, _dp, _i64, _i64, _dp, _i64]),
     "fr_posterior": (_int, [_vp, _kp, _dp, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _dp, _i64]),
     "fr_gemm": (_int, [_vp, _int, _int, _i64, _i64, _i64, _dbl, _dp, _i64, _dp, _i64, _dbl, _dp, _i64]),
+    "fr_panel_rows_solve": (_int, [_vp, _dp, _i64, _i64, _dp, _i64, _i64, _dp]),
     "fr_mean_pairwise_distance": (_int, [_vp, _dp, _i64, _i64, _i64, _pdbl]),
     "fr_grad_terms": (_int, [_vp, _kp, _dp, _dbl, _int, _pdbl, _pdbl]),
 }

@@ -29,6 +29,20 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _version_script():
+    """Linker version script: the dynamic symbol table holds exactly the functions include/friedrich_amd.h declares."""
+    import re
+
+    hdr = open(os.path.join(ROOT, "include", "friedrich_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(fr_[a-z0-9_]+)\s*\(", hdr)))
+    path = os.path.join(OBJ, "exports.map")
+    text = "{\n  global:\n" + "".join(f"    {n};\n" for n in names) + "  local: *;\n};\n"
+    if not os.path.exists(path) or open(path).read() != text:
+        open(path, "w").write(text)
+    return path
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -55,11 +69,18 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _newer(LIB, objs):
+    vs = _version_script()
+    if force or jobs or _newer(LIB, objs + [vs]):
         # Linked WITHOUT a DT_NEEDED on libamdhip64: the HIP runtime is whichever one the host process already
         # has (torch bundles its own copy; two HSA runtimes in one process cannot both open the GPU).
         # Python: friedrich_amd._capi.load() preloads it; C/C++/Rust hosts link -lamdhip64 themselves.
-        run([CLANGXX, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+        run([CLANGXX, "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB] + objs + ["-ldl", "-lpthread"])
+    # bench.py's measured FP64 matrix-core ceiling: the instruction loop of scripts/mfma_f64_peak.hip as a
+    # small executable next to the library, so that it travels to the GPU box like the built .so
+    probe_src = os.path.join(ROOT, "scripts", "mfma_f64_peak.hip")
+    probe = os.path.join(HERE, "lib", "mfma_f64_peak")
+    if os.path.exists(probe_src) and (force or _newer(probe, [probe_src])):
+        run([HIPCC, "--offload-arch=gfx950", "-O3", "-o", probe, probe_src])
     return LIB
 
 

@@ -1480,6 +1480,7 @@ static int assemble_and_factor_once(fr_chol* c, const fr_kprog* kernel, double n
     FR_TRY(potrf_blocked(ctx, c->A, c->ld_a, c->n, 0, has_eps ? 1 : 0, eps, c->dinv, c->info, c->nb, true));
     FR_TRY(chol_fetch_info(c, ctx->world <= 1));
     if (ctx->world > 1) FR_TRY(merge_info(c));  // (also the largest conditioning estimate over every rank's blocks)
+    c->collective = ctx->world > 1;  // every rank holds this handle: fr_grad_terms / fr_chol_add_rows on it may be collective
     if (c->fail_col >= 0)
         return set_err(ctx, FR_NOT_POSITIVE_DEFINITE,
                        has_eps ? "Cholesky decomposition failed even though we used `cholesky_epsilon` value of %g (column %lld)"
@@ -1797,9 +1798,21 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
         FR_TRY(comm_stream_sync(ctx, ctx->stream, "add_rows"));  // (sharded: the stream holds an all-gather -- bounded wait)
         return check_status_word(ctx);
     };
-    int st = solve_retry(ctx, append);
+    // a failed append leaves the old factor: so do its caches.  Whatever the abandoned attempt queued into the inverse-block caches
+    // described rows that are not part of the factor -- a later append of OTHER rows at the same n_old would find
+    // inv512_rows >= its need and skip the rebuild (advisor finding, round 5): every failing exit cuts them back
+    auto cut_caches_back = [&]() {
+        if (ext_inv512_before >= 0) {
+            c->inv512_rows = ext_inv512_before < c->inv512_rows ? ext_inv512_before : c->inv512_rows;
+            c->invbig_rows = ext_invbig_before < c->invbig_rows ? ext_invbig_before : c->invbig_rows;
+            ext_inv512_before = ext_invbig_before = -1;
+        }
+    };
+    // sharded: the body holds collectives, so a rank must not repeat it on its own (solve_retry: collective = true)
+    int st = solve_retry(ctx, append, ctx->world > 1);
     if (st != FR_OK) {
         c->n = n_old;
+        cut_caches_back();
         return st;
     }
     if (readback_ok) {
@@ -1832,13 +1845,12 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
         }
         if (!c->refine && c->max_cest > ctx->refine_threshold) {
             c->refine = true;  // an ill-conditioned appended block: once more with the refinement step behind every inverse product
-            st = solve_retry(ctx, append);
-            if (st != FR_OK) c->n = n_old;
+            st = solve_retry(ctx, append, ctx->world > 1);
+            if (st != FR_OK) {
+                c->n = n_old;
+                cut_caches_back();
+            }
         }
-    }
-    if (st != FR_OK && ext_inv512_before >= 0) {  // (a failed append leaves the old factor: so do its caches)
-        c->inv512_rows = ext_inv512_before < c->inv512_rows ? ext_inv512_before : c->inv512_rows;
-        c->invbig_rows = ext_invbig_before < c->invbig_rows ? ext_invbig_before : c->invbig_rows;
     }
     return st;
 }

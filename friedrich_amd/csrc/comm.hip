@@ -109,7 +109,8 @@ static inline int64_t now_ms()
 //     the handles:
 //         0                 no guarded sequence
 //         2 * seq           the host thread is inside a guarded sequence, BETWEEN two RCCL calls: it runs, the watchdog keeps off
-//         2 * seq + 1       the host thread is INSIDE an RCCL call (since call_t0)
+//         2 * seq + 1       the host thread is INSIDE an RCCL call (since call_t0); seq is bumped at EVERY enter(), so the word
+//                           names one call, not one sequence
 //         kWatchAborting    the watchdog has taken the handles
 //     The host thread moves 2 seq -> 2 seq + 1 (CallGuard::enter) and back (leave) with compare-and-swaps around EVERY single
 //     RCCL call; the watchdog moves 2 seq + 1 -> kWatchAborting, and only that: it aborts a call that has been in progress
@@ -204,8 +205,15 @@ struct CallGuard {
         if (!w) return true;
         if (lost) return false;
         w->call_t0.store(now_ms());
+        // a FRESH sequence value per call (advisor finding, round 5: with one value per guarded sequence the watchdog could load
+        // "call A in progress", see A past its deadline, and have its compare-and-swap succeed on call B's identical word -- an
+        // ABA that aborted a call which had only just started)
+        const uint64_t fresh = 2 * ++w->seq;
         uint64_t expect = mine;
-        if (w->call.compare_exchange_strong(expect, mine | 1)) return true;
+        if (w->call.compare_exchange_strong(expect, fresh | 1)) {
+            mine = fresh;
+            return true;
+        }
         take_note();
         return false;
     }
@@ -261,6 +269,15 @@ struct GroupGuard {
 // watchdog could only abort the OTHER, healthy communicator).  It therefore runs on a helper thread and this thread waits for
 // it with the deadline (option "comm_timeout_ms"; 0: for ever).  Past the deadline the job is abandoned: the caller gets
 // ncclSystemError at once, and the helper, if RCCL ever lets it go, aborts the communicator it was handed and frees the job.
+// What an abandoned job costs (advisor finding, round 5): a detached thread that may sit inside ncclCommInitRank for ever, holding
+// the device and the g_rccl entry points.  So (i) librccl is never dlclosed (rccl_load keeps the handle for the life of the
+// process), (ii) the abandoned jobs are counted and a process that has kMaxAbandonedInits of them outstanding refuses further
+// attempts at once (FR_RCCL_ERROR) instead of leaking a thread per fall-back of the schedule ladder, (iii) peers whose init DID
+// complete hold a communicator with a rank that never arrived -- their first collective runs into comm_stream_sync's deadline and
+// the context is lost like after any other missing peer.
+constexpr int kMaxAbandonedInits = 8;
+static std::atomic<int> g_abandoned_inits{0};
+
 struct InitJob {
     std::mutex m;
     std::condition_variable cv;
@@ -273,6 +290,7 @@ static ncclResult_t init_rank_bounded(fr_ctx* ctx, ncclComm_t* out, int world, c
 {
     *out = nullptr;
     *timed_out = false;
+    if (g_abandoned_inits.load() >= kMaxAbandonedInits) return ncclSystemError;  // (the caller reports FR_RCCL_ERROR)
     auto job = std::make_shared<InitJob>();
     const int device = ctx->device;
     std::thread([job, device, world, id, rank] {
@@ -281,6 +299,7 @@ static ncclResult_t init_rank_bounded(fr_ctx* ctx, ncclComm_t* out, int world, c
         std::lock_guard<std::mutex> lk(job->m);
         if (job->abandoned) {
             if (r == ncclSuccess && c && g_rccl.CommAbort) (void)g_rccl.CommAbort(c);
+            g_abandoned_inits.fetch_sub(1);  // RCCL let the helper go after all
             return;
         }
         job->comm = r == ncclSuccess ? c : nullptr;
@@ -293,6 +312,7 @@ static ncclResult_t init_rank_bounded(fr_ctx* ctx, ncclComm_t* out, int world, c
     if (T > 0) {
         if (!job->cv.wait_for(lk, std::chrono::milliseconds(T), [&] { return job->done; })) {
             job->abandoned = true;
+            g_abandoned_inits.fetch_add(1);
             *timed_out = true;
             __atomic_fetch_add(&ctx->comm_timeouts, (int64_t)1, __ATOMIC_RELAXED);
             return ncclSystemError;
@@ -764,7 +784,9 @@ static void comm_release(fr_ctx* ctx, bool abort)
     ctx->world = 1;
 }
 
-void fr_comm_destroy_internal(fr_ctx* ctx)
+}  // extern "C"
+
+void fr::comm_destroy_internal(fr_ctx* ctx)
 {
     comm_release(ctx, ctx->comm_lost);
     if (ctx->agree_buf) {
@@ -772,6 +794,8 @@ void fr_comm_destroy_internal(fr_ctx* ctx)
         ctx->agree_buf = nullptr;
     }
 }
+
+extern "C" {
 
 int fr_ctx_comm_finalize(fr_ctx* ctx, int abort)
 {

@@ -458,8 +458,7 @@ void fr_ctx_destroy(fr_ctx* ctx)
     // (every stream that may still hold records of the communicator's events, before those go)
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
-    extern void fr_comm_destroy_internal(fr_ctx*);
-    fr_comm_destroy_internal(ctx);
+    fr::comm_destroy_internal(ctx);
     for (auto& r : ctx->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);

@@ -178,6 +178,10 @@ struct fr_chol {
     int64_t d = 0;  // feature count (0 for fr_chol_from_matrix)
     int64_t ld_x = 0;
     int64_t nb = 256;
+    // the handle came out of a COLLECTIVE factorisation (fr_chol_from_inputs / fr_chol_refactor on a context with a communicator):
+    // every rank holds it, so operations on it may themselves be collective (fr_grad_terms from grad_shard_min rows on).  A handle
+    // that exists on one rank only -- fr_chol_from_matrix, fr_chol_upload_l -- never takes part in a collective (advisor, round 5).
+    bool collective = false;
     double* A = nullptr;
     double* X = nullptr;     // capacity x d training inputs (EMatrix mirror)
     double* dinv = nullptr;  // ceil(capacity/128) explicit inverses of the 128 x 128 diagonal blocks
@@ -370,9 +374,9 @@ struct GemmDesc {
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 // S (rows x kb, ld lds_) <- S L^-T against a factored kb x kb diagonal block and its 128-block inverses: one launch (gemm_f64.hip)
 int launch_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const double* L, int64_t ldl, int64_t kb, const double* dinv);
-int launch_release_xcds(fr_ctx* ctx, unsigned epoch);
+int launch_release_xcds(fr_ctx* ctx, unsigned epoch);  // on ctx->ls: the chain of panel `epoch` is finished
 bool cu_table_ready(fr_ctx* ctx);     // option cu_reserve is set and the chip looks as expected (builds the CU rank table on first use)
-bool cu_reserve_active(fr_ctx* ctx);  // the reservation in force is carried out by CUs  // on ctx->ls: the chain of panel `epoch` is finished
+bool cu_reserve_active(fr_ctx* ctx);  // the reservation in force is carried out by CUs
 
 // K4: factor one diagonal block (nbk <= 128) and emit its explicit inverse (inv may be NULL).
 //   mode 0: fail on non-positive pivot, 1: substitute sqrt(sub), 2: plain sqrt (NaN propagates; add_rows),
@@ -428,13 +432,15 @@ void drain_stale_status(fr_ctx* ctx);
 // word -> check_status_word returns FR_HIP_ERROR and raises ctx->solve_timeout_seen), run the body ONCE more with the
 // persistent kernels switched off: the same solve as a recursion of GEMM launches, which waits for nothing but stream order.
 // The body must be restartable (inputs re-staged from the caller's memory, in-place device operands restored by the caller).
+// collective: the body issues collectives on a sharded context -- a rank that repeated it ALONE would issue them a second time
+// while its peers have moved on (mismatched collectives until the watchdog fires): no solo repeat then, the error stands.
 template <class F>
-int solve_retry(fr_ctx* ctx, F&& body)
+int solve_retry(fr_ctx* ctx, F&& body, bool collective = false)
 {
     drain_stale_status(ctx);
     ctx->solve_timeout_seen = false;
     int st = body();
-    if (st == FR_HIP_ERROR && ctx->solve_timeout_seen && ctx->trsv) {
+    if (st == FR_HIP_ERROR && ctx->solve_timeout_seen && ctx->trsv && !collective) {
         ctx->solve_timeout_seen = false;
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->host_status) ((volatile unsigned*)ctx->host_status)[0] = 0;
@@ -458,6 +464,7 @@ int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok);  // collective: does EVERY r
 void comm_abort(fr_ctx* ctx);                        // failing rank: tear the communicator down so that peers do not wait forever
 int comm_stream_sync(fr_ctx* ctx, hipStream_t s, const char* what);  // wait for a stream that may hold collectives, with the deadline
 void comm_drain(fr_ctx* ctx);                        // after comm_abort: give the context's three streams a bounded time to empty
+void comm_destroy_internal(fr_ctx* ctx);             // fr_ctx_destroy: communicators, watchdog, events (comm.hip)
 int ensure_comm2(fr_ctx* ctx);                       // collective: the second communicator exists on every rank (created on first use)
 
 // ---- blocked algorithms (chol.hip) ------------------------------------------------------------------

@@ -800,9 +800,9 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
 
 }  // namespace fr
 
-// Developer hook (not part of the ABI, not declared in friedrich_amd.h): the one-launch panel-row solve by itself, for
-// scripts/rows_solve_probe.py.  S (rows x kb, device) <- S L^-T against a factored kb x kb block L and its 128-block inverses.
-extern "C" int fr_debug_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const double* L, int64_t ldl, int64_t kb, const double* dinv)
+// The one-launch panel-row solve by itself (friedrich_amd.h: a diagnostic entry like fr_gemm; scripts/rows_solve_probe.py,
+// scripts/dist_model.py, tests/test_gpu_dist.py).  S (rows x kb, device) <- S L^-T against a factored kb x kb block L and its 128-block inverses.
+extern "C" int fr_panel_rows_solve(fr_ctx* ctx, double* S, int64_t lds_, int64_t rows, const double* L, int64_t ldl, int64_t kb, const double* dinv)
 {
     if (!ctx) return FR_INVALID_ARGUMENT;
     FR_LOCK(ctx);

@@ -361,7 +361,7 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
     // in a snake over DESCENDING row ranges (the cost of a chunk grows with the square of where it ends).  Ill-conditioned
     // (refined) handles and small factors: every rank computes the whole, no collective.
     const int Wn = ctx->world, me = ctx->rank;
-    const bool sharded = Wn > 1 && n >= ctx->grad_shard_min && n >= 1024 && !c->refine;
+    const bool sharded = Wn > 1 && c->collective && n >= ctx->grad_shard_min && n >= 1024 && !c->refine;
     const int64_t cs = n >= 8192 ? 2048 : 512;  // rows per chunk
     WsGuard wg(ctx), kg(ctx), vg(ctx), pg(ctx), yg(ctx);
     double* W = wg.get(sizeof(double) * (size_t)ld * (size_t)(sharded ? cs : n));

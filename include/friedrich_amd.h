@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FR_ABI_VERSION 1
+#define FR_ABI_VERSION 2 /* 2: FR_PROF_COUNT = 8; fr_grad_terms collective on collectively created handles */
 
 typedef enum {
     FR_OK = 0,
@@ -142,7 +142,9 @@ const char* fr_last_error(const fr_ctx* ctx);
  *   "tri_inverse"    1 (default): the gradient terms form L^-1 and K^-1 = W^T W skipping the structural zeros
  *   "grad_shard_min" 4096 (default): with a communicator attached, fr_grad_terms of a factor with at least this many rows is split
  *                    over the ranks (row blocks of L^-1 per rank, partial K^-1 and partial reductions, one all-gather of p + 2
- *                    scalars); below, every rank computes the whole.  Every rank must use the same value.
+ *                    scalars); below, every rank computes the whole.  Every rank must use the same value.  Only handles that
+ *                    came out of a collective factorisation (fr_chol_from_inputs / fr_chol_refactor with the communicator
+ *                    attached) are split: a handle one rank made for itself (fr_chol_from_matrix, fr_chol_upload_l) stays local.
  *   "refine"         -1 (default): automatic -- see fr_chol_conditioning; 0: never; 1: always.  "refine_threshold": 30
  *   "predict_assoc"  0 (default): predict as the reference associates it, prior + (K^-1 K*)^T y  (mod.rs:234-241,
  *                    two n x m triangular solves);  1: prior + K*^T (K^-1 y), the same value up to rounding with two
@@ -309,6 +311,13 @@ int fr_posterior(fr_chol* chol, const fr_kprog* kernel, const double* y, const d
  * alias A or B. */
 int fr_gemm(fr_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+/* The rows of a panel against its factored diagonal block, by itself (one step of algebra/mod.rs:81-91's factorisation as the sharded
+ * schedule cuts it, DESIGN.md section 6: R1 and the slice solves):  S (rows x kb, device, leading dimension lds) <- S L^-T  against a
+ * factored kb x kb lower block L (device, ldl) and the explicit inverses of its 128 x 128 diagonal blocks (dinv: block s at
+ * dinv + s * 128 * 128, leading dimension 128), ONE launch.  A diagnostic entry like fr_gemm: probes, tests, the cost model of the
+ * sharded schedule (scripts/dist_model.py). */
+int fr_panel_rows_solve(fr_ctx* ctx, double* S, int64_t lds, int64_t rows, const double* L, int64_t ldl, int64_t kb,
+                        const double* dinv);
 
 /* ---- src/parameters/kernel.rs heuristics ----------------------------------------------------------- */
 /* fit_bandwidth_mean (kernel.rs:94-113): mean Euclidean distance over the n(n-1)/2 row pairs */

@@ -55,14 +55,14 @@ A512, B512, C512 = cm(nb, nb), cm(nb, nb), cm(nb, nb)
 print(f"u1 / LA1 (512 x 512 x 512 product): {best(lambda: ctx.gemm(A512, B512, C512, trans_b=True, alpha=-1.0, beta=1.0)):.0f} us")
 # R1 / slice solves: 4 sub-panels, S_s <- (S_s - S_<s L^T) W_s^T
 import ctypes
-ctx.lib.fr_debug_rows_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+ctx.lib.fr_panel_rows_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_void_p]
 def solve_rows(rows):
-    """the library's own one-launch kernel (round 5: through the developer hook fr_debug_rows_solve; rounds 3 and 4 priced this
+    """the library's own one-launch kernel (round 5: through the developer hook fr_panel_rows_solve; rounds 3 and 4 priced this
     term with seven separate products).  Timings of random operands: the kernel's time does not depend on the values"""
     Sx, L, Wi = cm(rows, nb), cm(nb, nb), cm(128, 4 * 128)
     def run():
-        st = ctx.lib.fr_debug_rows_solve(ctx.h, Sx.data_ptr(), rows, rows, L.data_ptr(), nb, nb, Wi.data_ptr())
+        st = ctx.lib.fr_panel_rows_solve(ctx.h, Sx.data_ptr(), rows, rows, L.data_ptr(), nb, nb, Wi.data_ptr())
         assert st == 0
     return best(run)
 print(f"R1 (512 rows against D): {solve_rows(512):.0f} us")

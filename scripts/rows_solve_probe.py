@@ -13,7 +13,7 @@ from friedrich_amd.device import Context
 
 ctx = Context()
 lib = ctx.lib
-lib.fr_debug_rows_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+lib.fr_panel_rows_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                     ctypes.c_void_p]
 dev = torch.device("cuda:0")
 kb = 512
@@ -28,7 +28,7 @@ for rows in [int(a) for a in sys.argv[1:]] or [512, 1024, 4096]:
     want = np.linalg.solve(Lh, S0.T).T  # S L^-T
     Sd = torch.from_numpy(np.asfortranarray(S0).T.copy()).to(dev)
     def run():
-        st = lib.fr_debug_rows_solve(ctx.h, Sd.data_ptr(), rows, rows, Ld.data_ptr(), kb, kb, Wd.data_ptr())
+        st = lib.fr_panel_rows_solve(ctx.h, Sd.data_ptr(), rows, rows, Ld.data_ptr(), kb, kb, Wd.data_ptr())
         assert st == 0
     run()
     ctx.synchronize()

@@ -1,4 +1,4 @@
-//! Raw bindings to `libfriedrich_amd.so` (include/friedrich_amd.h, FR_ABI_VERSION 1).
+//! Raw bindings to `libfriedrich_amd.so` (include/friedrich_amd.h, FR_ABI_VERSION 2).
 //!
 //! One declaration per export of the header, same order, same argument order; `tests/test_rust_shim.py` parses both files
 //! and fails when they drift.  Nothing here is safe to call directly: `super::device` wraps what friedrich needs.
@@ -14,7 +14,7 @@ pub struct fr_chol {
     _private: [u8; 0],
 }
 
-pub const FR_ABI_VERSION: c_int = 1;
+pub const FR_ABI_VERSION: c_int = 2;
 
 // fr_status
 pub const FR_OK: c_int = 0;
@@ -138,6 +138,8 @@ extern "C" {
                         ldl: i64) -> c_int;
     pub fn fr_gemm(ctx: *mut fr_ctx, trans_a: c_int, trans_b: c_int, m: i64, n: i64, k: i64, alpha: f64, a: *const f64,
                    lda: i64, b: *const f64, ldb: i64, beta: f64, c: *mut f64, ldc: i64) -> c_int;
+    pub fn fr_panel_rows_solve(ctx: *mut fr_ctx, s: *mut f64, lds: i64, rows: i64, l: *const f64, ldl: i64, kb: i64,
+                               dinv: *const f64) -> c_int;
     // ---- src/parameters/kernel.rs heuristics
     pub fn fr_mean_pairwise_distance(ctx: *mut fr_ctx, x: *const f64, n: i64, ldx: i64, d: i64, out: *mut f64) -> c_int;
     // ---- src/parameters/prior.rs

@@ -21,9 +21,17 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 30
     for name in names:
         assert hasattr(lib, name), f"{name} is declared in friedrich_amd.h but not exported"
+    # ... and nothing else: the dynamic symbol table is the header (friedrich_amd/build.py writes the linker's version script from it)
+    import subprocess
+
+    nm = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in nm.splitlines() if line.split()[-2] in ("T", "t", "W") and line.split()[-1].startswith("fr_"))
+    assert exported == names, (set(exported) ^ set(names))
+    others = [line.split()[-1] for line in nm.splitlines() if line.split()[-2] in ("T", "W", "D", "B") and not line.split()[-1].startswith("fr_")]
+    assert not others, others
     # the Python binding declares exactly the header's functions
     assert sorted(_capi.SIGNATURES) == names
-    assert lib.fr_abi_version() == 1
+    assert lib.fr_abi_version() == 2
 
 
 def test_no_gpu_means_no_context():

@@ -262,7 +262,7 @@ def test_config3_full_size_sharded_over_eight_ranks():
 @pytest.mark.parametrize("rows", [16, 100, 512, 1000])
 def test_panel_row_solve_kernels_match_numpy(kb, rows):
     """The one-launch panel-row solve of the sharded schedules (R1, slice solves): S <- S L^-T against a factored kb x kb block and
-    its 128-block inverses, through the developer hook fr_debug_rows_solve.  kb a multiple of 128: rows_solve16_kernel (the
+    its 128-block inverses, through the developer hook fr_panel_rows_solve.  kb a multiple of 128: rows_solve16_kernel (the
     workgroup's 16 rows resident in LDS, round 5), ragged row counts included; otherwise the generic item-loop kernel."""
     import ctypes
 
@@ -272,7 +272,7 @@ def test_panel_row_solve_kernels_match_numpy(kb, rows):
 
     ctx = Context()
     lib = ctx.lib
-    lib.fr_debug_rows_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+    lib.fr_panel_rows_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_void_p]
     rng = np.random.default_rng(kb + rows)
     A = rng.standard_normal((kb, kb))
@@ -287,7 +287,7 @@ def test_panel_row_solve_kernels_match_numpy(kb, rows):
     dev = torch.device("cuda:0")
     cm = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)  # column-major image: element (i, j) at i + j * rows
     Sd, Ld, Wd = cm(S0), cm(L), cm(W)
-    st = lib.fr_debug_rows_solve(ctx.h, Sd.data_ptr(), rows, rows, Ld.data_ptr(), kb, kb, Wd.data_ptr())
+    st = lib.fr_panel_rows_solve(ctx.h, Sd.data_ptr(), rows, rows, Ld.data_ptr(), kb, kb, Wd.data_ptr())
     assert st == 0
     ctx.synchronize()
     got = Sd.cpu().numpy().T
