@@ -78,9 +78,30 @@ static int invert_block128(fr_ctx* ctx, double* A, int64_t ld, int64_t sb, doubl
 // earlier panels.  Recursive halving down to the 128-wide inverse blocks: the second half of the block is updated by
 // the first with ONE GEMM of depth kb/2 (instead of a depth-128 GEMM per 128 columns) -- the read-modify-write of the
 // result tile is a fixed cost per tile, so the deeper the contraction the closer the GEMM runs to the MFMA rate.
+// (the launcher's own shape test, potf2.hip: launch_panel_chain)
+static inline bool panel_chain_fits(const fr_ctx* ctx, int64_t kb, int64_t rows, int mode)
+{
+    return ctx->panel_chain && ctx->trsv && !ctx->refine_now && mode != 3 && kb >= 2 * IB && kb <= 4 * IB && kb % IB == 0 && rows >= kb &&
+           (rows - kb > 512 || 1 + (rows - IB + 15) / 16 <= ctx->num_cus - 8);
+}
+
 static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k, int64_t kb, int64_t col0, int mode,
                         double sub, double* dinv, int64_t* info, double* T)
 {
+    // The resident panel chain (potf2.hip: panel_chain_kernel): the kb x kb diagonal block -- and the rows below it, as many as stay
+    // resident -- in ONE launch instead of kb / 128 diagonal-block kernels and 2 kb / 128 - 1 launch-bound products.  Taken where the
+    // launch has CUs of its own: no second stream (small matrices, the Schur block of an append), the sharded chain (diagonal block
+    // only), and -- option panel_chain = 2 -- wherever the shape fits.
+    if (panel_chain_fits(ctx, kb, n - k, mode) && ctx->cols_final_at < 0 && (ctx->panel_chain == 2 || ctx->k4_alone || n == k + kb)) {
+        const int64_t col = col0 + k;
+        const int rc = launch_panel_chain(ctx, A + k + k * ld, ld, kb, n - k, col, mode, sub, dinv + (k / IB) * INV_ELEMS, info,
+                                          ctx->cur_cest ? ctx->cur_cest + (col - ctx_cest_col0(ctx)) / IB : nullptr);
+        if (rc == FR_OK) {
+            ++ctx->panel_chain_launches;
+            return FR_OK;
+        }
+        if (rc != 1) return rc;
+    }
     if (kb <= IB) {
         double* inv = dinv + (k / IB) * INV_ELEMS;
         FR_TRY(factor_block128(ctx, A + k + k * ld, ld, kb, col0 + k, mode, sub, inv, info, T));
@@ -510,11 +531,13 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     bool la_on_panel = false;  // ... and its remainder too, on the panel stream: the update is complete in that stream's order
     auto la_hook = [&](int64_t kk, int64_t kbb) {
         ctx->cols_final_at = -1;
+        if (ctx->panel_chain == 2 && panel_chain_fits(ctx, kbb, n - kk, mode)) return;  // (one resident launch for the whole panel: nothing becomes final early)
         if (world == 1 && ctx->ev_cols && kbb > IB && kbb % IB == 0 && n - (kk + kbb) > 0) ctx->cols_final_at = kk + kbb - IB;
     };
     auto la_first_part = [&](int64_t kk, int64_t kbb) -> int {  // on S0, behind whatever trailing update is queued there
         la_split = false;
         const int64_t after = n - (kk + kbb);
+        if (ctx->panel_chain == 2 && panel_chain_fits(ctx, kbb, n - kk, mode)) return FR_OK;
         if (!(world == 1 && ctx->ev_cols && kbb > IB && kbb % IB == 0 && after > 0)) return FR_OK;
         FR_HIP(ctx, hipStreamWaitEvent(S0, ctx->ev_cols, 0));
         const double* Pn = A + (kk + kbb) + kk * ld;
@@ -1444,7 +1467,19 @@ static int assemble_and_factor(fr_chol* c, const fr_kprog* kernel, double noise,
     // refinement runs on the whole-panel schedule (potrf_blocked), whose owner solves its panel with the refined products.
     if (ctx->refine == 0) c->refine = false;
     if (ctx->refine == 1) c->refine = true;
+    ctx->solve_timeout_seen = false;
     int st = assemble_and_factor_once(c, kernel, noise, has_eps, eps);
+    if (st == FR_HIP_ERROR && ctx->solve_timeout_seen && ctx->panel_chain && ctx->panel_chain_launches > 0 && ctx->world == 1) {
+        // a hand-off of the resident panel chain timed out (its workgroups did not get CUs side by side: another context's resident
+        // kernels on this GPU, a tool that serialises workgroups): once more on the chain of launches, which waits for nothing but
+        // stream order.  Single rank only -- a sharded factorisation is a collective, a rank must not repeat it alone.
+        ctx->solve_timeout_seen = false;
+        ++ctx->panel_chain_fallbacks;
+        const int64_t saved = ctx->panel_chain;
+        ctx->panel_chain = 0;
+        st = assemble_and_factor_once(c, kernel, noise, has_eps, eps);
+        ctx->panel_chain = saved;
+    }
     if (ctx->refine != -1 || (st != FR_OK && st != FR_NOT_POSITIVE_DEFINITE)) return st;
     const bool ill = c->max_cest > ctx->refine_threshold;
     if (!c->refine && ill) {
@@ -1616,7 +1651,14 @@ int fr_chol_from_matrix(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, in
     // upload the matrix again and factor once more with the refinement step behind every product with an inverse block
     c->refine = ctx->refine == 1;
     int st = FR_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    const int64_t chain_saved = ctx->panel_chain;
+    struct ChainRestore {
+        fr_ctx* ctx;
+        int64_t v;
+        ~ChainRestore() { ctx->panel_chain = v; }
+    } chain_restore{ctx, chain_saved};
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        ctx->solve_timeout_seen = false;
         st = upload_rows(ctx, A, lda, c->A, c->ld_a, n, n);
         if (st == FR_OK && (hipMemsetAsync(c->info, 0, sizeof(int64_t) * 3, ctx->stream) != hipSuccess ||
                             hipMemsetAsync(c->cest, 0, sizeof(double) * (size_t)((c->capacity + IB - 1) / IB), ctx->stream) != hipSuccess))
@@ -1630,7 +1672,12 @@ int fr_chol_from_matrix(fr_ctx* ctx, const double* A, int64_t n, int64_t lda, in
             ctx->cur_cest = nullptr;
         }
         if (st == FR_OK) st = chol_fetch_info(c, true);
-        if (st == FR_OK && attempt == 0 && ctx->refine == -1 && !c->refine && c->max_cest > ctx->refine_threshold) {
+        if (st == FR_HIP_ERROR && ctx->solve_timeout_seen && ctx->panel_chain && ctx->world == 1) {
+            ++ctx->panel_chain_fallbacks;  // (a timed-out hand-off of the resident panel chain: once more on the launch chain)
+            ctx->panel_chain = 0;
+            continue;
+        }
+        if (st == FR_OK && ctx->refine == -1 && !c->refine && c->max_cest > ctx->refine_threshold) {
             c->refine = true;
             continue;
         }

@@ -474,6 +474,8 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (ctx->cu_rank) (void)hipFree(ctx->cu_rank);
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->claim_ring) (void)hipFree(ctx->claim_ring);
+    if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
+    if (ctx->chain_ts) (void)hipHostFree(ctx->chain_ts);
     if (ctx->dyn_ring) (void)hipFree(ctx->dyn_ring);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
@@ -575,6 +577,11 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
         ctx->cu_reserve = value;
         return FR_OK;
     }
+    if (!strcmp(name, "panel_chain")) {
+        if (value < 0 || value > 2) return set_err(ctx, FR_INVALID_ARGUMENT, "panel_chain must be 0 (launch chain), 1 (resident chain where measured) or 2 (wherever the shape fits)");
+        ctx->panel_chain = value;
+        return FR_OK;
+    }
     if (!strcmp(name, "k4_flat")) {
         if (value < -1 || value > 1) return set_err(ctx, FR_INVALID_ARGUMENT, "k4_flat must be -1 (automatic), 0 or 1");
         ctx->k4_flat = value;
@@ -655,6 +662,20 @@ int fr_ctx_get_counter(fr_ctx* ctx, const char* name, int64_t* out)
     FR_LOCK(ctx);
     if (!strcmp(name, "solve_retries")) {
         *out = ctx->solve_retries;
+        return FR_OK;
+    }
+    if (!strncmp(name, "chain_ts:", 9)) {  // developer stamps of the last resident panel-chain launch (FRIEDRICH_AMD_CHAIN_TS=1)
+        const int i = atoi(name + 9);
+        if (!ctx->chain_ts || i < 0 || i >= 128) return set_err(ctx, FR_INVALID_ARGUMENT, "no such stamp");
+        *out = (int64_t)((volatile unsigned long long*)ctx->chain_ts)[i];
+        return FR_OK;
+    }
+    if (!strcmp(name, "panel_chain_launches")) {
+        *out = ctx->panel_chain_launches;
+        return FR_OK;
+    }
+    if (!strcmp(name, "panel_chain_fallbacks")) {
+        *out = ctx->panel_chain_fallbacks;
         return FR_OK;
     }
     if (!strcmp(name, "stale_status_drops")) {

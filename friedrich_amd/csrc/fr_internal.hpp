@@ -103,6 +103,14 @@ struct fr_ctx {
     bool trsmn_lds_set = false;
     bool prior_lds_set = false;
     bool rs16_lds_set = false;
+    bool chain_lds_set = false;
+    // resident panel chain (potf2.hip: panel_chain_kernel): progress flags of the launches in flight (a ring of blocks, values carry
+    // the launch's epoch: nothing is zeroed between launches)
+    int* chain_flags = nullptr;
+    int64_t chain_epoch = 0;
+    unsigned long long* chain_ts = nullptr;  // developer stamps of the last resident-chain launch (pinned host memory; FRIEDRICH_AMD_CHAIN_TS)
+    int64_t panel_chain = 1;       // option: diagonal kb x kb blocks (kb = 256 .. 512) factored by ONE resident launch; 0: the launch chain
+    int64_t panel_chain_launches = 0, panel_chain_fallbacks = 0;  // counters (fr_ctx_get_counter)
     // profiling
     bool prof = false;
     unsigned prof_mask = ~0u;
@@ -340,6 +348,7 @@ int kprog_check(fr_ctx* ctx, const fr_kprog* p);
 //   b_kmajor = true : element (k,n) of op(B) is B[k + n*ldb]  ("N")      false: B[n + k*ldb] ("T")
 //   lower = true: only tiles intersecting the lower triangle of the M x M result are computed (SYRK use)
 constexpr int64_t kClaimSlots = 4096;
+constexpr int64_t kChainRing = 64;  // flag blocks of the resident panel chain, by launch epoch
 
 struct GemmDesc {
     int64_t M, N, K;
@@ -383,6 +392,12 @@ bool cu_reserve_active(fr_ctx* ctx);  // the reservation in force is carried out
 //   mode 3: the block already holds a factor, only the inverse is produced
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub,
                  double* inv, int64_t ldinv, int64_t* info, double* cest = nullptr);
+
+// Resident panel chain: the kb x kb diagonal block at A (kb = 256 / 384 / 512) with its inverse blocks, and `rows - kb` rows below it
+// solved against it, in ONE launch (potf2.hip).  Returns 1 when the shape is not taken (nothing launched: the caller keeps the chain
+// of launches), FR_OK when launched.
+int launch_panel_chain(fr_ctx* ctx, double* A, int64_t lda, int64_t kb, int64_t rows, int64_t col0, int mode, double sub, double* dinv,
+                       int64_t* info, double* cest);
 
 // small helpers (elementwise / reductions)
 int launch_fill(fr_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t ld, double v);

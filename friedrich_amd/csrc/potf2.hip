@@ -37,6 +37,7 @@
 // f64 operation then queues behind the neighbour's MFMAs and an LDS round trip costs ~900 cycles instead of ~150
 // (scripts/contention_probe.hip, scripts/potf2_bench_phases.hip).
 #include "fr_internal.hpp"
+#include "handoff.hpp"
 
 namespace fr {
 
@@ -1358,14 +1359,14 @@ __device__ __forceinline__ void u_wave(double* lds, int* prog, int lane, const d
 
 }  // namespace flat
 
-__global__ __launch_bounds__(PT, 2) void potf2_flat_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
-                                                        double sub, double* __restrict__ inv, int64_t ldinv,
-                                                        int64_t* __restrict__ info, double* __restrict__ cest,
-                                                        unsigned* __restrict__ xcc_word)
+// The flat kernel's body: one full 128 x 128 block at A, its inverse to inv; all PT threads of the workgroup, `lds` = the
+// workgroup's flat::LDS_BYTES.  Called once by potf2_flat_kernel and once per diagonal block by the resident panel-chain kernel
+// (panel_chain_kernel below), which is why it is a function: the LDS image is rebuilt from scratch on every call.
+__device__ __forceinline__ void potf2_flat_body(double* __restrict__ lds, double* __restrict__ A, int64_t lda, int64_t col0, int mode,
+                                                double sub, double* __restrict__ inv, int64_t ldinv, int64_t* __restrict__ info,
+                                                double* __restrict__ cest, unsigned* __restrict__ xcc_word, const int t)
 {
     using namespace flat;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int t = threadIdx.x;
     const int lane = t & 63;
     const int hw = __builtin_amdgcn_readfirstlane(t >> 6);
     // role of hardware wave hw: 0 / 1 the block's row waves, 2 / 3 the rows of X^T, 4 .. 7 the update waves.  Waves hw and hw + 4
@@ -1475,6 +1476,338 @@ __global__ __launch_bounds__(PT, 2) void potf2_flat_kernel(double* __restrict__ 
             *cest = (dm < 0.0) ? __builtin_nan("") : wm / dm;
         }
     }
+}
+
+__global__ __launch_bounds__(PT, 2) void potf2_flat_kernel(double* __restrict__ A, int64_t lda, int n, int64_t col0, int mode,
+                                                        double sub, double* __restrict__ inv, int64_t ldinv,
+                                                        int64_t* __restrict__ info, double* __restrict__ cest,
+                                                        unsigned* __restrict__ xcc_word)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    (void)n;
+    potf2_flat_body(lds, A, lda, col0, mode, sub, inv, ldinv, info, cest, xcc_word, (int)threadIdx.x);
+}
+
+// =====================================================================================================================
+// Resident panel chain (round 6): the kb x kb diagonal block of a panel (kb = 128 J, J <= 4) -- and, optionally, rows below it --
+// factored by ONE launch instead of J diagonal-block kernels + 2 J - 2 launch-bound products (+ the one-launch solve of the rows
+// below).  Between two diagonal-block kernels of a stream sat two chip-wide launches whose matrix-core time is 3.4 us and whose
+// launch-bound time is 12.6 - 13.6 us each ("what the chain costs now"): 43 % of the chain at N = 4096, 40 %
+// of the sharded schedule's D_p.  Here the workgroups are resident and hand over through memory:
+//
+//   workgroup 0        the flat diagonal-block kernel's body (potf2_flat_body), once per 128-block j: waits until the eight slabs
+//                      of tile row j have published their rows of D_j, factors, writes L_jj and W_j = L_jj^-1, publishes "W_j".
+//   workgroup 1 + i    SLAB i: rows 128 + 16 i .. + 15 of the panel (tile row t = 1 + i / 8), resident in LDS as a strip of
+//                      16 x 128 (min(t, J) + 1) doubles for the whole launch (the layout of rows_solve16_kernel, gemm_f64.hip:
+//                      right operands as matrix-core fragments straight from memory).  LEFT-looking, everything that does not need
+//                      the newest inverse done before it arrives.  Per sub-panel q < min(t, J):
+//                          wait W_q;  S_q <- S_q W_q^T  (S_q already carries the updates of the sub-panels before);  store, publish;
+//                          t < J: wait for the eight slabs of MY tile row (their S_q): D_t rows -= S_q S_{t,q}^T; after q = t - 1 the
+//                                 rows of D_t are stored and published -- workgroup 0 takes over, the slab retires;
+//                          for every later sub-panel s: wait for tile row s's S_q:  S_s -= S_q L[s, q]^T.
+//                      Slabs of rows below the diagonal block (t >= J) only solve; nobody waits for them.
+//
+// The chain between W_q and the start of diagonal block q + 1 is then: flag -> one 16 x 128 x 128 product -> store + flag -> one
+// product -> store + flag, on the eight slabs of tile row q + 1 side by side.  Hand-offs are the agent-scope release / acquire of
+// handoff.hpp (placement-independent; every spin bounded, a timed-out launch raises the context's status word and the factorisation
+// is repeated on the launch chain).  Flags carry epoch * 16 + progress, so nothing is zeroed between launches.
+// Deterministic: every element is computed by one workgroup in a fixed order.  A slab only ever waits for workgroup 0 and for slabs
+// of tile rows <= its own, and the grid is small (1 + 8 (J - 1) + extra rows / 16 workgroups of one CU each): the launcher
+// keeps it below the CU count, the dispatcher places workgroups in order.
+namespace chain {
+
+constexpr int SSTR = 516;  // doubles per strip row (516 mod 32 = 4: rows 0..7 x four k's hit 32 distinct 8-byte banks)
+constexpr int NFLAGS = 8 + 8 * 3;  // [0] = W progress; [8 + 8 (t - 1) + i] = slab i of tile row t (t = 1 .. 3)
+constexpr size_t SLAB_LDS = sizeof(double) * 16 * SSTR;
+
+struct Args {
+    double* A;       // element (0, 0) of the diagonal block
+    int64_t lda;
+    int64_t rows;    // rows of the panel handled by this launch, counted from the block's first row (>= 128 J)
+    int J;           // 128-blocks on the diagonal
+    int64_t col0;    // global column of the block (log entries, failure column)
+    int mode;
+    double sub;
+    double* dinv;    // J inverse blocks (ld 128)
+    int64_t* info;
+    double* cest;    // J estimates (may be NULL)
+    int* flags;
+    int base;        // epoch * 16
+    unsigned* status;
+    unsigned* xcc_word;
+    int bulk_mt;     // rows below the diagonal block: 0 = resident 16-row slabs like the block's own; 2 / 4 = workgroups of 32 / 64 rows (bulk_role)
+    unsigned long long* ts;  // developer stamps (FRIEDRICH_AMD_CHAIN_TS=1, read through the counters "chain_ts:<i>"): 100 MHz wall clock; NULL in normal operation
+};
+
+// stamp slot layout: workgroup 0: [8 j + 0] D_j seen, [8 j + 1] block j factored, [8 j + 2] W_j published;
+// first slab of tile row t: [32 + 16 t + 4 q + 0] W_q seen, [+ 1] S_q published, [+ 2] tile row's S_q seen, [+ 3] product done / D published
+__device__ __forceinline__ void stamp(const Args& a, int slot)
+{
+    if (a.ts && threadIdx.x == 0) a.ts[slot] = wall_clock64();
+}
+
+// strip[:, oc .. oc + 128) (op)= strip[:, lc .. lc + 128) X^T, X element (n, k) at X[n + k ldx]; a wave owns 16 result columns
+template <bool SUB>
+__device__ __forceinline__ void slab_product(double* __restrict__ strip, int lc, const double* __restrict__ X, int64_t ldx, int oc, int wave,
+                                             int l15, int lq)
+{
+    const double* p = X + (16 * wave + l15) + (int64_t)lq * ldx;
+    double rb[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) rb[u] = p[(int64_t)(4 * u) * ldx];
+    const double* left = strip + l15 * SSTR + lc + lq;
+    // (even and odd k-groups on accumulators of their own: dependent matrix-core instructions do not issue back to back)
+    d4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const double av = left[4 * u];
+        if (u & 1) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(rb[u], av, a1, 0, 0, 0);
+        else a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(rb[u], av, a0, 0, 0, 0);
+    }
+    __syncthreads();  // every wave has read the left operand before anybody overwrites it (oc == lc: the solve)
+    a0 += a1;
+    double* out = strip + l15 * SSTR + oc + 16 * wave + lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[4 * r] = SUB ? out[4 * r] - a0[r] : a0[r];
+    __syncthreads();
+}
+
+// columns [c0, c0 + 128) of the strip -> rows r0 .. r0 + 15 of A (a column is 128 contiguous bytes)
+__device__ __forceinline__ void slab_store(const double* __restrict__ strip, double* __restrict__ A, int64_t lda, int64_t r0, int64_t rows, int c0)
+{
+    const int t = threadIdx.x, r = t & 15;
+    if (r0 + r < rows) {
+        double* dst = A + (r0 + r) + (int64_t)(c0 + (t >> 4)) * lda;
+        const double* src = strip + r * SSTR + c0 + (t >> 4);
+#pragma unroll
+        for (int c = 0; c < 128; c += 32) dst[(int64_t)c * lda] = src[c];
+    }
+}
+
+__device__ __forceinline__ void slab_role(double* __restrict__ strip, const Args& a, int slab)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t r0 = 128 + 16 * (int64_t)slab;
+    const int trow = (int)(r0 >> 7);
+    const int nsolve = trow < a.J ? trow : a.J;
+    const bool diag = trow < a.J;
+    const int ncols = 128 * (nsolve + (diag ? 1 : 0));
+    {
+        // (several loads in flight per thread)
+        const int r = t & 15;
+        const bool rok = r0 + r < a.rows;
+        const double* src = a.A + (r0 + r) + (int64_t)(t >> 4) * a.lda;
+        double* dst = strip + r * SSTR + (t >> 4);
+        for (int cb = 0; cb < ncols; cb += 128) {
+            double v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = rok ? src[(int64_t)(cb + 32 * i) * a.lda] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[cb + 32 * i] = v[i];
+        }
+    }
+    __syncthreads();
+    int* myflag = a.flags + 8 + 8 * (trow - 1) + (slab & 7);
+    const bool st = (slab & 7) == 0 && trow < 4;
+    for (int q = 0; q < nsolve; ++q) {
+        if (!handoff_wait_ge(a.flags, a.base + q + 1, a.status)) return;
+        if (st) stamp(a, 32 + 16 * trow + 4 * q + 0);
+        slab_product<false>(strip, 128 * q, a.dinv + (int64_t)q * (128 * 128), 128, 128 * q, wave, l15, lq);
+        slab_store(strip, a.A, a.lda, r0, a.rows, 128 * q);
+        if (diag) {
+            handoff_publish(myflag, a.base + q + 1);
+            if (st) stamp(a, 32 + 16 * trow + 4 * q + 1);
+            // the rows of my tile row in sub-panel q, from all eight slabs: my share of D_t
+            if (!handoff_wait_all_ge(a.flags + 8 + 8 * (trow - 1), 8, a.base + q + 1, a.status)) return;
+            if (st) stamp(a, 32 + 16 * trow + 4 * q + 2);
+            slab_product<true>(strip, 128 * q, a.A + 128 * trow + (int64_t)(128 * q) * a.lda, a.lda, 128 * trow, wave, l15, lq);
+            if (q == trow - 1) {
+                slab_store(strip, a.A, a.lda, r0, a.rows, 128 * trow);
+                handoff_publish(myflag, a.base + trow + 1);
+                if (st) stamp(a, 32 + 16 * trow + 4 * q + 3);
+                return;
+            }
+            if (st) stamp(a, 32 + 16 * trow + 4 * q + 3);
+        }
+        for (int s = q + 1; s < nsolve; ++s) {
+            if (!handoff_wait_all_ge(a.flags + 8 + 8 * (s - 1), 8, a.base + q + 1, a.status)) return;
+            slab_product<true>(strip, 128 * q, a.A + 128 * s + (int64_t)(128 * q) * a.lda, a.lda, 128 * s, wave, l15, lq);
+        }
+    }
+}
+
+// Rows BELOW the diagonal block, 16 MT of them per workgroup (MT = 2, 4): nobody inside the launch waits for them, so they need not
+// keep up with the chain row for row -- what they must not do is hold a CU each for the length of the panel at a quarter of its
+// matrix-core time (the resident 16-row slabs: N = 4096, 224 of them next to the trailing update of the panel before).  RIGHT-looking
+// over the sub-panels: step q loads the rows' sub-panel q (it carries every earlier update) into LDS, waits for W_q, solves in
+// place, stores, and applies it to the later sub-panels of its rows as read-modify-writes of memory -- a wave owns 16 result columns
+// and all MT row tiles, so one right-operand fragment feeds MT matrix-core instructions.  The workgroups wait for workgroup 0 and
+// for the diagonal block's slabs only (lower block indices), so any number of them is safe whatever the residency.
+constexpr int BSTR = 132;  // doubles per row of the LDS tile (132 mod 32 = 4)
+
+template <int MT>
+__device__ __forceinline__ void bulk_role(double* __restrict__ S, const Args& a, int64_t r0)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int ROWS = 16 * MT, CPP = PT / ROWS;  // columns per pass of the loaders
+    const int lr = t % ROWS, lc = t / ROWS;
+    const bool rok = r0 + lr < a.rows;
+    for (int q = 0; q < a.J; ++q) {
+        {
+            const double* src = a.A + (r0 + lr) + (int64_t)(128 * q + lc) * a.lda;
+            double* dst = S + lr * BSTR + lc;
+#pragma unroll 4
+            for (int c = 0; c < 128; c += CPP) dst[c] = rok ? src[(int64_t)c * a.lda] : 0.0;
+        }
+        if (!handoff_wait_ge(a.flags, a.base + q + 1, a.status)) return;  // (its barrier also closes the tile's image)
+        for (int s = q; s < a.J; ++s) {
+            const bool solve = s == q;
+            if (!solve && !handoff_wait_all_ge(a.flags + 8 + 8 * (s - 1), 8, a.base + q + 1, a.status)) return;
+            const double* X = solve ? a.dinv + (int64_t)q * (128 * 128) : a.A + 128 * s + (int64_t)(128 * q) * a.lda;
+            const int64_t ldx = solve ? 128 : a.lda;
+            const double* p = X + (16 * wave + l15) + (int64_t)lq * ldx;
+            double rb[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) rb[u] = p[(int64_t)(4 * u) * ldx];
+            d4_t acc[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = d4_t{0.0, 0.0, 0.0, 0.0};
+            const double* left = S + l15 * BSTR + lq;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(rb[u], left[16 * mt * BSTR + 4 * u], acc[mt][u & 1], 0, 0, 0);
+            if (solve) {
+                __syncthreads();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const d4_t v = acc[mt][0] + acc[mt][1];
+                    double* out = S + (16 * mt + l15) * BSTR + 16 * wave + lq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[4 * r] = v[r];
+                }
+                __syncthreads();
+                if (rok) {
+                    double* dst = a.A + (r0 + lr) + (int64_t)(128 * q + lc) * a.lda;
+                    const double* src = S + lr * BSTR + lc;
+#pragma unroll 4
+                    for (int c = 0; c < 128; c += CPP) dst[(int64_t)c * a.lda] = src[c];
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const d4_t v = acc[mt][0] + acc[mt][1];
+                    const int64_t row = r0 + 16 * mt + l15;
+                    if (row < a.rows) {
+                        double* g = a.A + row + (int64_t)(128 * s + 16 * wave + lq) * a.lda;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g[(int64_t)(4 * r) * a.lda] -= v[r];
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // this workgroup's stores, drained, before its own loads of the same rows in the next step
+    }
+}
+
+}  // namespace chain
+
+__global__ __launch_bounds__(PT, 2) void panel_chain_kernel(const chain::Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (blockIdx.x != 0) {
+        const int slab = (int)blockIdx.x - 1, ndiag = 8 * (a.J - 1);
+        if (a.bulk_mt == 0 || slab < ndiag) chain::slab_role(lds, a, slab);
+        else if (a.bulk_mt == 2) chain::bulk_role<2>(lds, a, 128 * (int64_t)a.J + 32 * (int64_t)(slab - ndiag));
+        else chain::bulk_role<4>(lds, a, 128 * (int64_t)a.J + 64 * (int64_t)(slab - ndiag));
+        return;
+    }
+#pragma nounroll
+    for (int j = 0; j < a.J; ++j) {
+        if (j > 0 && !handoff_wait_all_ge(a.flags + 8 + 8 * (j - 1), 8, a.base + j + 1, a.status)) return;
+        chain::stamp(a, 8 * j + 0);
+        // (the body's per-lane addresses are formed from an opaque copy of the thread index and of the LDS base: hoisted out of this
+        // loop they would stay live across the whole body -- 32 registers spilled, measured with -Rpass-analysis)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        potf2_flat_body(lds, a.A + (int64_t)(128 * j) * (a.lda + 1), a.lda, a.col0 + 128 * j, a.mode, a.sub, a.dinv + (int64_t)j * (128 * 128), 128,
+                        a.info, a.cest ? a.cest + j : nullptr, j == 0 ? a.xcc_word : nullptr, tid);
+        chain::stamp(a, 8 * j + 1);
+        handoff_publish(a.flags, a.base + j + 1);  // (its barrier also closes the block's LDS image before the next one is built)
+        chain::stamp(a, 8 * j + 2);
+    }
+}
+
+// The kb x kb diagonal block at A (kb = 128 J, 2 <= J <= 4) factored with its J inverse blocks, and rows - kb further rows below it
+// solved against it, in ONE launch.  FR_UNSUPPORTED_KERNEL-like contract: returns 1 when the shape is not taken (the caller keeps
+// the launch chain), FR_OK (0) when launched, an error code otherwise.
+int launch_panel_chain(fr_ctx* ctx, double* A, int64_t lda, int64_t kb, int64_t rows, int64_t col0, int mode, double sub, double* dinv,
+                       int64_t* info, double* cest)
+{
+    if (kb % PB != 0 || kb < 2 * PB || kb > 4 * PB || rows < kb || mode == 3 || !dinv || !info) return 1;
+    // rows below the diagonal block: resident 16-row slabs while they are few (they finish 4 us behind the last diagonal block), 32- or
+    // 64-row workgroups beyond (6 - 10 us behind it, a half / a quarter of the CUs)
+    const int64_t below = rows - kb;
+    static const int force_mt = getenv("FRIEDRICH_AMD_CHAIN_BULK") ? atoi(getenv("FRIEDRICH_AMD_CHAIN_BULK")) : -1;
+    const int bulk_mt = force_mt >= 0 ? force_mt : (below <= 512 ? 0 : (below <= 4096 ? 2 : 4));
+    const int64_t ndiag = (kb - PB) / 16;
+    const int64_t nslab = ndiag + (bulk_mt == 0 ? (below + 15) / 16 : (below + 16 * bulk_mt - 1) / (16 * bulk_mt));
+    // (the diagonal block's own workgroups take a CU each and wait for one another: they must be resident together; the others only
+    // wait for lower block indices)
+    if (1 + (bulk_mt == 0 ? nslab : ndiag) > ctx->num_cus - 8) return 1;
+    FR_TRY(ensure_status_word(ctx));
+    if (!ctx->chain_flags) {
+        FR_HIP(ctx, dev_malloc(ctx, (void**)&ctx->chain_flags, sizeof(int) * chain::NFLAGS * kChainRing));
+        FR_HIP(ctx, hipMemsetAsync(ctx->chain_flags, 0, sizeof(int) * chain::NFLAGS * kChainRing, ctx->ls));
+        FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+        ctx->chain_epoch = 0;
+    }
+    if (!ctx->chain_lds_set) {
+        FR_TRY(set_dyn_lds(ctx, reinterpret_cast<const void*>(panel_chain_kernel), (int)flat::LDS_BYTES));
+        ctx->chain_lds_set = true;
+    }
+    static_assert(flat::LDS_BYTES >= chain::SLAB_LDS, "the slabs' strip fits in the diagonal-block kernel's LDS");
+    if (ctx->chain_epoch >= (1 << 26)) {  // (flags carry epoch * 16 + progress in an int)
+        FR_HIP(ctx, hipDeviceSynchronize());
+        FR_HIP(ctx, hipMemset(ctx->chain_flags, 0, sizeof(int) * chain::NFLAGS * kChainRing));
+        ctx->chain_epoch = 0;
+    }
+    const int64_t e = ++ctx->chain_epoch;
+    chain::Args a;
+    a.A = A; a.lda = lda; a.rows = rows; a.J = (int)(kb / PB); a.col0 = col0; a.mode = mode; a.sub = sub; a.dinv = dinv; a.info = info;
+    a.cest = cest;
+    a.flags = ctx->chain_flags + chain::NFLAGS * (e % kChainRing);
+    a.base = (int)(e * 16);
+    a.status = ctx->dev_status;
+    a.xcc_word = ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr;
+    a.bulk_mt = bulk_mt;
+    static const bool want_ts = getenv("FRIEDRICH_AMD_CHAIN_TS") != nullptr;
+    if (want_ts && !ctx->chain_ts) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, sizeof(unsigned long long) * 128, hipHostMallocMapped) == hipSuccess) {
+            memset(h, 0, sizeof(unsigned long long) * 128);
+            ctx->chain_ts = (unsigned long long*)h;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    a.ts = nullptr;
+    if (ctx->chain_ts) {
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, ctx->chain_ts, 0) == hipSuccess) a.ts = (unsigned long long*)d;
+    }
+    const double J = (double)a.J;
+    ProfScope ps(ctx, FR_PROF_POTF2, (double)kb * kb * kb / 3.0 + (double)(rows - kb) * kb * kb, 8.0 * (double)rows * kb * 2.0 + J * 128.0 * 128.0 * 8.0);
+    hipLaunchKernelGGL(panel_chain_kernel, dim3((unsigned)(1 + nslab)), dim3(PT), flat::LDS_BYTES, ctx->ls, a);
+    FR_HIP(ctx, hipGetLastError());
+    ctx->persistent_pending = true;
+    return FR_OK;
 }
 
 int launch_potf2(fr_ctx* ctx, double* A, int64_t lda, int64_t nbk, int64_t col0, int mode, double sub, double* inv,
