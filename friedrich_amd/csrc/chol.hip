@@ -576,6 +576,31 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     // The FIRST panel too (round 5): nothing runs next to it but the early look-ahead update, which then keeps off like every
     // later one -- and the panel's diagonal blocks get the flat kernel (31 us) instead of the staged one that fits beside a GEMM
     // workgroup (48 us): 4 x 17 us of a fit of 2.3 ms at N = 4096
+    // A panel factored by ONE resident launch (panel_chain = 2) has no "all but the last 128 columns are final" moment: the whole
+    // look-ahead update (K = the panel's width) follows the launch on the PANEL stream, in front of ev_panel -- no stream hop between
+    // a panel and the next, as with the K = 128 remainder below.
+    bool ev_panel_early = false;
+    static const int64_t la_overlap_rows = getenv("FRIEDRICH_AMD_LA_OVERLAP_ROWS") ? atoll(getenv("FRIEDRICH_AMD_LA_OVERLAP_ROWS")) : 4096;
+    auto chain_panel = [&](int64_t kk, int64_t kbb) { return world == 1 && ctx->panel_chain == 2 && panel_chain_fits(ctx, kbb, n - kk, mode); };
+    auto la_full_on_panel = [&](int64_t kk, int64_t kbb, bool hop) -> int {
+        const int64_t after = n - (kk + kbb);
+        if (after <= 0) return FR_OK;
+        if (hop && (hipEventRecord(ctx->ev_la, S0) != hipSuccess || hipStreamWaitEvent(S1, ctx->ev_la, 0) != hipSuccess)) return FR_HIP_ERROR;
+        hipStream_t saved = ctx->ls;
+        ctx->ls = S1;
+        GemmDesc g;
+        g.M = after; g.N = width(after); g.K = kbb;
+        g.A = A + (kk + kbb) + kk * ld; g.lda = ld; g.a_kmajor = false;
+        g.B = g.A; g.ldb = ld; g.b_kmajor = false;
+        g.D = A + (kk + kbb) + (kk + kbb) * ld; g.ldd = ld;
+        g.Cin = g.D; g.ldcin = ld;
+        g.alpha = -1.0; g.beta = 1.0; g.lower = false; g.prof_cls = FR_PROF_GEMM_PANEL;
+        g.whole_chip = true;
+        const int st2 = launch_gemm(ctx, g);
+        ctx->ls = saved;
+        if (st2 == FR_OK) la_on_panel = true;
+        return st2;
+    };
     set_reservation(n, kb0);
     {
         if (split) {
@@ -589,8 +614,15 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
         }
         if (st != FR_OK) return fail(st);
+        if (chain_panel(0, kb0)) {
+            // (while the trailing update bounds the step it starts WITH the look-ahead update, not behind it: ev_panel first)
+            ev_panel_early = n - kb0 > la_overlap_rows;
+            if (ev_panel_early && hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
+            st = la_full_on_panel(0, kb0, false);
+            if (st != FR_OK) return fail(st);
+        }
     }
-    if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
+    if (!ev_panel_early && hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
     ctx->ls = S0;
     st = la_first_part(0, kb0);
     if (st != FR_OK) return fail(st);
@@ -654,6 +686,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         st = la_first_part(k + kb, kb2);  // (behind the trailing update on this stream; waits for the panel stream's ev_cols)
         if (st != FR_OK) return fail(st);
         la_on_panel = false;
+        ev_panel_early = false;
         if (la_split && ctx->reserve_now > 0) {
             // Chain-bound: the K = 128 remainder of the look-ahead update goes on the PANEL stream, right behind the panel it
             // completes and in front of ev_panel -- the next panel then starts in stream order, without the two stream hops
@@ -677,8 +710,13 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             la_on_panel = true;
             la_split = false;
             ctx->ls = S0;
+        } else if (chain_panel(k + kb, kb2)) {
+            ev_panel_early = n - (k + kb + kb2) > la_overlap_rows;
+            if (ev_panel_early && hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
+            st = la_full_on_panel(k + kb, kb2, true);
+            if (st != FR_OK) return fail(st);
         }
-        if (hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
+        if (!ev_panel_early && hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
     }
     ctx->ls = S0;
     ctx->reserve_now = 0;

@@ -109,7 +109,7 @@ struct fr_ctx {
     int* chain_flags = nullptr;
     int64_t chain_epoch = 0;
     unsigned long long* chain_ts = nullptr;  // developer stamps of the last resident-chain launch (pinned host memory; FRIEDRICH_AMD_CHAIN_TS)
-    int64_t panel_chain = 1;       // option: diagonal kb x kb blocks (kb = 256 .. 512) factored by ONE resident launch; 0: the launch chain
+    int64_t panel_chain = 2;       // option: panels of 256 .. 512 columns factored by ONE resident launch (potf2.hip); 2 (default): wherever the shape fits, 1: only where the launch has the chip to itself (no second stream, sharded chain), 0: the launch chain
     int64_t panel_chain_launches = 0, panel_chain_fallbacks = 0;  // counters (fr_ctx_get_counter)
     // profiling
     bool prof = false;

@@ -1514,6 +1514,9 @@ __global__ __launch_bounds__(PT, 2) void potf2_flat_kernel(double* __restrict__ 
 // Deterministic: every element is computed by one workgroup in a fixed order.  A slab only ever waits for workgroup 0 and for slabs
 // of tile rows <= its own, and the grid is small (1 + 8 (J - 1) + extra rows / 16 workgroups of one CU each): the launcher
 // keeps it below the CU count, the dispatcher places workgroups in order.
+static inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
+static inline int64_t imax64(int64_t a, int64_t b) { return a > b ? a : b; }
+
 namespace chain {
 
 constexpr int SSTR = 516;  // doubles per strip row (516 mod 32 = 4: rows 0..7 x four k's hit 32 distinct 8-byte banks)
@@ -1535,6 +1538,10 @@ struct Args {
     int base;        // epoch * 16
     unsigned* status;
     unsigned* xcc_word;
+    int place_r;     // XCD-level reservation in force: only the workgroups with blockIdx % 8 < place_r work (they run on the panel stream's
+                     // XCDs: workgroup b of a launch runs on XCD (X + b) % 8), the others exit at once; 0: every workgroup works
+    int nwork;       // working workgroups
+    int bulk_groups, bulk_workers;  // (bulk_mt != 0) row groups of 16 bulk_mt rows below the diagonal block, workgroups that share them
     int bulk_mt;     // rows below the diagonal block: 0 = resident 16-row slabs like the block's own; 2 / 4 = workgroups of 32 / 64 rows (bulk_role)
     unsigned long long* ts;  // developer stamps (FRIEDRICH_AMD_CHAIN_TS=1, read through the counters "chain_ts:<i>"): 100 MHz wall clock; NULL in normal operation
 };
@@ -1647,16 +1654,21 @@ __device__ __forceinline__ void slab_role(double* __restrict__ strip, const Args
 // for the diagonal block's slabs only (lower block indices), so any number of them is safe whatever the residency.
 constexpr int BSTR = 132;  // doubles per row of the LDS tile (132 mod 32 = 4)
 
+// `worker` of `a.bulk_workers` takes the row groups worker, worker + bulk_workers, ... through every step: with fewer workers than
+// groups a workgroup is busy for most of the panel instead of waiting for the next inverse three quarters of the time -- the
+// launcher sizes the workers to the CUs the trailing update leaves to the panel stream.
 template <int MT>
-__device__ __forceinline__ void bulk_role(double* __restrict__ S, const Args& a, int64_t r0)
+__device__ __forceinline__ void bulk_role(double* __restrict__ S, const Args& a, int worker)
 {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int ROWS = 16 * MT, CPP = PT / ROWS;  // columns per pass of the loaders
     const int lr = t % ROWS, lc = t / ROWS;
-    const bool rok = r0 + lr < a.rows;
-    for (int q = 0; q < a.J; ++q) {
+    for (int q = 0; q < a.J; ++q)
+    for (int grp = worker; grp < a.bulk_groups; grp += a.bulk_workers) {
+        const int64_t r0 = 128 * (int64_t)a.J + (int64_t)ROWS * grp;
+        const bool rok = r0 + lr < a.rows;
         {
             const double* src = a.A + (r0 + lr) + (int64_t)(128 * q + lc) * a.lda;
             double* dst = S + lr * BSTR + lc;
@@ -1721,11 +1733,17 @@ __device__ __forceinline__ void bulk_role(double* __restrict__ S, const Args& a,
 __global__ __launch_bounds__(PT, 2) void panel_chain_kernel(const chain::Args a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (blockIdx.x != 0) {
-        const int slab = (int)blockIdx.x - 1, ndiag = 8 * (a.J - 1);
+    int wg = (int)blockIdx.x;
+    if (a.place_r) {
+        if ((wg & 7) >= a.place_r) return;
+        wg = (wg >> 3) * a.place_r + (wg & 7);
+    }
+    if (wg >= a.nwork) return;
+    if (wg != 0) {
+        const int slab = wg - 1, ndiag = 8 * (a.J - 1);
         if (a.bulk_mt == 0 || slab < ndiag) chain::slab_role(lds, a, slab);
-        else if (a.bulk_mt == 2) chain::bulk_role<2>(lds, a, 128 * (int64_t)a.J + 32 * (int64_t)(slab - ndiag));
-        else chain::bulk_role<4>(lds, a, 128 * (int64_t)a.J + 64 * (int64_t)(slab - ndiag));
+        else if (a.bulk_mt == 2) chain::bulk_role<2>(lds, a, slab - ndiag);
+        else chain::bulk_role<4>(lds, a, slab - ndiag);
         return;
     }
 #pragma nounroll
@@ -1755,9 +1773,16 @@ int launch_panel_chain(fr_ctx* ctx, double* A, int64_t lda, int64_t kb, int64_t 
     // 64-row workgroups beyond (6 - 10 us behind it, a half / a quarter of the CUs)
     const int64_t below = rows - kb;
     static const int force_mt = getenv("FRIEDRICH_AMD_CHAIN_BULK") ? atoi(getenv("FRIEDRICH_AMD_CHAIN_BULK")) : -1;
-    const int bulk_mt = force_mt >= 0 ? force_mt : (below <= 512 ? 0 : (below <= 4096 ? 2 : 4));
+    const int bulk_mt = force_mt >= 0 ? force_mt : (below <= 512 ? 0 : (below <= 2048 ? 2 : 4));
     const int64_t ndiag = (kb - PB) / 16;
-    const int64_t nslab = ndiag + (bulk_mt == 0 ? (below + 15) / 16 : (below + 16 * bulk_mt - 1) / (16 * bulk_mt));
+    const int64_t groups = bulk_mt == 0 ? 0 : (below + 16 * bulk_mt - 1) / (16 * bulk_mt);
+    // workers for the rows below: one per group.  (Measured, N = 8192: 8 workers for ~90 groups -- what a one-unit reservation leaves
+    // beside the diagonal block's 25 workgroups -- make a panel 1.7 ms instead of 0.18: a worker's products are latency-bound, 16 us
+    // each where the matrix core needs 6.8, so the rows below want many workgroups in flight, not few busy ones.)
+    int64_t workers = groups;
+    static const int force_workers = getenv("FRIEDRICH_AMD_CHAIN_WORKERS") ? atoi(getenv("FRIEDRICH_AMD_CHAIN_WORKERS")) : 0;
+    if (force_workers > 0) workers = imin64(groups, force_workers);
+    const int64_t nslab = ndiag + (bulk_mt == 0 ? (below + 15) / 16 : workers);
     // (the diagonal block's own workgroups take a CU each and wait for one another: they must be resident together; the others only
     // wait for lower block indices)
     if (1 + (bulk_mt == 0 ? nslab : ndiag) > ctx->num_cus - 8) return 1;
@@ -1787,6 +1812,13 @@ int launch_panel_chain(fr_ctx* ctx, double* A, int64_t lda, int64_t kb, int64_t 
     a.status = ctx->dev_status;
     a.xcc_word = ctx->xcd_reserve != 0 ? ctx->xcc_word : nullptr;
     a.bulk_mt = bulk_mt;
+    a.bulk_groups = (int)groups;
+    a.bulk_workers = (int)(workers > 0 ? workers : 1);
+    a.nwork = (int)(1 + nslab);
+    // by XCDs (at most 4096 trailing rows, gemm_f64.hip): the launch carries 8 / R times the workgroups, those dealt to the panel
+    // stream's XCDs work.  By CUs the trailing update keeps CUs free everywhere: the workgroups go where there is room.
+    a.place_r = (ctx->reserve_now > 0 && !ctx->reserve_by_cu_now && ctx->ls == ctx->stream2 && ctx->world == 1) ? ctx->reserve_now : 0;
+    const unsigned grid = a.place_r ? (unsigned)((a.nwork + a.place_r - 1) / a.place_r * 8) : (unsigned)a.nwork;
     static const bool want_ts = getenv("FRIEDRICH_AMD_CHAIN_TS") != nullptr;
     if (want_ts && !ctx->chain_ts) {
         void* h = nullptr;
@@ -1804,7 +1836,7 @@ int launch_panel_chain(fr_ctx* ctx, double* A, int64_t lda, int64_t kb, int64_t 
     }
     const double J = (double)a.J;
     ProfScope ps(ctx, FR_PROF_POTF2, (double)kb * kb * kb / 3.0 + (double)(rows - kb) * kb * kb, 8.0 * (double)rows * kb * 2.0 + J * 128.0 * 128.0 * 8.0);
-    hipLaunchKernelGGL(panel_chain_kernel, dim3((unsigned)(1 + nslab)), dim3(PT), flat::LDS_BYTES, ctx->ls, a);
+    hipLaunchKernelGGL(panel_chain_kernel, dim3(grid), dim3(PT), flat::LDS_BYTES, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
     ctx->persistent_pending = true;
     return FR_OK;

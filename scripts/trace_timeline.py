@@ -20,7 +20,7 @@ streams = {}
 for r in fit:
     streams.setdefault(r["Stream_Id"], []).append(r)
 def short(n):
-    for k in ("syrk_lower", "potf2", "gemm_f64", "gram", "copy", "fill", "pairdist"):
+    for k in ("syrk_lower", "panel_chain", "potf2", "gemm_f64", "gram", "copy", "fill", "pairdist"):
         if k in n: return k
     return n[:20]
 for sid, rs in streams.items():
