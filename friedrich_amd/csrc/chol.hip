@@ -1369,12 +1369,12 @@ int chol_fetch_info(fr_chol* c, bool with_cest)
 {
     fr_ctx* ctx = c->ctx;
     int64_t head[3] = {0, 0, 0};
-    FR_HIP(ctx, hipMemcpyAsync(head, c->info, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
+    FR_TRY(comm_d2h(ctx, head, c->info, sizeof(head), ctx->stream, "the sharded factorisation"));
     const int64_t nblk = (c->n + IB - 1) / IB;
     std::vector<double> hc;
     if (with_cest && nblk > 0 && c->cest) {
         hc.resize((size_t)nblk);
-        FR_HIP(ctx, hipMemcpyAsync(hc.data(), c->cest, sizeof(double) * (size_t)nblk, hipMemcpyDeviceToHost, ctx->stream));
+        FR_TRY(comm_d2h(ctx, hc.data(), c->cest, sizeof(double) * (size_t)nblk, ctx->stream, "the sharded factorisation"));
     }
     FR_TRY(comm_stream_sync(ctx, ctx->stream, "the sharded factorisation"));  // (single rank: a plain hipStreamSynchronize)
     FR_TRY(check_status_word(ctx));  // a bounded device-side wait of the factorisation (hand-offs, counted tiles) gave up
@@ -1423,7 +1423,7 @@ static int merge_info(fr_chol* c)
     }
     FR_TRY(comm_allgather_i64(ctx, mine, all, (size_t)len));
     std::vector<int64_t> host((size_t)(len * W));
-    FR_HIP(ctx, hipMemcpyAsync(host.data(), all, sizeof(int64_t) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
+    FR_TRY(comm_d2h(ctx, host.data(), all, sizeof(int64_t) * host.size(), ctx->stream, "the merge of the substitution logs"));
     FR_TRY(comm_stream_sync(ctx, ctx->stream, "the merge of the substitution logs"));
     FR_TRY(check_status_word(ctx));  // a bounded device-side wait of the factorisation (hand-offs, counted tiles) gave up
     int64_t fail = -1;
@@ -1487,7 +1487,7 @@ static int fetch_max_cest(fr_chol* c)
     c->max_cest = 0.0;
     if (nblk <= 0 || !c->cest) return FR_OK;
     std::vector<double> h((size_t)nblk);
-    FR_HIP(ctx, hipMemcpyAsync(h.data(), c->cest, sizeof(double) * (size_t)nblk, hipMemcpyDeviceToHost, ctx->stream));
+    FR_TRY(comm_d2h(ctx, h.data(), c->cest, sizeof(double) * (size_t)nblk, ctx->stream, "the read-back of the conditioning estimates"));
     FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (double v : h)
         if (v > c->max_cest) c->max_cest = v;  // (NaN: a failed block, reported through fail_col)
@@ -1923,7 +1923,7 @@ int fr_chol_add_rows(fr_chol* c, const fr_kprog* kernel, const double* Xall, int
             FR_TRY(comm_allgather(ctx, ab, ab + 1, 1));
             if (ctx->world > 64) return set_err(ctx, FR_INVALID_ARGUMENT, "more than 64 ranks");
             double hm[64];
-            FR_HIP(ctx, hipMemcpyAsync(hm, ab + 1, sizeof(double) * (size_t)ctx->world, hipMemcpyDeviceToHost, ctx->stream));
+            FR_TRY(comm_d2h(ctx, hm, ab + 1, sizeof(double) * (size_t)ctx->world, ctx->stream, "add_rows: agreement on the conditioning estimate"));
             FR_TRY(comm_stream_sync(ctx, ctx->stream, "add_rows: agreement on the conditioning estimate"));
             for (int r = 0; r < ctx->world; ++r)
                 if (hm[r] > c->max_cest) c->max_cest = hm[r];
@@ -2018,7 +2018,7 @@ static int check_zero_diag(fr_chol* c, const char* what)
         FR_HIP(ctx, hipMemsetAsync(c->info + 2, 0, sizeof(int64_t), ctx->stream));
         FR_TRY(launch_diag_check_zero(ctx, c->A, c->n, c->ld_a, c->info + 2));
         int64_t flag = 0;
-        FR_HIP(ctx, hipMemcpyAsync(&flag, c->info + 2, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FR_TRY(comm_d2h(ctx, &flag, c->info + 2, sizeof(int64_t), ctx->stream, "the zero-diagonal check"));
         FR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         c->diag_zero = flag != 0;
         c->diag_gen = c->gen;

@@ -647,6 +647,13 @@ int comm_stream_sync(fr_ctx* ctx, hipStream_t s, const char* what)
                    (long long)waited, (long long)ctx->dist_schedule, ctx->rank, ctx->world);
 }
 
+int comm_d2h(fr_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s, const char* what)
+{
+    if (ctx->world > 1 && ctx->comm && !ctx->local && ctx->comm_timeout_ms > 0) FR_TRY(comm_stream_sync(ctx, s, what));
+    FR_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    return FR_OK;
+}
+
 // Every rank contributes ok (1) / failed (0); all learn whether EVERY rank is ok.  Used before the first panel exchange of a
 // sharded factorisation: a rank that could not allocate its buffers must not leave its peers waiting inside a broadcast.
 // Synchronises the launch stream (with the deadline).
@@ -659,7 +666,7 @@ int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok)
     FR_HIP(ctx, hipMemcpyAsync(ctx->agree_buf, &mine, sizeof(int64_t), hipMemcpyHostToDevice, ctx->ls));
     FR_TRY(comm_allgather_i64(ctx, ctx->agree_buf, ctx->agree_buf + 1, 1));
     std::vector<int64_t> h((size_t)ctx->world);
-    FR_HIP(ctx, hipMemcpyAsync(h.data(), ctx->agree_buf + 1, sizeof(int64_t) * h.size(), hipMemcpyDeviceToHost, ctx->ls));
+    FR_TRY(comm_d2h(ctx, h.data(), ctx->agree_buf + 1, sizeof(int64_t) * h.size(), ctx->ls, "status agreement of the ranks"));
     FR_TRY(comm_stream_sync(ctx, ctx->ls, "status agreement of the ranks"));
     for (int64_t v : h)
         if (v != 1) *all_ok = false;
@@ -712,7 +719,7 @@ int ensure_comm2(fr_ctx* ctx)
         CallGuard guard(ctx);
         FR_NCCL_G(ctx, g_rccl.Broadcast(d, d, sizeof(id2), ncclChar, 0, (ncclComm_t)ctx->comm, s));
     }
-    FR_HIP(ctx, hipMemcpyAsync(&id2, d, sizeof(id2), hipMemcpyDeviceToHost, s));
+    FR_TRY(comm_d2h(ctx, &id2, d, sizeof(id2), s, "hand-over of the second communicator's id"));
     FR_TRY(comm_stream_sync(ctx, s, "hand-over of the second communicator's id"));
     bool id_ok = false;
     for (size_t i = 0; i < sizeof(id2); ++i) id_ok = id_ok || ((const char*)&id2)[i] != 0;

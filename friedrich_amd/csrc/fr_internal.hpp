@@ -478,6 +478,10 @@ int comm_fanout(fr_ctx* ctx, double* buf, size_t count, int root, int which = 0)
 int comm_agree(fr_ctx* ctx, bool ok, bool* all_ok);  // collective: does EVERY rank report ok?  (synchronises)
 void comm_abort(fr_ctx* ctx);                        // failing rank: tear the communicator down so that peers do not wait forever
 int comm_stream_sync(fr_ctx* ctx, hipStream_t s, const char* what);  // wait for a stream that may hold collectives, with the deadline
+// device -> PAGEABLE host memory on a stream that may hold collectives: such a copy blocks the host until it is done -- behind a
+// collective whose peer never arrives, for ever, and in front of the bounded wait that was meant to find it (found by the mock-RCCL
+// test with device-side waits, round 6: 60 s in hipMemcpyAsync, no time-out counted).  Waits for the stream WITH the deadline first.
+int comm_d2h(fr_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s, const char* what);
 void comm_drain(fr_ctx* ctx);                        // after comm_abort: give the context's three streams a bounded time to empty
 void comm_destroy_internal(fr_ctx* ctx);             // fr_ctx_destroy: communicators, watchdog, events (comm.hip)
 int ensure_comm2(fr_ctx* ctx);                       // collective: the second communicator exists on every rank (created on first use)

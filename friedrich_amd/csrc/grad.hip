@@ -482,7 +482,7 @@ static int grad_terms_impl(fr_chol* c, const fr_kprog* kernel, const double* y, 
         double* all = outs + (MAXG + 8);
         FR_TRY(comm_allgather(ctx, outs, all, cnt));
         std::vector<double> hh(cnt * (size_t)Wn);
-        FR_HIP(ctx, hipMemcpyAsync(hh.data(), all, sizeof(double) * hh.size(), hipMemcpyDeviceToHost, ctx->stream));
+        FR_TRY(comm_d2h(ctx, hh.data(), all, sizeof(double) * hh.size(), ctx->stream, "the all-gather of the gradient partials"));
         FR_TRY(comm_stream_sync(ctx, ctx->stream, "the all-gather of the gradient partials"));
         for (size_t q = 0; q < cnt; ++q) {
             h[q] = 0.0;

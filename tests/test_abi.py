@@ -107,3 +107,26 @@ def test_binding_passes_leading_rows_of_a_column_major_matrix_without_a_copy():
     assert np.array_equal(c.keep, X[:6])
     one = _Mat(X[:6, :1])  # a single column: ld is irrelevant, any layout
     assert (one.rows, one.cols) == (6, 1)
+
+
+def test_rccl_mock_exports_what_the_library_resolves():
+    """tests/mock_rccl (the stand-in for librccl behind tests/test_gpu_rccl_multi.py on 1-GPU boxes) builds without a GPU and
+    defines every nccl* symbol friedrich_amd/csrc/comm.hip looks up with dlsym; the product never names it (only the environment
+    variable FRIEDRICH_AMD_RCCL_PATH of a test's child process does)."""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mock_rccl"))
+    import build_mock
+
+    lib = build_mock.build()
+    src = open(os.path.join(ROOT, "friedrich_amd", "csrc", "comm.hip")).read()
+    wanted = {"nccl" + n for n in re.findall(r"^\s*LOAD\((\w+)\);", src, flags=re.M)} | {"ncclCommGetAsyncError"}
+    assert len(wanted) >= 12, wanted
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    have = {line.split()[-1] for line in nm.splitlines() if " T " in line}
+    assert wanted <= have, wanted - have
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "friedrich_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                assert "rccl_mock" not in open(os.path.join(dirpath, f)).read(), f

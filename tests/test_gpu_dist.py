@@ -293,3 +293,35 @@ def test_panel_row_solve_kernels_match_numpy(kb, rows):
     got = Sd.cpu().numpy().T
     assert rel_err(got, want) < 1e-12
     ctx.close()
+
+
+def test_thread_rank_contexts_created_and_destroyed_under_stress():
+    """Round 5's one unexplained crash of the GPU suite (a segmentation fault inside test_sharded_cholesky_matches_oracle[...-4-...],
+    thread-ranks; DESIGN.md section 6 has the account: never reproduced, two candidate causes fixed -- a rank's ready / done events
+    destroyed while a peer still held the bare handles, and unsynchronised first-use initialisation (dynamic-LDS attributes,
+    rccl_load) from several contexts' threads).  This is the loop that would see a recurrence in the driver's suite: the 4-rank fit in
+    all three schedules, contexts (streams, events, workspaces, the group) created and destroyed by every iteration, >= 30 times."""
+    import time
+
+    k = ("matern2", 0.7, 1.2)
+    n, nb = 700, 128
+    X = rand_inputs(n, 5, n)
+    st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
+    Lref = np.tril(L_o)
+    t0 = time.perf_counter()
+    iterations = 0
+    while iterations < 30 or (time.perf_counter() - t0 < 20 and iterations < 90):
+        split = iterations % 3
+
+        def fn(ctx, rank):
+            ctx.set_option("nb", nb)
+            ctx.set_option("dist_schedule", split)
+            chol = ctx.cholesky_from_inputs(k, X, 0.1)
+            L = chol.l()
+            chol.free()
+            return L
+
+        for L in run_ranks(4, fn):
+            assert rel_err(L, Lref) < TOL
+        iterations += 1
+    assert iterations >= 30
