@@ -596,6 +596,9 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         g.Cin = g.D; g.ldcin = ld;
         g.alpha = -1.0; g.beta = 1.0; g.lower = false; g.prof_cls = FR_PROF_GEMM_PANEL;
         g.whole_chip = true;
+        // (32-row tiles while at most 4096 rows remain -- N = 4096 / 8192 fits 1.91 / 5.81 -> 1.86 / 5.69 ms; up to 8192 rows: 6.0)
+        static const int la_small = getenv("FRIEDRICH_AMD_LA_SMALL") ? atoi(getenv("FRIEDRICH_AMD_LA_SMALL")) : 4096;
+        g.force_small = la_small != 0 && after <= (int64_t)la_small;
         const int st2 = launch_gemm(ctx, g);
         ctx->ls = saved;
         if (st2 == FR_OK) la_on_panel = true;
