@@ -56,6 +56,7 @@ def measured_mfma_peak():
     except (OSError, subprocess.TimeoutExpired):
         return None
     rates = [float(v) for b, v in re.findall(r"blocks=\s*(\d+) waves/block=\d+:\s*([0-9.]+) TFLOP/s", r.stdout) if int(b) >= 256]
+    rates = [v for v in rates if 1.0 < v < 1.25 * PEAK_F64_MFMA_TFLOPS]  # (a launch that failed reads as an absurd rate)
     return max(rates) if rates else None
 
 

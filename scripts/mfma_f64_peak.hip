@@ -59,6 +59,5 @@ int main()
     run<16>(512, 256);
     run<4>(256, 256);
     run<1>(256, 256);
-    run<8>(256, 512);
     return 0;
 }
