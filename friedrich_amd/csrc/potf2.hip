@@ -1839,6 +1839,10 @@ int launch_panel_chain(fr_ctx* ctx, double* A, int64_t lda, int64_t kb, int64_t 
     hipLaunchKernelGGL(panel_chain_kernel, dim3(grid), dim3(PT), flat::LDS_BYTES, ctx->ls, a);
     FR_HIP(ctx, hipGetLastError());
     ctx->persistent_pending = true;
+    if (ctx->test_force_timeout) {  // test hook: behave as if a hand-off of this launch had timed out
+        FR_HIP(ctx, hipStreamSynchronize(ctx->ls));
+        ((volatile unsigned*)ctx->host_status)[0] = 1u;
+    }
     return FR_OK;
 }
 

@@ -51,6 +51,13 @@ def test_throughput_kernels_do_not_spill():
         assert v["ScratchSize"] <= 128 and v["Occupancy"] >= 2, (name, v)
     rs16 = [v for n, v in r.items() if "rows_solve16" in n]
     assert rs16 and rs16[0]["ScratchSize"] == 0, rs16  # (the LDS-resident panel-row solve keeps 64 fragment registers in flight)
+    # the resident panel chain (round 6): the flat diagonal-block body inside a loop next to the slab / row-group roles -- with the body's
+    # per-lane addresses hoisted out of that loop it spilled 32 registers (124 B per lane) and the diagonal block took 38 us instead of 28
+    p = resources("potf2.hip")
+    chain = [v for n, v in p.items() if "panel_chain_kernel" in n]
+    assert chain and chain[0]["ScratchSize"] == 0 and chain[0]["Occupancy"] >= 2, chain
+    flat = [v for n, v in p.items() if "potf2_flat_kernel" in n]
+    assert flat and flat[0]["ScratchSize"] == 0, flat
     g = resources("gram.hip")
     leaf = [v for n, v in g.items() if "gram_kernel" in n and "ILi1ELi2" in n]  # the squared-exponential leaf of the bench
     assert leaf and all(v["ScratchSize"] == 0 for v in leaf), g
