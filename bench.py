@@ -36,8 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_NB = 1024  # block size of the run profiles/r05/fit32k_counters.json was collected with
-PMC_FILE = os.path.join("profiles", "r05", "fit32k_counters.json")
+PMC_NB = 1024  # block size of the run profiles/r06/fit32k_counters.json was collected with
+PMC_FILE = os.path.join("profiles", "r06", "fit32k_counters.json")
 PEAK_F64_MFMA_TFLOPS = 78.6  # MI355X datasheet FP64 matrix peak; measured_mfma_peak() times the instruction loop on the box (77.0-77.6)
 MFMA_PEAK_PROBE = os.path.join(ROOT, "friedrich_amd", "lib", "mfma_f64_peak")  # scripts/mfma_f64_peak.hip, built by friedrich_amd/build.py
 
@@ -162,7 +162,7 @@ def cpu_baseline(n, d, m, cfg):
 # the critical-path model of the chain-first schedule at N = 32768, nb = 512, W = 8 (microseconds per
 # panel; compute terms measured on one idle GPU, transfers priced at 45 GB/s per xGMI link + 20 us per RCCL call) -- printed
 # next to the measured per-class times of an N > 1 run so that the first scaling curve says where its time went
-MODEL_TERMS_US = {"diag_block_D_p": 226, "R1_solve": 54, "M_p_fanout": 65, "u1": 34, "chain_step": 390,  # profiles/r05/dist_model.txt
+MODEL_TERMS_US = {"diag_block_D_p": 226, "R1_solve": 54, "M_p_fanout": 65, "u1": 34, "chain_step": 390,  # profiles/r06/dist_model.txt
                   "bulk_latency_first": 980, "bulk_latency_last": 390, "rank_share_of_update_k0": 1070,
                   "predicted_fit_ms_8gpus": "38-41 (schedule 2), ~65 (schedule 1), 100-130 (schedule 0)"}
 
@@ -425,7 +425,7 @@ def run_rank(args, link, device_index, emit, mode):
         pmc_path = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc_path) and (n, d, nb_eff, world) == (32768, 16, PMC_NB, 1):
             with open(pmc_path) as f:
-                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: tests/test_profiles_fresh.py fails when gemm_f64.hip / gemm_tile.hpp changed after the passes (scripts/profile_r05.sh)
+                traffic = json.load(f)["kernels"]["fr::syrk_lower_f64_kernel"]["total_bytes_per_launch"]  # same kernel code as this build: tests/test_profiles_fresh.py fails when gemm_f64.hip / gemm_tile.hpp changed after the passes (scripts/profile_r06.sh)
             traffic_src = PMC_FILE
         if not sharded:
             parallelism = "1 GPU"

@@ -120,6 +120,15 @@ const char* fr_last_error(const fr_ctx* ctx);
  *                    no second stream, sharded chain -- and by the staged variant that fits beside a GEMM workgroup elsewhere; 0 / 1:
  *                    one variant throughout.  The two round differently (both within the parity tolerance): a factor is a
  *                    function of the input AND of the options that select kernels
+ *   "panel_chain"    2 (default): a panel of 256 / 384 / 512 columns -- its diagonal block with the inverse blocks, and the rows below
+ *                    it -- is factored by ONE resident launch (potf2.hip: panel_chain_kernel: the flat diagonal-block body on one
+ *                    workgroup, 16-row slabs resident in LDS that hand over through memory, 32- / 64-row workgroups for the rows
+ *                    below) instead of kb / 128 diagonal-block kernels and 2 kb / 128 - 1 launch-bound products; the look-ahead
+ *                    update then follows on the panel stream.  1: only where the launch has its CUs to itself (no second stream:
+ *                    small matrices, the Schur block of fr_chol_add_rows; the diagonal blocks of a sharded factorisation); 0: the
+ *                    chain of launches.  A hand-off that times out (the workgroups did not get CUs side by side) raises the status
+ *                    word; the factorisation is then repeated on the chain of launches (counter "panel_chain_fallbacks").  Like
+ *                    "k4_flat" the option selects kernels: the factor is the same to round-off (1e-13), not to the bit
  *   "dist_schedule"  sharded (multi-GPU) factorisation, how a panel step travels: 0 = the owner solves the whole panel, one
  *                    broadcast; 1 (default) = diagonal block broadcast, rows below scattered / solved per rank / all-gathered;
  *                    2 = as 1 with the chain of diagonal blocks running ahead of the bulk rows on a second communicator
@@ -153,7 +162,8 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value);
 /* Observability: "solve_retries" = how often an entry point of this context repeated its work on the recursive path because a
  * persistent solve gave up on a hand-off (0 in normal operation); "comm_timeouts" = how often a wait for a collective ran out; "stale_status_drops" = time-outs
  * left unread by an entry point that returned early and dropped by the next one;
- * "pool_bytes" = bytes held by the workspace pool.
+ * "pool_bytes" = bytes held by the workspace pool; "panel_chain_launches" / "panel_chain_fallbacks" = resident panel launches taken /
+ * factorisations repeated on the chain of launches after one of them timed out.
  * Environment read when a context is created (operators / tests; none is needed in normal use):
  *   FRIEDRICH_AMD_DIST_SCHEDULE = 0 | 1 | 2, FRIEDRICH_AMD_COMM_TIMEOUT_MS   the options of the same name without touching the host program
  *   FRIEDRICH_AMD_RCCL_PATH         the librccl to dlopen (it has to match the process's HIP runtime)
