@@ -205,7 +205,18 @@ __device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double*
         const long long tlin = item;
         if (tlin < 0) return;
         int64_t tm, tn;
-        if (g.lower) {
+        if (g.lower && g.sig_tiles > 0) {
+            // column-major over the lower triangle: column c holds T - c tiles, cum(c) = c T - c (c - 1) / 2
+            const int64_t T = g.tiles_m;
+            const double b = 2.0 * (double)T + 1.0;
+            int64_t c = (int64_t)((b - sqrt(b * b - 8.0 * (double)tlin)) * 0.5);
+            if (c < 0) c = 0;
+            if (c > T - 1) c = T - 1;
+            while (c > 0 && c * T - c * (c - 1) / 2 > tlin) --c;
+            while (c + 1 < T && (c + 1) * T - (c + 1) * c / 2 <= tlin) ++c;
+            tn = c;
+            tm = c + (tlin - (c * T - c * (c - 1) / 2));
+        } else if (g.lower) {
             int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
             while (row * (row + 1) / 2 > tlin) --row;
             while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
@@ -224,6 +235,20 @@ __device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double*
         asm volatile("" : "+s"(gt.lda), "+s"(gt.ldb), "+s"(gt.ldd), "+s"(gt.ldcin));
         asm volatile("" : "+s"(gt.A), "+s"(gt.B), "+s"(gt.D), "+s"(gt.Cin));
         gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, tm * BM, n0);
+        if (g.sig_tiles > 0 && tlin < g.sig_tiles) {
+            // a tile of the look-ahead part: stored, released, counted; the last one tells the waiting stream
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned got = __hip_atomic_fetch_add(g.sig_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int64_t)got == g.sig_tiles - 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                    __hip_atomic_store(g.sig, g.sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
     }
 }
 
@@ -690,6 +715,11 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.tri = d.tri;
     g.cu_rank = nullptr;
     g.ncu_res = 0;
+    g.sig_tiles = 0;
+    g.sig_count = nullptr;
+    g.sig = nullptr;
+    g.sig_value = 0;
+    ctx->la_signal_armed = false;
     int64_t persist_grid = 0;
     const bool by_cu = ctx->reserve_now && cu_reserve_active(ctx);
     if (by_cu) {
@@ -714,6 +744,14 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
             g.max_exit = (unsigned)(me > 0 ? me : 0);
             persist_grid = G;
             use_super = false;
+            if (d.sig_cols > 0 && d.lower && d.sig && ctx->la_count) {
+                const int64_t T = g.tiles_m, c = d.sig_cols < T ? d.sig_cols : T;
+                g.sig_tiles = c * T - c * (c - 1) / 2;
+                g.sig_count = ctx->la_count + (ctx->claim_next - 1);
+                g.sig = d.sig;
+                g.sig_value = d.sig_value;
+                ctx->la_signal_armed = true;
+            }
         }
     } else if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip) {
         if (ctx->ls == ctx->stream2) {
