@@ -162,9 +162,9 @@ def cpu_baseline(n, d, m, cfg):
 # the critical-path model of the chain-first schedule at N = 32768, nb = 512, W = 8 (microseconds per
 # panel; compute terms measured on one idle GPU, transfers priced at 45 GB/s per xGMI link + 20 us per RCCL call) -- printed
 # next to the measured per-class times of an N > 1 run so that the first scaling curve says where its time went
-MODEL_TERMS_US = {"diag_block_D_p": 226, "R1_solve": 54, "M_p_fanout": 65, "u1": 34, "chain_step": 390,  # profiles/r06/dist_model.txt
+MODEL_TERMS_US = {"diag_block_D_p": 156, "R1_solve": 52, "M_p_fanout": 65, "u1": 34, "chain_step": 320,  # profiles/r06/dist_model.txt (D_p: ONE resident launch)
                   "bulk_latency_first": 980, "bulk_latency_last": 390, "rank_share_of_update_k0": 1070,
-                  "predicted_fit_ms_8gpus": "38-41 (schedule 2), ~65 (schedule 1), 100-130 (schedule 0)"}
+                  "predicted_fit_ms_8gpus": "35-38 (schedule 2), ~60 (schedule 1), 100-130 (schedule 0)"}
 
 
 def run_rank(args, link, device_index, emit, mode):

@@ -881,18 +881,32 @@ def test_cu_level_reservation_same_bits(ctx, n):
     X = rand_inputs(n, 3, 99 + n)
     st, L_o, _ = O.make_cholesky_cov_matrix(k, X, 0.1)
     chol = ctx.cholesky_from_inputs(k, X, 0.1)
-    L_cu = chol.l()
-    assert rel_err(L_cu, np.tril(L_o)) < TOL
     try:
-        for opts in ({"cu_reserve": 0}, {"cu_reserve": 1, "reserve_rows2_cu": 8192}, {"cu_reserve": 1, "cu_reserve_min_rows": 1024},
-                     {"cu_reserve": 1, "xcd_reserve": 1}, {"cu_reserve": 1, "xcd_reserve": 4}, {"cu_reserve": 1}):
-            for o, v in {"cu_reserve": 1, "reserve_rows2_cu": 6144, "reserve_rows1_cu": 12288, "cu_reserve_min_rows": 4096, "xcd_reserve": -1, **opts}.items():
-                ctx.set_option(o, v)
-            for rep in range(2):
-                chol.refactor(k, 0.1)
-                assert np.array_equal(chol.l(), L_cu), opts
+        # panel_chain = 0: the launch chain of round 5 -- the property above, bit for bit.  panel_chain = 2 (round 6, the default): by CUs
+        # the rows below a resident panel's diagonal block take the one-launch row solve (left-looking: one accumulation per sub-panel)
+        # and look-ahead + trailing update are one launch; by XCDs they stay inside the resident launch (right-looking): the same
+        # products summed in a different order -- equal to round-off, and each setting reproducible bit for bit
+        for chain in (0, 2):
+            ctx.set_option("panel_chain", chain)
+            chol.refactor(k, 0.1)
+            L_cu = chol.l()
+            assert rel_err(L_cu, np.tril(L_o)) < TOL
+            for opts in ({"cu_reserve": 0}, {"cu_reserve": 1, "reserve_rows2_cu": 8192}, {"cu_reserve": 1, "cu_reserve_min_rows": 1024},
+                         {"cu_reserve": 1, "xcd_reserve": 1}, {"cu_reserve": 1, "xcd_reserve": 4}, {"cu_reserve": 1}):
+                for o, v in {"cu_reserve": 1, "reserve_rows2_cu": 6144, "reserve_rows1_cu": 12288, "cu_reserve_min_rows": 4096, "xcd_reserve": -1, **opts}.items():
+                    ctx.set_option(o, v)
+                first = None
+                for rep in range(2):
+                    chol.refactor(k, 0.1)
+                    L = chol.l()
+                    if chain == 0:
+                        assert np.array_equal(L, L_cu), opts
+                    else:
+                        assert rel_err(L, L_cu) < 1e-12, opts
+                        assert first is None or np.array_equal(L, first), opts
+                        first = L
     finally:
-        for o, v in {"cu_reserve": 1, "reserve_rows2_cu": 6144, "cu_reserve_min_rows": 4096, "xcd_reserve": -1}.items():
+        for o, v in {"cu_reserve": 1, "reserve_rows2_cu": 6144, "cu_reserve_min_rows": 4096, "xcd_reserve": -1, "panel_chain": 2}.items():
             ctx.set_option(o, v)
     chol.free()
 
