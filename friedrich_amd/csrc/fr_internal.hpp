@@ -142,7 +142,10 @@ struct fr_ctx {
     bool la_signal_failed = false;   // no stream-wait-value on this device / runtime: look-ahead and trailing update stay two launches
     bool la_signal_armed = false;    // (set by launch_gemm: the last launch carries the signal request)
     unsigned la_signal_value = 0;
-    int64_t la_fused = 1;            // option: look-ahead update and trailing update as one resident launch where the reservation is by CUs
+    int64_t la_fused = 0;            // option (opt-in): look-ahead update and trailing update as one resident launch where the reservation is by
+                                     // CUs, the next panel started through a stream-wait word (chol.hip); measured N = 8192 / 12288 / 16384 fits
+                                     // 5.73 / 14.57 / 29.45 -> 5.73 / 13.87 / 28.48 ms -- off by default: `rocprofv3 --pmc` of a fit did not
+                                     // finish with it (the one tool run of round 6 that was killed by its time limit: DESIGN.md section 5)
     int64_t claim_next = 0;
     bool refine_now = false;      // state of the running operation (set under the context lock)
     double* cur_cest = nullptr;   // where the diagonal-block kernel of the running factorisation puts its estimates

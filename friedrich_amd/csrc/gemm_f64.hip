@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g
 // workgroups (which have to wait for a slot on the busy XCDs before they can exit: scripts/dispatch_probe.hip).  Every tile is
 // computed whole by one workgroup with the arithmetic of the one-tile-per-workgroup launch: the same bits.
 // Own kernel symbols: the loop around the tile function costs registers the one-tile kernels must not pay (see MIRROR above).
-template <bool A_KMAJ, bool B_KMAJ>
+// SIG: the variant that claims the lower triangle column by column and signals when its first sig_tiles tiles are done (the fused
+// look-ahead + trailing update, option la_fused) -- a kernel symbol of its own: the extra state costs the loop 44 B of scratch per lane,
+// which the launches that do not signal must not pay (tests/test_kernel_resources.py)
+template <bool A_KMAJ, bool B_KMAJ, bool SIG = false>
 __device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double* lds)
 {
     __shared__ long long item;
@@ -205,7 +208,7 @@ __device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double*
         const long long tlin = item;
         if (tlin < 0) return;
         int64_t tm, tn;
-        if (g.lower && g.sig_tiles > 0) {
+        if (SIG && g.lower && g.sig_tiles > 0) {
             // column-major over the lower triangle: column c holds T - c tiles, cum(c) = c T - c (c - 1) / 2
             const int64_t T = g.tiles_m;
             const double b = 2.0 * (double)T + 1.0;
@@ -235,7 +238,7 @@ __device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double*
         asm volatile("" : "+s"(gt.lda), "+s"(gt.ldb), "+s"(gt.ldd), "+s"(gt.ldcin));
         asm volatile("" : "+s"(gt.A), "+s"(gt.B), "+s"(gt.D), "+s"(gt.Cin));
         gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, tm * BM, n0);
-        if (g.sig_tiles > 0 && tlin < g.sig_tiles) {
+        if (SIG && g.sig_tiles > 0 && tlin < g.sig_tiles) {
             // a tile of the look-ahead part: stored, released, counted; the last one tells the waiting stream
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -256,6 +259,12 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_persist_f64_kernel(const Ge
 {
     __shared__ double lds[4 * TILE_ELEMS];
     gemm_f64_persist_body<false, false>(g, lds);
+}
+
+__global__ __launch_bounds__(256, 2) void syrk_lower_persist_sig_f64_kernel(const GemmArgs g)
+{
+    __shared__ double lds[4 * TILE_ELEMS];
+    gemm_f64_persist_body<false, false, true>(g, lds);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_f64_persist_kernel(const GemmArgs g)
@@ -818,6 +827,8 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         hipLaunchKernelGGL((gemm_f64_m32_kernel<true, true>), grid, block, 0, ctx->ls, g);
     else if (small)
         hipLaunchKernelGGL((gemm_f64_m32_kernel<true, false>), grid, block, 0, ctx->ls, g);
+    else if (g.place == 3 && d.lower && g.sig_tiles > 0)
+        hipLaunchKernelGGL(syrk_lower_persist_sig_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (g.place == 3 && d.lower)
         hipLaunchKernelGGL(syrk_lower_persist_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (g.place == 3)
