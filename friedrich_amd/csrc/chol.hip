@@ -92,12 +92,7 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
     // resident -- in ONE launch instead of kb / 128 diagonal-block kernels and 2 kb / 128 - 1 launch-bound products.  Taken where the
     // launch has CUs of its own: no second stream (small matrices, the Schur block of an append), the sharded chain (diagonal block
     // only), and -- option panel_chain = 2 -- wherever the shape fits.
-    // (inside a WIDER panel -- the recursion's 512-column halves of a 1024- / 2048-column panel, experiment FRIEDRICH_AMD_CHAIN_WIDE --
-    // the sub-panel is taken when the "columns final" mark of the look-ahead pipeline does not fall inside it)
-    static const int chain_wide = getenv("FRIEDRICH_AMD_CHAIN_WIDE") ? atoi(getenv("FRIEDRICH_AMD_CHAIN_WIDE")) : 0;
-    const bool in_wide = ctx->cols_final_at >= 0;
-    if (panel_chain_fits(ctx, kb, n - k, mode) && (!in_wide || (chain_wide && ctx->panel_chain == 2 && kb == 4 * IB && ctx->cols_final_at >= k + kb)) &&
-        (ctx->panel_chain == 2 || ctx->k4_alone || n == k + kb)) {
+    if (panel_chain_fits(ctx, kb, n - k, mode) && ctx->cols_final_at < 0 && (ctx->panel_chain == 2 || ctx->k4_alone || n == k + kb)) {
         const int64_t col = col0 + k;
         // Next to a RESIDENT trailing update (reservation by CUs) the launch only finds the few CUs that update vacates, and its
         // workgroups take a whole CU each (the diagonal-block body's LDS): the rows below then leave the launch for the one-launch
@@ -106,13 +101,12 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
         static const int64_t bulk_out_env = getenv("FRIEDRICH_AMD_CHAIN_BULK_OUT") ? atoll(getenv("FRIEDRICH_AMD_CHAIN_BULK_OUT")) : -1;
         const int64_t bulk_out = bulk_out_env >= 0 ? bulk_out_env : ctx->la_fused;
         const int64_t below = n - k - kb;
-        const bool bulk_inside = !(below > 0 && (in_wide || (bulk_out && ctx->reserve_now > 0 && ctx->reserve_by_cu_now && ctx->ls == ctx->stream2)));
+        const bool bulk_inside = !(bulk_out && below > 0 && ctx->reserve_now > 0 && ctx->reserve_by_cu_now && ctx->ls == ctx->stream2);
         const int rc = launch_panel_chain(ctx, A + k + k * ld, ld, kb, bulk_inside ? n - k : kb, col, mode, sub, dinv + (k / IB) * INV_ELEMS, info,
                                           ctx->cur_cest ? ctx->cur_cest + (col - ctx_cest_col0(ctx)) / IB : nullptr);
         if (rc == FR_OK) {
             ++ctx->panel_chain_launches;
             if (!bulk_inside) FR_TRY(launch_rows_solve(ctx, A + (k + kb) + k * ld, ld, below, A + k + k * ld, ld, kb, dinv + (k / IB) * INV_ELEMS));
-            if (in_wide && ctx->cols_final_at == k + kb && ctx->ev_cols) FR_HIP(ctx, hipEventRecord(ctx->ev_cols, ctx->ls));
             return FR_OK;
         }
         if (rc != 1) return rc;
