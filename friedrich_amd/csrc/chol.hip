@@ -94,19 +94,10 @@ static int factor_panel(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t k
     // only), and -- option panel_chain = 2 -- wherever the shape fits.
     if (panel_chain_fits(ctx, kb, n - k, mode) && ctx->cols_final_at < 0 && (ctx->panel_chain == 2 || ctx->k4_alone || n == k + kb)) {
         const int64_t col = col0 + k;
-        // Next to a RESIDENT trailing update (reservation by CUs) the launch only finds the few CUs that update vacates, and its
-        // workgroups take a whole CU each (the diagonal-block body's LDS): the rows below then leave the launch for the one-launch
-        // row solve (rows_solve16_kernel: two workgroups to a CU, no waiting), which follows the diagonal block in stream order.
-        // (only with the fused update, option la_fused: alone it costs more than it gives -- N = 8192 / 12288 / 16384 6.05 / 15.08 / 29.9 ms)
-        static const int64_t bulk_out_env = getenv("FRIEDRICH_AMD_CHAIN_BULK_OUT") ? atoll(getenv("FRIEDRICH_AMD_CHAIN_BULK_OUT")) : -1;
-        const int64_t bulk_out = bulk_out_env >= 0 ? bulk_out_env : ctx->la_fused;
-        const int64_t below = n - k - kb;
-        const bool bulk_inside = !(bulk_out && below > 0 && ctx->reserve_now > 0 && ctx->reserve_by_cu_now && ctx->ls == ctx->stream2);
-        const int rc = launch_panel_chain(ctx, A + k + k * ld, ld, kb, bulk_inside ? n - k : kb, col, mode, sub, dinv + (k / IB) * INV_ELEMS, info,
+        const int rc = launch_panel_chain(ctx, A + k + k * ld, ld, kb, n - k, col, mode, sub, dinv + (k / IB) * INV_ELEMS, info,
                                           ctx->cur_cest ? ctx->cur_cest + (col - ctx_cest_col0(ctx)) / IB : nullptr);
         if (rc == FR_OK) {
             ++ctx->panel_chain_launches;
-            if (!bulk_inside) FR_TRY(launch_rows_solve(ctx, A + (k + kb) + k * ld, ld, below, A + k + k * ld, ld, kb, dinv + (k / IB) * INV_ELEMS));
             return FR_OK;
         }
         if (rc != 1) return rc;
@@ -277,7 +268,7 @@ static int potrf_dist_chain(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64
     if (!hb || !mb || !sb) return FR_OUT_OF_MEMORY;
     if (!all_ok) return set_err(ctx, FR_OUT_OF_MEMORY, "a peer rank could not allocate its panel buffers: sharded factorisation abandoned on every rank");
     if (ctx->xcd_reserve != 0 && ctx->claim_ring) {
-        FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 3 * kClaimSlots, S0));
+        FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 2 * kClaimSlots, S0));
         ctx->claim_next = 0;
     }
     int st = FR_OK;
@@ -499,7 +490,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     const bool cu_ok = ctx->cu_reserve != 0 && ctx->xcd_reserve != 0 && cu_table_ready(ctx);  // (builds the CU rank table on first use: one small launch + a synchronisation, here rather than between two panels)
     if (world == 1 && ctx->xcd_reserve != 0 && ctx->claim_ring) {
         // claim counters of the launches that keep off the panel stream's XCD (gemm_f64.hip): one pair per launch
-        FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 3 * kClaimSlots, S0));
+        FR_HIP(ctx, hipMemsetAsync(ctx->claim_ring, 0, sizeof(unsigned) * 2 * kClaimSlots, S0));
         ctx->claim_next = 0;
     }
     auto fail = [&](int code) {
@@ -536,7 +527,6 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     // columns of a panel are final (the leaf before the last says so through ev_cols), the main stream applies those columns'
     // part of the update (K = kb - 128) while the panel stream still factors the last block; what remains between the panels
     // is the K = 128 part.  Single GPU only (the sharded schedules have their own look-ahead).
-    auto chain_panel_fits_at = [&](int64_t kk, int64_t kbb) { return world == 1 && ctx->panel_chain == 2 && panel_chain_fits(ctx, kbb, n - kk, mode); };
     bool la_split = false;  // the first part of the update by the panel just finished has been issued
     bool la_on_panel = false;  // ... and its remainder too, on the panel stream: the update is complete in that stream's order
     auto la_hook = [&](int64_t kk, int64_t kbb) {
@@ -558,12 +548,10 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
     };
     // once the panel chain is longer than the trailing update, the update's launches leave XCDs / CUs to the panel stream
     // (gemm_f64.hip / gemm_tile.hpp: claim_item, gemm_f64_persist_body); `remaining` = rows from the panel about to be factored on
-    auto set_reservation = [&](int64_t remaining, int64_t kbw, bool dry = false) -> bool {  // dry: -> "would be by CUs", nothing changes
-        const int saved_now = ctx->reserve_now;
-        const bool saved_cu = ctx->reserve_by_cu_now;
+    auto set_reservation = [&](int64_t remaining, int64_t kbw) {
         ctx->reserve_now = 0;
         ctx->reserve_by_cu_now = false;
-        if (!dry) ++ctx->panel_epoch;
+        ++ctx->panel_epoch;
         if (world == 1 && ctx->claim_ring) {
             if (ctx->xcd_reserve < 0) {
                 // measured (scripts/xcd_reserve_ab.py): N = 4096 / 8192 / 16384 fit -3 / -9 / -6 %; with nb = 1024 the panel's
@@ -584,40 +572,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             }
             ctx->reserve_by_cu_now = cu_ok && ctx->reserve_now > 0 && remaining > ctx->cu_reserve_min_rows;
         }
-        const bool by_cu = ctx->reserve_by_cu_now && ctx->reserve_now > 0;
-        if (dry) {
-            ctx->reserve_now = saved_now;
-            ctx->reserve_by_cu_now = saved_cu;
-        }
-        return by_cu;
     };
-    // Look-ahead update and trailing update as ONE resident launch (round 6): where the reservation is by CUs the trailing update is
-    // a single round of resident workgroups that claim tiles -- column by column, the next panel's columns first -- and the launch
-    // itself tells the panel stream when those columns are done (a stream-wait word: hipStreamWaitValue32, 2 - 3 us from the store
-    // to the waiting stream's next kernel, scripts/waitvalue_probe.hip).  Neither a second launch on the few CUs the reservation
-    // leaves, nor a stream hop, nor a main stream that waits for the panel behind every update (N = 16384: 120 - 180 us per step).
-    auto signal_ready = [&]() -> bool {
-        if (!ctx->la_fused || ctx->la_signal_failed) return false;
-        if (!ctx->la_signal) {
-            int can = 0;
-            (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device);
-            void* sp = nullptr;
-            if (!can || hipExtMallocWithFlags(&sp, 8, hipMallocSignalMemory) != hipSuccess || hipMemset(sp, 0, 8) != hipSuccess) {
-                (void)hipGetLastError();
-                ctx->la_signal_failed = true;
-                return false;
-            }
-            ctx->la_signal = (unsigned*)sp;
-            ctx->la_signal_value = 0;
-        }
-        return true;
-    };
-    // the update by the panel that ends in front of `first` (rows / columns from `first` on), its next panel `kbn` columns wide
-    auto will_fuse = [&](int64_t first, int64_t kbn) -> bool {
-        const int64_t remaining = n - first;
-        return world == 1 && remaining > kbn && kbn % IB == 0 && chain_panel_fits_at(first, kbn) && set_reservation(remaining, kbn, true) && signal_ready();
-    };
-    bool la_fused_now = false;  // the look-ahead update of the panel just factored rides in its trailing update (issued at the top of the next round)
     // The FIRST panel too (round 5): nothing runs next to it but the early look-ahead update, which then keeps off like every
     // later one -- and the panel's diagonal blocks get the flat kernel (31 us) instead of the staged one that fits beside a GEMM
     // workgroup (48 us): 4 x 17 us of a fit of 2.3 ms at N = 4096
@@ -662,9 +617,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             if (st == FR_OK && world > 1) st = exchange_panel(ctx, A, ld, n, 0, kb0, dinv, pbuf, owner_of(0, nb, world));
         }
         if (st != FR_OK) return fail(st);
-        if (chain_panel(0, kb0) && will_fuse(kb0, width(n - kb0))) {
-            la_fused_now = true;
-        } else if (chain_panel(0, kb0)) {
+        if (chain_panel(0, kb0)) {
             // (while the trailing update bounds the step it starts WITH the look-ahead update, not behind it: ev_panel first)
             ev_panel_early = n - kb0 > la_overlap_rows;
             if (ev_panel_early && hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);
@@ -687,27 +640,6 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         // (gemm_f64.hip / gemm_tile.hpp: claim_item)
         set_reservation(rest, kb2);
         const bool own_next = world == 1 || rank == owner_of(k + kb, nb, world);
-        const bool fused = la_fused_now;
-        la_fused_now = false;
-        if (fused) {
-            // ONE lower-mode launch over everything below the panel; its first kb2 / 128 tile columns -- the next panel's -- signal
-            GemmDesc g;
-            g.M = rest; g.N = rest; g.K = kb;
-            g.A = P; g.lda = ld; g.a_kmajor = false;
-            g.B = P; g.ldb = ld; g.b_kmajor = false;
-            g.D = A + (k + kb) + (k + kb) * ld; g.ldd = ld;
-            g.Cin = g.D; g.ldcin = ld;
-            g.alpha = -1.0; g.beta = 1.0; g.lower = true; g.prof_cls = FR_PROF_SYRK;
-            g.sig_cols = (kb2 + IB - 1) / IB;
-            g.sig = ctx->la_signal;
-            g.sig_value = ++ctx->la_signal_value;
-            st = launch_gemm(ctx, g);
-            if (st != FR_OK) return fail(st);
-            // (a launch that did not take the request -- no claim slot left -- is followed by the signal in stream order)
-            if (!ctx->la_signal_armed && hipStreamWriteValue32(S0, ctx->la_signal, g.sig_value, 0) != hipSuccess) return fail(FR_HIP_ERROR);
-            if (hipStreamWaitValue32(S1, ctx->la_signal, g.sig_value, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) return fail(FR_HIP_ERROR);
-            la_on_panel = true;  // (nothing more to issue or to wait for in front of the next panel)
-        }
         // look-ahead part of the trailing update: the next panel's columns (all rows below the current block)
         if (own_next && !la_on_panel) {
             // (profile class: panel -- the SYRK class times exactly the syrk_lower_f64_kernel launches)
@@ -740,7 +672,7 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
         if (st != FR_OK) return fail(st);
         ctx->ls = S0;
         const int64_t rest2 = rest - kb2;
-        if (rest2 > 0 && !fused) {
+        if (rest2 > 0) {
             // K6: the rest of the trailing update runs under the next panel; multi-GPU: owned block columns only
             const double* P2 = P + kb2;
             GemmDesc g;
@@ -781,8 +713,6 @@ static int potrf_blocked(fr_ctx* ctx, double* A, int64_t ld, int64_t n, int64_t 
             la_on_panel = true;
             la_split = false;
             ctx->ls = S0;
-        } else if (chain_panel(k + kb, kb2) && will_fuse(k + kb + kb2, width(n - (k + kb + kb2)))) {
-            la_fused_now = true;
         } else if (chain_panel(k + kb, kb2)) {
             ev_panel_early = n - (k + kb + kb2) > la_overlap_rows;
             if (ev_panel_early && hipEventRecord(ctx->ev_panel, S1) != hipSuccess) return fail(FR_HIP_ERROR);

@@ -441,12 +441,11 @@ int fr_ctx_create(fr_ctx** out, int device)
         return FR_HIP_ERROR;
     }
     if (hipMalloc((void**)&ctx->xcc_word, 64) != hipSuccess || hipMemset(ctx->xcc_word, 0, 64) != hipSuccess ||
-        hipMalloc((void**)&ctx->claim_ring, sizeof(unsigned) * 3 * kClaimSlots) != hipSuccess ||
+        hipMalloc((void**)&ctx->claim_ring, sizeof(unsigned) * 2 * kClaimSlots) != hipSuccess ||
         hipMalloc((void**)&ctx->dyn_ring, sizeof(unsigned) * 2 * 256) != hipSuccess) {
         fr_ctx_destroy(ctx);
         return FR_HIP_ERROR;
     }
-    ctx->la_count = ctx->claim_ring + 2 * kClaimSlots;
     *out = ctx;
     return FR_OK;
 }
@@ -476,7 +475,6 @@ void fr_ctx_destroy(fr_ctx* ctx)
     if (ctx->host_status) (void)hipHostFree(ctx->host_status);
     if (ctx->claim_ring) (void)hipFree(ctx->claim_ring);
     if (ctx->chain_flags) (void)hipFree(ctx->chain_flags);
-    if (ctx->la_signal) (void)hipFree(ctx->la_signal);
     if (ctx->chain_ts) (void)hipHostFree(ctx->chain_ts);
     if (ctx->dyn_ring) (void)hipFree(ctx->dyn_ring);
     if (ctx->stream3) {
@@ -577,11 +575,6 @@ int fr_ctx_set_option(fr_ctx* ctx, const char* name, int64_t value)
     if (!strcmp(name, "cu_reserve")) {
         if (value != 0 && value != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "cu_reserve must be 0 or 1");
         ctx->cu_reserve = value;
-        return FR_OK;
-    }
-    if (!strcmp(name, "la_fused")) {
-        if (value != 0 && value != 1) return set_err(ctx, FR_INVALID_ARGUMENT, "la_fused must be 0 or 1");
-        ctx->la_fused = value;
         return FR_OK;
     }
     if (!strcmp(name, "panel_chain")) {

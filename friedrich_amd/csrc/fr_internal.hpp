@@ -137,15 +137,6 @@ struct fr_ctx {
     unsigned* dyn_ring = nullptr;    // device: counter pairs of `dynamic` launches outside a factorisation, zeroed one by one
     int64_t dyn_next = 0;
     unsigned* claim_ring = nullptr;  // device: {tile counter, retire counter} per reserved launch of a factorisation
-    unsigned* la_count = nullptr;    // device: per launch slot, the finished tiles of the look-ahead part of a fused trailing update
-    unsigned* la_signal = nullptr;   // signal memory: the word such a launch writes and the panel stream waits for (hipStreamWaitValue32)
-    bool la_signal_failed = false;   // no stream-wait-value on this device / runtime: look-ahead and trailing update stay two launches
-    bool la_signal_armed = false;    // (set by launch_gemm: the last launch carries the signal request)
-    unsigned la_signal_value = 0;
-    int64_t la_fused = 0;            // option (opt-in): look-ahead update and trailing update as one resident launch where the reservation is by
-                                     // CUs, the next panel started through a stream-wait word (chol.hip); measured N = 8192 / 12288 / 16384 fits
-                                     // 5.73 / 14.57 / 29.45 -> 5.73 / 13.87 / 28.48 ms -- off by default: `rocprofv3 --pmc` of a fit did not
-                                     // finish with it (the one tool run of round 6 that was killed by its time limit: DESIGN.md section 5)
     int64_t claim_next = 0;
     bool refine_now = false;      // state of the running operation (set under the context lock)
     double* cur_cest = nullptr;   // where the diagonal-block kernel of the running factorisation puts its estimates
@@ -388,12 +379,6 @@ struct GemmDesc {
     int64_t kslice = 0, k_total = 0;  // (set by the split-K path: slice length and whole contraction of the batched launch)
     bool mirror = false;       // a workgroup takes row tile i and then row tile (last - i): equal work per workgroup with a triangular left operand
     bool force_small = false;  // 32-row tiles whatever the tile count, triangular operands included (the big solve leaves: chol.hip)
-    // lower mode, resident launch (CU-level reservation): the first sig_cols tile columns are computed first and, once complete, the
-    // launch writes sig_value to the stream-wait word sig (gemm_tile.hpp: GemmArgs::sig_tiles).  fr_ctx::la_signal_armed says whether
-    // the launch took the request (otherwise the caller signals behind the launch, in stream order)
-    int64_t sig_cols = 0;
-    unsigned* sig = nullptr;
-    unsigned sig_value = 0;
 };
 int launch_gemm(fr_ctx* ctx, const GemmDesc& g);
 // S (rows x kb, ld lds_) <- S L^-T against a factored kb x kb diagonal block and its 128-block inverses: one launch (gemm_f64.hip)

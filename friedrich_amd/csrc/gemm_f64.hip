@@ -180,10 +180,7 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_f64_kernel(const GemmArgs g
 // workgroups (which have to wait for a slot on the busy XCDs before they can exit: scripts/dispatch_probe.hip).  Every tile is
 // computed whole by one workgroup with the arithmetic of the one-tile-per-workgroup launch: the same bits.
 // Own kernel symbols: the loop around the tile function costs registers the one-tile kernels must not pay (see MIRROR above).
-// SIG: the variant that claims the lower triangle column by column and signals when its first sig_tiles tiles are done (the fused
-// look-ahead + trailing update, option la_fused) -- a kernel symbol of its own: the extra state costs the loop 44 B of scratch per lane,
-// which the launches that do not signal must not pay (tests/test_kernel_resources.py)
-template <bool A_KMAJ, bool B_KMAJ, bool SIG = false>
+template <bool A_KMAJ, bool B_KMAJ>
 __device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double* lds)
 {
     __shared__ long long item;
@@ -208,18 +205,7 @@ __device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double*
         const long long tlin = item;
         if (tlin < 0) return;
         int64_t tm, tn;
-        if (SIG && g.lower && g.sig_tiles > 0) {
-            // column-major over the lower triangle: column c holds T - c tiles, cum(c) = c T - c (c - 1) / 2
-            const int64_t T = g.tiles_m;
-            const double b = 2.0 * (double)T + 1.0;
-            int64_t c = (int64_t)((b - sqrt(b * b - 8.0 * (double)tlin)) * 0.5);
-            if (c < 0) c = 0;
-            if (c > T - 1) c = T - 1;
-            while (c > 0 && c * T - c * (c - 1) / 2 > tlin) --c;
-            while (c + 1 < T && (c + 1) * T - (c + 1) * c / 2 <= tlin) ++c;
-            tn = c;
-            tm = c + (tlin - (c * T - c * (c - 1) / 2));
-        } else if (g.lower) {
+        if (g.lower) {
             int64_t row = (int64_t)((sqrt(8.0 * (double)tlin + 1.0) - 1.0) * 0.5);
             while (row * (row + 1) / 2 > tlin) --row;
             while ((row + 1) * (row + 2) / 2 <= tlin) ++row;
@@ -238,20 +224,6 @@ __device__ __forceinline__ void gemm_f64_persist_body(const GemmArgs& g, double*
         asm volatile("" : "+s"(gt.lda), "+s"(gt.ldb), "+s"(gt.ldd), "+s"(gt.ldcin));
         asm volatile("" : "+s"(gt.A), "+s"(gt.B), "+s"(gt.D), "+s"(gt.Cin));
         gemm_f64_tile<A_KMAJ, B_KMAJ>(gt, lds, tm * BM, n0);
-        if (SIG && g.sig_tiles > 0 && tlin < g.sig_tiles) {
-            // a tile of the look-ahead part: stored, released, counted; the last one tells the waiting stream
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned got = __hip_atomic_fetch_add(g.sig_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int64_t)got == g.sig_tiles - 1) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-                    __hip_atomic_store(g.sig, g.sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-        }
     }
 }
 
@@ -259,12 +231,6 @@ __global__ __launch_bounds__(256, 2) void syrk_lower_persist_f64_kernel(const Ge
 {
     __shared__ double lds[4 * TILE_ELEMS];
     gemm_f64_persist_body<false, false>(g, lds);
-}
-
-__global__ __launch_bounds__(256, 2) void syrk_lower_persist_sig_f64_kernel(const GemmArgs g)
-{
-    __shared__ double lds[4 * TILE_ELEMS];
-    gemm_f64_persist_body<false, false, true>(g, lds);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_f64_persist_kernel(const GemmArgs g)
@@ -724,11 +690,6 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
     g.tri = d.tri;
     g.cu_rank = nullptr;
     g.ncu_res = 0;
-    g.sig_tiles = 0;
-    g.sig_count = nullptr;
-    g.sig = nullptr;
-    g.sig_value = 0;
-    ctx->la_signal_armed = false;
     int64_t persist_grid = 0;
     const bool by_cu = ctx->reserve_now && cu_reserve_active(ctx);
     if (by_cu) {
@@ -753,14 +714,6 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
             g.max_exit = (unsigned)(me > 0 ? me : 0);
             persist_grid = G;
             use_super = false;
-            if (d.sig_cols > 0 && d.lower && d.sig && ctx->la_count) {
-                const int64_t T = g.tiles_m, c = d.sig_cols < T ? d.sig_cols : T;
-                g.sig_tiles = c * T - c * (c - 1) / 2;
-                g.sig_count = ctx->la_count + (ctx->claim_next - 1);
-                g.sig = d.sig;
-                g.sig_value = d.sig_value;
-                ctx->la_signal_armed = true;
-            }
         }
     } else if (ctx->reserve_now && d.batch <= 1 && !d.whole_chip) {
         if (ctx->ls == ctx->stream2) {
@@ -827,8 +780,6 @@ static int launch_gemm_plain(fr_ctx* ctx, const GemmDesc& d)
         hipLaunchKernelGGL((gemm_f64_m32_kernel<true, true>), grid, block, 0, ctx->ls, g);
     else if (small)
         hipLaunchKernelGGL((gemm_f64_m32_kernel<true, false>), grid, block, 0, ctx->ls, g);
-    else if (g.place == 3 && d.lower && g.sig_tiles > 0)
-        hipLaunchKernelGGL(syrk_lower_persist_sig_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (g.place == 3 && d.lower)
         hipLaunchKernelGGL(syrk_lower_persist_f64_kernel, grid, block, 0, ctx->ls, g);
     else if (g.place == 3)

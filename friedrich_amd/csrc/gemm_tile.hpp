@@ -60,14 +60,6 @@ struct GemmArgs {
     // the last slice may be shorter and ragged); the triangular restriction above is applied in the coordinates of the whole
     // contraction (0: not sliced)
     int64_t kslice, k_total;
-    // place 3, lower mode, sig_tiles > 0: the tiles are claimed COLUMN by column (the next panel's columns first) and the first
-    // sig_tiles of them -- the look-ahead part of a trailing update -- count themselves done (sig_count); the last one writes sig_value
-    // to the stream-wait word the panel stream waits for (hipStreamWaitValue32), so the next panel starts while the rest of the
-    // update still runs: look-ahead update and trailing update are ONE launch (round 6)
-    int64_t sig_tiles;
-    unsigned* sig_count;
-    unsigned* sig;
-    unsigned sig_value;
 };
 
 // element (x, k) of an operand tile; x is the m (or n) index inside the 128-wide tile

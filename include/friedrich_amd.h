@@ -129,11 +129,6 @@ const char* fr_last_error(const fr_ctx* ctx);
  *                    chain of launches.  A hand-off that times out (the workgroups did not get CUs side by side) raises the status
  *                    word; the factorisation is then repeated on the chain of launches (counter "panel_chain_fallbacks").  Like
  *                    "k4_flat" the option selects kernels: the factor is the same to round-off (1e-13), not to the bit
- *   "la_fused"       0 (default) / 1: with "panel_chain" = 2, while the trailing update runs as resident workgroups (reservation by CUs),
- *                    look-ahead update and trailing update are ONE launch whose first tile columns -- the next panel's -- announce
- *                    themselves to the panel stream through a stream-wait word (hipStreamWaitValue32); the rows below a resident
- *                    panel's diagonal block then take the one-launch row solve.  Measured N = 12288 / 16384 fits 14.57 / 29.45 ->
- *                    13.87 / 28.48 ms; opt-in: a `rocprofv3 --pmc` pass of a fit did not finish with it
  *   "dist_schedule"  sharded (multi-GPU) factorisation, how a panel step travels: 0 = the owner solves the whole panel, one
  *                    broadcast; 1 (default) = diagonal block broadcast, rows below scattered / solved per rank / all-gathered;
  *                    2 = as 1 with the chain of diagonal blocks running ahead of the bulk rows on a second communicator

@@ -37,7 +37,7 @@ done
 for W in "fit32k|python scripts/fit_only.py 32768 2" "config2|python scripts/config_run.py 2"; do
   tag=${W%%|*}; cmd=${W#*|}
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o s -- $cmd > /dev/null 2>&1
-  # (every counter pass under its own time limit: the pass of round 6's fused build -- option la_fused, off by default since -- never
+  # (every counter pass under its own time limit: the pass of round 6's fused build -- history: tag fused-la-opt-in -- never
   # finished and took the whole call's 3000 s with it)
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -o f -- $cmd > /dev/null 2>&1 || echo "PMC pass FETCH_SIZE of $tag: rc $?"
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -o w -- $cmd > /dev/null 2>&1 || echo "PMC pass WRITE_SIZE of $tag: rc $?"
@@ -47,11 +47,4 @@ cp $(find gpurun_out/fit32k_stats -name "*kernel_stats.csv" | head -1) $O/fit32k
 python scripts/summarise_counters.py fit32k $O/fit32k_counters.json "two fits (Gram + blocked Cholesky) at N=32768 d=16 RBF, automatic panel widths (2048 / 1024 / 512), scripts/fit_only.py 32768 2, one rocprofv3 --pmc pass per counter group" | head -5
 python scripts/summarise_counters.py config2 $O/config2_counters.json "BASELINE configs[2]: N=16384 d=16 Matern-5/2 + cholesky_epsilon, fit x3 + predict(m=1024) x2 + predict_variance x2 (scripts/config_run.py 2), one rocprofv3 --pmc pass per counter group" | head -8
 rm -rf $O/*_stats gpurun_out/fit32k_* gpurun_out/config2_*
-# the opt-in fused update under the counter tool, bounded: does the pass finish?
-for f in 0 1; do
-  timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_t -o f -- python scripts/fit_only.py 16384 1 --la_fused=$f > /dev/null 2>&1
-  echo "rocprofv3 --pmc FETCH_SIZE of a fit at N = 16384 with la_fused = $f: exit code $? (124 = killed by the 150 s limit)" >> $O/la_fused_under_pmc.txt
-  rm -rf gpurun_out/pmc_t
-done
-cat $O/la_fused_under_pmc.txt
 ls $O

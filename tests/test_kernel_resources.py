@@ -45,13 +45,10 @@ def test_throughput_kernels_do_not_spill():
     # the resident variants of round 5 (a loop around the tile function): the loop costs per-lane address arithmetic that is hoisted
     # out of it and reloaded at the start of a tile -- 100 B of scratch per lane, none of it inside the K-loop (ISA inspected);
     # more than that means the accumulators or the prefetch registers have started to spill.  Two workgroups per CU as well.
-    persist = {n: v for n, v in r.items() if "persist" in n and "persist_sig" not in n}
+    persist = {n: v for n, v in r.items() if "persist" in n}
     assert len(persist) == 2, sorted(r)
     for name, v in persist.items():
         assert v["ScratchSize"] <= 128 and v["Occupancy"] >= 2, (name, v)
-    # (round 6: the opt-in variant that signals when its look-ahead tiles are done -- a symbol of its own so that the two above keep theirs)
-    sig = [v for n, v in r.items() if "persist_sig" in n]
-    assert len(sig) == 1 and sig[0]["ScratchSize"] <= 160 and sig[0]["Occupancy"] >= 2, sig
     rs16 = [v for n, v in r.items() if "rows_solve16" in n]
     assert rs16 and rs16[0]["ScratchSize"] == 0, rs16  # (the LDS-resident panel-row solve keeps 64 fragment registers in flight)
     # the resident panel chain (round 6): the flat diagonal-block body inside a loop next to the slab / row-group roles -- with the body's
